@@ -1,0 +1,88 @@
+"""Pins oracle/mink_maps.c (C restatement) against brute-force numpy/python sets."""
+import numpy as np
+import pytest
+
+from helpers import shell_scene
+
+
+def _coords(seed, batch=2, negative=False):
+    out = []
+    for b in range(batch):
+        xyz, _ = shell_scene(seed + b, grid=16, negative=negative)
+        out.append(np.concatenate([np.full((len(xyz), 1), b), xyz], 1))
+    return np.concatenate(out).astype(np.int32)
+
+
+def test_kernel_offsets_order(oracle_maps):
+    off = oracle_maps.kernel_offsets(3, 2)
+    assert off.shape == (27, 3)
+    # x fastest, z slowest; z-axis line = kernel indices 4, 13, 22 (sparse_conv.py:375-379)
+    assert off[4].tolist() == [0, 0, -2] and off[13].tolist() == [0, 0, 0] and off[22].tolist() == [0, 0, 2]
+    assert off[0].tolist() == [-2, -2, -2] and off[1].tolist() == [0, -2, -2] and off[3].tolist() == [-2, 0, -2]
+    off2 = oracle_maps.kernel_offsets(2, 4)
+    assert off2.tolist() == [[0, 0, 0], [4, 0, 0], [0, 4, 0], [4, 4, 0], [0, 0, 4], [4, 0, 4], [0, 4, 4], [4, 4, 4]]
+    assert oracle_maps.kernel_offsets(1, 8).tolist() == [[0, 0, 0]]
+
+
+def test_quantize_is_floor_not_trunc(oracle_maps):
+    f = np.array([[0, -0.5, 1.5, -1.0], [1, 2.999, -2.001, 0.0]], np.float32)
+    assert oracle_maps.quantize(f).tolist() == [[0, -1, 1, -1], [1, 2, -3, 0]]
+
+
+@pytest.mark.parametrize("negative", [False, True])
+def test_unique_first_occurrence(oracle_maps, negative):
+    c = _coords(0, negative=negative)
+    rng = np.random.default_rng(1)
+    dup = np.concatenate([c, c[rng.integers(0, len(c), 200)]])
+    dup = dup[rng.permutation(len(dup))]
+    ui, inv = oracle_maps.unique(dup)
+    ui_b, inv_b = oracle_maps.unique_bruteforce(dup)
+    assert np.array_equal(ui, ui_b) and np.array_equal(inv, inv_b)
+    assert np.all(np.diff(ui) > 0)  # first-occurrence order
+    assert np.array_equal(dup[ui][inv], dup)
+
+
+def test_unique_empty_and_range(oracle_maps):
+    ui, inv = oracle_maps.unique(np.zeros((0, 4), np.int32))
+    assert ui.size == 0 and inv.size == 0
+    with pytest.raises(RuntimeError):
+        oracle_maps.unique(np.array([[0, 40000, 0, 0]], np.int32))
+
+
+@pytest.mark.parametrize("negative", [False, True])
+@pytest.mark.parametrize("ts", [2, 4, 8])
+def test_stride_map(oracle_maps, negative, ts):
+    c = _coords(3, negative=negative)
+    if ts > 2:
+        c, _ = oracle_maps.stride_map(c, ts // 2)
+    oc, i2o = oracle_maps.stride_map(c, ts)
+    oc_b, i2o_b = oracle_maps.stride_map_bruteforce(c, ts)
+    assert np.array_equal(oc, oc_b) and np.array_equal(i2o, i2o_b)
+    assert np.all(oc[:, 1:] % ts == 0)
+    assert len(np.unique(oc, axis=0)) == len(oc)
+    # floor semantics for negatives
+    assert np.all(oc[i2o][:, 1:] <= c[:, 1:]) and np.all(c[:, 1:] - oc[i2o][:, 1:] < ts)
+
+
+@pytest.mark.parametrize("ksize,stride", [(3, 1), (3, 2), (1, 2), (2, 2)])
+def test_kernel_map(oracle_maps, ksize, stride):
+    cin = _coords(5, negative=True)
+    cout = cin if stride == 1 else oracle_maps.stride_map(cin, stride)[0]
+    off = oracle_maps.kernel_offsets(ksize, 1)
+    nbr = oracle_maps.kernel_map_table(cin, cout, off)
+    assert np.array_equal(nbr, oracle_maps.kernel_map_bruteforce(cin, cout, off))
+    lists = oracle_maps.table_to_lists(nbr)
+    for k, io in lists.items():
+        assert np.array_equal(cin[io[0]][:, 1:], cout[io[1]][:, 1:] + off[k])
+        assert np.all(np.diff(io[1]) > 0)
+    if ksize == 2:  # pooling region == stride map (each input row has exactly one parent)
+        i2o = oracle_maps.stride_map(cin, 2)[1]
+        got = np.full(len(cin), -1)
+        for k, io in lists.items():
+            got[io[0]] = io[1]
+        assert np.array_equal(got, i2o)
+    if ksize == 3 and stride == 1:  # centre offset is the identity, map is symmetric
+        assert np.array_equal(nbr[:, 13], np.arange(len(cin)))
+        for k in range(27):
+            v = nbr[:, k] >= 0
+            assert np.array_equal(nbr[nbr[v, k], 26 - k], np.nonzero(v)[0])
