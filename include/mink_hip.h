@@ -1,0 +1,198 @@
+/*
+ * mink_hip.h -- C ABI of libmink_hip.so: the MI355X (gfx950) native backend for the
+ * sparse-3D-convolution classification hot path of POSTECH-CVLab/NeRF-Downstream
+ * (co3d_3d/train.py -> Mink-ResNet14/34 on PeRFception-CO3D plenoxel grids).
+ *
+ * The reference has no C FFI of its own for this path: its seam is the Python module
+ * API of the third-party MinkowskiEngine (ME), whose native backend
+ * (`MinkowskiEngineBackend._C`, imported by the reference at
+ * co3d_3d/src/models/mink/modules/sparse_conv.py:7-12) is what these entry points
+ * replace.  Each declaration cites the reference call site(s) it serves; paths are
+ * relative to /root/reference.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless named `*_host`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued asynchronously on it, nothing here synchronises the device;
+ *   - the caller owns every buffer (no hidden allocations, no global state) so the
+ *     library is safe to call from a graph-captured or multi-stream host;
+ *   - return value 0 = success, otherwise a negative MINK_E* code and
+ *     mink_last_error() (thread-local) describes the failure;
+ *   - coordinates are int32 rows (batch, x, y, z); row counts are int64; feature
+ *     matrices are row-major fp32 with an explicit leading dimension (`ld*`, in
+ *     elements) so channel-padded layouts (e.g. 27 -> 28) need no copy;
+ *   - a "neighbour table" nbr[n_out][K] (int32, -1 = no neighbour) is the
+ *     output-stationary form of ME's kernel map: nbr[o][k] = input row located at
+ *     coordinate(o) + offset(k).  K = kernel volume, offsets enumerated x fastest /
+ *     z slowest (k = (dx+1) + 3(dy+1) + 9(dz+1) for a 3^3 kernel; witness
+ *     sparse_conv.py:375-379).
+ */
+#ifndef MINK_HIP_H
+#define MINK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MINK_OK 0
+#define MINK_EINVAL (-1)   /* bad argument (shape / alignment / NULL) */
+#define MINK_ELAUNCH (-2)  /* HIP launch or runtime error */
+
+/* Device-side status word bits (written by the coordinate kernels into `status`). */
+#define MINK_STATUS_RANGE 1u     /* a coordinate fell outside the packable range */
+#define MINK_STATUS_UNSORTED 2u  /* batch column is not non-decreasing */
+
+const char *mink_last_error(void);
+int mink_abi_version(void);
+
+/* ------------------------------------------------------------------ coordinate maps
+ * Coordinate hash map: open addressing, linear probing, 64-bit packed keys
+ * (16 bits each for batch | x+2^15 | y+2^15 | z+2^15), int32 values.
+ * Replaces ME's CoordinateMapCPU/GPU (insert_and_map / stride / kernel_map) behind
+ * ME.TensorField(...).sparse() (models/mink/base_model.py:10-13, models/mink/resnet.py:164)
+ * and behind every MinkowskiConvolution / MinkowskiSumPooling forward
+ * (modules/common.py:116-125, resnet.py:62-64).
+ */
+
+/* Number of hash slots (power of two) required for `n` keys. */
+int64_t mink_table_capacity(int64_t n);
+
+/* Bytes of scratch required by mink_coords_unique for `n` rows. */
+int64_t mink_unique_workspace_bytes(int64_t n);
+
+/* Key generation.  mode 0: float field rows (b,x,y,z) -> floor() (ME A1 quantisation);
+ * mode 1: int32 rows copied; both then floor each spatial coordinate to a multiple of
+ * `out_ts` (>=1; 1 = identity) which is ME's stride map key functor
+ * (CoordinateMap::stride, used by sparse_conv.py:403-405).
+ * keys[n] receives the packed keys; *status |= MINK_STATUS_RANGE on overflow. */
+int mink_coords_make_keys(const void *coords, int mode, int64_t n, int32_t out_ts, uint64_t *keys,
+                          uint32_t *status, void *stream);
+
+/* insert_and_map with FIRST-OCCURRENCE row numbering (what ME's CPU insert_and_map
+ * yields for TensorField.sparse(); the same order is used for stride maps, see
+ * DESIGN.md "row order").
+ *   table_keys[cap], table_vals[cap] : the hash map (cap = mink_table_capacity(n));
+ *                                      on return vals hold the unique row id
+ *   out_coords[n][4]   : coordinates of the unique rows (first n_unique rows valid)
+ *   unique_index[n]    : first input row of each unique row
+ *   inverse[n]         : unique row of every input row (the stride map in2out)
+ *   n_unique           : device int32 scalar
+ */
+int mink_coords_unique(const uint64_t *keys, int64_t n, uint64_t *table_keys, int32_t *table_vals,
+                       int64_t cap, int32_t *out_coords, int32_t *unique_index, int32_t *inverse,
+                       int32_t *n_unique, void *workspace, void *stream);
+
+/* Kernel map as a neighbour table: for every output row o and offset k probe the INPUT
+ * map at out_coords[o] + offsets[k].  offsets_host[K][3] are already scaled by
+ * dilation * input tensor stride.  If nbr_t != NULL it must be pre-filled with -1
+ * ([n_in][K]) and receives the transposed table nbr_t[i][k] = o (used by dgrad).
+ * Replaces CoordinateMapManager::kernel_map (witness for the Python-visible format:
+ * sparse_conv.py:90-96,124-143). */
+int mink_kernel_map(const uint64_t *in_table_keys, const int32_t *in_table_vals, int64_t in_cap,
+                    const int32_t *out_coords, int64_t n_out, const int32_t *offsets_host, int32_t K,
+                    int32_t *nbr, int32_t *nbr_t, void *stream);
+
+/* ME-format rulebook from a neighbour table: per offset k the (in,out) pairs ordered
+ * by output row, built with wave64 ballot + prefix sums.
+ *   counts[K+1]      : exclusive scan of pairs per offset (device, int32)
+ *   pairs_in/out[P]  : concatenated lists (P <= n_out*K), may be NULL to only count
+ *   workspace        : >= mink_rulebook_workspace_bytes(n_out, K)
+ */
+int64_t mink_rulebook_workspace_bytes(int64_t n_out, int32_t K);
+int mink_rulebook(const int32_t *nbr, int64_t n_out, int32_t K, int32_t *counts, int32_t *pairs_in,
+                  int32_t *pairs_out, void *workspace, void *stream);
+
+/* Row ranges of each batch index in a coordinate list whose batch column is
+ * non-decreasing (guaranteed by ME.utils.sparse_collate, data/utils.py:25-30).
+ * batch_offsets[B+1].  Sets MINK_STATUS_UNSORTED otherwise.  (ME origin_map.) */
+int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *batch_offsets,
+                       uint32_t *status, void *stream);
+
+/* ------------------------------------------------------------------ sparse convolution
+ * Replaces ME ConvolutionForward/BackwardKernel behind ME.MinkowskiConvolution
+ * (modules/common.py:116-125; the algorithm is re-stated by the reference at
+ * sparse_conv.py:122-144): out[o] = sum_k in[nbr[o][k]] @ W[k]  (+ bias).
+ */
+
+/* Output-stationary gather-GEMM on the fp32 matrix cores.
+ *   x[.. ][ldx], cin   : gathered operand
+ *   w                  : w_transposed == 0:  w[K][cin][cout]   (forward)
+ *                        w_transposed == 1:  w[K][cout][cin]   (dgrad: pass the forward
+ *                                            kernel and swap cin/cout)
+ *   flip_k             : use w[K-1-k] for table column k (dgrad of a stride-1 conv
+ *                        re-uses the forward table: nbr_t[i][k] == nbr[i][K-1-k])
+ *   nbr[n_out][K]      : neighbour table;  y[n_out][ldy] receives cout columns
+ *   bias[cout] or NULL
+ *   ksplit             : >1 splits the K offsets over `ksplit` workgroups per tile and
+ *                        reduces through `workspace` (ksplit*n_out*cout floats)
+ */
+/* Split-K factor the library recommends for a layer (1 for large row counts). */
+int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout);
+int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
+                          int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, float *y,
+                          int32_t ldy, int32_t cout, const float *bias, int32_t ksplit,
+                          float *workspace, void *stream);
+
+/* Weight gradient dW[k] = X[nbr[.][k]]^T @ dY, split over row blocks and reduced
+ * deterministically (no atomics).  workspace >= mink_conv_wgrad_workspace_bytes(). */
+int64_t mink_conv_wgrad_workspace_bytes(int64_t n_out, int32_t K, int32_t cin, int32_t cout);
+int mink_conv_wgrad(const float *x, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
+                    const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace,
+                    void *stream);
+
+/* ------------------------------------------------------------------ pooling / reductions
+ * MinkowskiSumPooling(k=2,s=2) (resnet.py:62-64): out[o] = sum_k in[nbr[o][k]] with the
+ * 2^3 children table; backward dIn[i] = dOut[in2out[i]].
+ */
+int mink_pool_sum_fwd(const float *x, int32_t ldx, int32_t C, const int32_t *nbr, int64_t n_out, int32_t K,
+                      float *y, void *stream);
+int mink_pool_sum_bwd(const float *dy, int32_t C, const int32_t *in2out, int64_t n_in, float *dx,
+                      void *stream);
+
+/* MinkowskiGlobalAvgPooling (resnet.py:15-22,175): y[b] = mean of rows
+ * [batch_offsets[b], batch_offsets[b+1]); backward dx[i] = dy[b]/N_b. */
+int mink_global_avg_fwd(const float *x, int32_t C, const int32_t *batch_offsets, int32_t B, float *y,
+                        void *stream);
+int mink_global_avg_bwd(const float *dy, int32_t C, const int32_t *batch_offsets, int32_t B, int64_t n,
+                        float *dx, void *stream);
+
+/* TensorField.sparse() feature averaging (ME UNWEIGHTED_AVERAGE, resnet.py:164):
+ * y[u] = mean_{j in [seg[u],seg[u+1])} x[members[j]] (members sorted by input row). */
+int mink_segment_mean(const float *x, int32_t ldx, int32_t C, const int32_t *members, const int32_t *seg,
+                      int64_t n_out, float *y, void *stream);
+
+/* ------------------------------------------------------------------ batch norm / relu / add
+ * MinkowskiBatchNorm == torch.nn.BatchNorm1d on the feature matrix
+ * (modules/common.py:22-24; witness resnet.py:101-105), MinkowskiReLU (resnet.py:61),
+ * residual `out += residual` (modules/resnet_block.py:66).
+ */
+int64_t mink_bn_workspace_bytes(int64_t n, int32_t C);
+
+/* Batch statistics: mean[C], invstd[C] = 1/sqrt(biased var + eps); if running_mean !=
+ * NULL also updates running stats with `momentum` (unbiased variance, torch semantics). */
+int mink_bn_stats(const float *x, int64_t n, int32_t C, float eps, float momentum, float *mean,
+                  float *invstd, float *running_mean, float *running_var, void *workspace,
+                  void *stream);
+
+/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+int mink_bn_apply(const float *x, int64_t n, int32_t C, const float *mean, const float *invstd,
+                  const float *gamma, const float *beta, const float *residual, int32_t relu, float *y,
+                  void *stream);
+
+/* Backward of the op above.  y (the forward output) is only read when relu != 0.
+ * dgamma[C], dbeta[C]; dx[n][C]; dresidual (may be NULL) receives the masked grad. */
+int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int32_t C, const float *mean,
+                const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual,
+                float *dgamma, float *dbeta, void *workspace, void *stream);
+
+/* Elementwise: mode 0: y = max(x,0); mode 1: dx = (y>0) ? dy : 0 (a=dy,b=y);
+ * mode 2: y = a + b. */
+int mink_eltwise(const float *a, const float *b, int64_t count, int32_t mode, float *y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINK_HIP_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of libmink_hip.so (the C ABI declared in include/mink_hip.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing the
+compute path raises.  ``build()`` compiles it in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmink_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_i32, _i64, _f32, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/mink_hip.h one to one
+SIGNATURES = {
+    "mink_last_error": (ctypes.c_char_p, []),
+    "mink_abi_version": (ctypes.c_int, []),
+    "mink_table_capacity": (_i64, [_i64]),
+    "mink_unique_workspace_bytes": (_i64, [_i64]),
+    "mink_coords_make_keys": (ctypes.c_int, [_p, ctypes.c_int, _i64, _i32, _p, _p, _p]),
+    "mink_coords_unique": (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "mink_kernel_map": (ctypes.c_int, [_p, _p, _i64, _p, _i64, _p, _i32, _p, _p, _p]),
+    "mink_rulebook_workspace_bytes": (_i64, [_i64, _i32]),
+    "mink_rulebook": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "mink_batch_offsets": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p]),
+    "mink_conv_plan_ksplit": (ctypes.c_int, [_i64, _i32, _i32]),
+    "mink_conv_gather_gemm": (
+        ctypes.c_int,
+        [_p, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _i32, _i32, _p, _i32, _p, _p],
+    ),
+    "mink_conv_wgrad_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32]),
+    "mink_conv_wgrad": (ctypes.c_int, [_p, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _p, _p]),
+    "mink_pool_sum_fwd": (ctypes.c_int, [_p, _i32, _i32, _p, _i64, _i32, _p, _p]),
+    "mink_pool_sum_bwd": (ctypes.c_int, [_p, _i32, _p, _i64, _p, _p]),
+    "mink_global_avg_fwd": (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p]),
+    "mink_global_avg_bwd": (ctypes.c_int, [_p, _i32, _p, _i32, _i64, _p, _p]),
+    "mink_segment_mean": (ctypes.c_int, [_p, _i32, _i32, _p, _p, _i64, _p, _p]),
+    "mink_bn_workspace_bytes": (_i64, [_i64, _i32]),
+    "mink_bn_stats": (ctypes.c_int, [_p, _i64, _i32, _f32, _f32, _p, _p, _p, _p, _p, _p]),
+    "mink_bn_apply": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p]),
+    "mink_bn_bwd": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
+    "mink_eltwise": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
+}
+
+
+def build(force=False):
+    """Compile libmink_hip.so in-tree (hipcc --offload-arch=gfx950)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+class MinkHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the native library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MinkHipError(
+                f"{LIB_PATH} not found: the HIP backend is mandatory (no CPU fallback). "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C nerf_downstream_amd/csrc`."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MinkHipError(f"libmink_hip: {lib().mink_last_error().decode()} (code {rc})")

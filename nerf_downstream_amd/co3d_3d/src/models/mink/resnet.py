@@ -1,0 +1,90 @@
+"""Mink-ResNet14/18/34 for plenoxel voxel-grid classification (counterpart of the reference's
+co3d_3d/src/models/mink/resnet.py:25-192).  Topology, tensor strides and parameter names:
+
+    TensorField.sparse()                                   ts 1
+    conv1 3^3 (Cin->64) - bn1 - relu - SumPool(2,2)        ts 1 -> 2
+    layer1..4: BasicBlock x LAYERS[i], first block stride 2, planes 64/128/256/512
+    glob_avg (global average over each batch sample) - final 1x1 conv with bias -> logits [B, classes]
+
+State-dict keys: conv1.kernel, bn1.bn.*, layer{i}.{j}.{conv1,conv2}.kernel,
+layer{i}.{j}.{norm1,norm2}.bn.*, layer{i}.0.downsample.{0.kernel,1.bn.*}, final.{kernel,bias}.
+Bottleneck variants (ResNet50/101) are out of scope (not in BASELINE configs)."""
+import torch.nn as nn
+
+from .base_model import MinkowskiBaseModel
+from .modules.common import conv, get_norm
+from .modules.resnet_block import BasicBlock
+
+
+class GlobalAvgPool(nn.Module):
+    def __init__(self, ME):
+        super().__init__()
+        self.global_avg_pool = ME.MinkowskiGlobalAvgPooling()
+
+    def forward(self, tensor):
+        return self.global_avg_pool(tensor)
+
+
+class ResNetBase(MinkowskiBaseModel):
+    BLOCK = None
+    LAYERS = ()
+    INIT_DIM = 64
+    PLANES = (64, 128, 256, 512)
+    NORM_TYPE = "BN"
+
+    def __init__(self, in_channel, out_channel, D=3, ME=None):
+        super().__init__(D, ME=ME)
+        self.D = D
+        ME = self._ME
+        self._fused = bool(getattr(ME, "SUPPORTS_FUSED_NORM", False))
+        self.inplanes = self.INIT_DIM
+        self.conv1 = conv(in_channel, self.inplanes, kernel_size=3, stride=1, D=D, ME=ME)
+        self.bn1 = get_norm(self.NORM_TYPE, self.inplanes, D=D, bn_momentum=0.1, ME=ME)
+        self.relu = ME.MinkowskiReLU(inplace=True)
+        self.pool = ME.MinkowskiSumPooling(kernel_size=2, stride=2, dimension=D)
+        for i, (planes, count) in enumerate(zip(self.PLANES, self.LAYERS), start=1):
+            setattr(self, f"layer{i}", self._make_layer(planes, count, stride=2))
+        self.glob_avg = GlobalAvgPool(ME)
+        self.final = conv(self.PLANES[3] * self.BLOCK.expansion, out_channel, kernel_size=1, bias=True, D=D, ME=ME)
+        self.weight_initialization()
+
+    def weight_initialization(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride):
+        ME, out_planes = self._ME, planes * self.BLOCK.expansion
+        shortcut = None
+        if stride != 1 or self.inplanes != out_planes:
+            shortcut = nn.Sequential(
+                conv(self.inplanes, out_planes, kernel_size=1, stride=stride, bias=False, D=self.D, ME=ME),
+                get_norm("BN", out_planes, D=self.D, bn_momentum=0.1, ME=ME),
+            )
+        seq = [self.BLOCK(self.inplanes, planes, stride=stride, downsample=shortcut, D=self.D, ME=ME)]
+        self.inplanes = out_planes
+        seq += [self.BLOCK(self.inplanes, planes, stride=1, D=self.D, ME=ME) for _ in range(1, blocks)]
+        return nn.Sequential(*seq)
+
+    def forward(self, x):
+        out = self.conv1(x.sparse())
+        out = self.bn1(out, relu=True) if self._fused else self.relu(self.bn1(out))
+        out = self.pool(out)
+        out = self.layer4(self.layer3(self.layer2(self.layer1(out))))
+        return self.final(self.glob_avg(out)).F
+
+
+class ResNet14(ResNetBase):
+    BLOCK = BasicBlock
+    LAYERS = (1, 1, 1, 1)
+
+
+class ResNet18(ResNetBase):
+    BLOCK = BasicBlock
+    LAYERS = (2, 2, 2, 2)
+
+
+class ResNet34(ResNetBase):
+    BLOCK = BasicBlock
+    LAYERS = (3, 4, 6, 3)

@@ -1,0 +1,373 @@
+// Sparse convolution on gfx950: output-stationary gather -> LDS -> fp32 MFMA.
+//
+//   forward / dgrad : y[o] = sum_k x[nbr[o][k]] @ W[k]      (mink_conv_gather_gemm)
+//   wgrad           : dW[k] = x[nbr[.][k]]^T @ dy            (mink_conv_wgrad)
+//
+// Both are implicit GEMMs over the neighbour table, accumulated in registers by
+// v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD), with no atomics: every output
+// element has exactly one owner, so results are bitwise reproducible run to run.
+#include "common.h"
+
+namespace mink {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128;    // output rows per workgroup (4 waves x 32 rows)
+constexpr int BN = 64;     // output columns per workgroup (2 MFMA tiles per wave)
+constexpr int BK = 32;     // reduction chunk (input channels) per stage
+constexpr int LDA = BK + 4;  // LDS row stride of the A tile: conflict-free ds_read_b128
+constexpr int KMAX = 27;
+
+struct GemmParams {
+  const float *x;
+  const float *w;
+  const int *nbr;
+  const float *bias;
+  float *y;
+  float *ws;
+  int64_t n_out;
+  int ldx, cin, ldy, cout, K, flip_k, kper;
+};
+
+__device__ __forceinline__ float4 ld4_guard(const float *p, int valid, bool vec) {
+  // valid = number of in-bounds floats at p (may be <= 0 or >= 4)
+  if (valid >= 4 && vec) return *reinterpret_cast<const float4 *>(p);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid > 0) v.x = p[0];
+  if (valid > 1) v.y = p[1];
+  if (valid > 2) v.z = p[2];
+  if (valid > 3) v.w = p[3];
+  return v;
+}
+
+// W_T = false: w[K][cin][cout];  W_T = true: w[K][cout][cin] (dgrad reads the forward kernel)
+template <bool W_T>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float sA[BM * LDA];
+  __shared__ __attribute__((aligned(16))) float sB[BK * BN];
+  __shared__ int s_nbr[BM * KMAX];
+  __shared__ unsigned s_kmask;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t o0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int K = p.K;
+  const int kbeg = blockIdx.z * p.kper;
+  const int kend = min(K, kbeg + p.kper);
+
+  // ---- stage this tile's slice of the neighbour table; find offsets with any neighbour
+  if (tid == 0) s_kmask = 0u;
+  __syncthreads();
+  {
+    unsigned m = 0u;
+    const int64_t base = o0 * K;
+    const int64_t lim = p.n_out * K;
+    for (int e = tid; e < BM * K; e += 256) {
+      const int64_t g = base + e;
+      const int v = g < lim ? p.nbr[g] : -1;
+      s_nbr[e] = v;
+      if (v >= 0) m |= 1u << (e % K);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d);
+    if (lane == 0 && m) atomicOr(&s_kmask, m);
+  }
+  __syncthreads();
+  unsigned kmask = s_kmask;
+  if (kend < 32) kmask &= (1u << kend) - 1u;
+  kmask &= ~((1u << kbeg) - 1u);
+
+  f32x16 acc0 = {0}, acc1 = {0};
+
+  const bool vecx = ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+  const bool vecw = W_T ? (((p.cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0))
+                        : (((p.cout & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0));
+
+  // per-thread staging coordinates
+  const int a_cc = tid & 7, a_r = tid >> 3;       // A: rows a_r + 32 i, float4 column a_cc
+  const int b_n4 = tid & 15, b_kk = tid >> 4;     // B (!W_T): rows b_kk + 16 i, float4 column b_n4
+  const int bt_n = tid & 63, bt_k4 = tid >> 6;    // B (W_T) : column bt_n, float4 of k at 4*(bt_k4 + 4 i)
+
+  float4 ra[4], rb[2];
+
+  auto load_chunk = [&](int k, int c0) {
+    const int kw = p.flip_k ? (K - 1 - k) : k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = a_r + 32 * i;
+      const int src = s_nbr[r * K + k];
+      const int c = c0 + 4 * a_cc;
+      ra[i] = src >= 0 ? ld4_guard(p.x + (int64_t)src * p.ldx + c, p.cin - c, vecx) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (!W_T) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = c0 + b_kk + 16 * i;
+        const int n = n0 + 4 * b_n4;
+        rb[i] = kk < p.cin ? ld4_guard(p.w + ((int64_t)kw * p.cin + kk) * p.cout + n, p.cout - n, vecw)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = c0 + 4 * (bt_k4 + 4 * i);
+        const int n = n0 + bt_n;
+        rb[i] = n < p.cout ? ld4_guard(p.w + ((int64_t)kw * p.cout + n) * p.cin + kk, p.cin - kk, vecw)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&sA[(a_r + 32 * i) * LDA + 4 * a_cc]) = ra[i];
+    if (!W_T) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<float4 *>(&sB[(b_kk + 16 * i) * BN + 4 * b_n4]) = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = 4 * (bt_k4 + 4 * i);
+        sB[(kk + 0) * BN + bt_n] = rb[i].x;
+        sB[(kk + 1) * BN + bt_n] = rb[i].y;
+        sB[(kk + 2) * BN + bt_n] = rb[i].z;
+        sB[(kk + 3) * BN + bt_n] = rb[i].w;
+      }
+    }
+  };
+
+  int k = kmask ? __builtin_ctz(kmask) : -1;
+  int c0 = 0;
+  if (k >= 0) load_chunk(k, c0);
+  const int arow = wave * 32 + (lane & 31), h = lane >> 5, col = lane & 31;
+  while (k >= 0) {
+    __syncthreads();
+    store_chunk();
+    __syncthreads();
+    // advance to the next (offset, channel chunk) and prefetch it into registers
+    int nk = k, nc0 = c0 + BK;
+    if (nc0 >= p.cin) {
+      nc0 = 0;
+      const unsigned rest = (k + 1 < 32) ? (kmask >> (k + 1)) : 0u;
+      nk = rest ? (k + 1 + __builtin_ctz(rest)) : -1;
+    }
+    if (nk >= 0) load_chunk(nk, nc0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float4 a = *reinterpret_cast<const float4 *>(&sA[arow * LDA + 8 * t + 4 * h]);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = 8 * t + 4 * h + j;
+        const float b0 = sB[kk * BN + col];
+        const float b1 = sB[kk * BN + 32 + col];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b1, acc1, 0, 0, 0);
+      }
+    }
+    k = nk;
+    c0 = nc0;
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool direct = gridDim.z == 1;
+  float *dst = direct ? p.y : p.ws + (int64_t)blockIdx.z * p.n_out * p.cout;
+  const int ldd = direct ? p.ldy : p.cout;
+  const int c_a = n0 + col, c_b = n0 + 32 + col;
+  const float bias_a = (direct && p.bias && c_a < p.cout) ? p.bias[c_a] : 0.f;
+  const float bias_b = (direct && p.bias && c_b < p.cout) ? p.bias[c_b] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = o0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (row < p.n_out) {
+      if (c_a < p.cout) dst[row * ldd + c_a] = acc0[r] + bias_a;
+      if (c_b < p.cout) dst[row * ldd + c_b] = acc1[r] + bias_b;
+    }
+  }
+}
+
+// y[row][c] = sum_z ws[z][row][c] + bias[c]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int64_t n_out, int cout,
+                                                            int ksplit, const float *__restrict__ bias,
+                                                            float *__restrict__ y, int ldy) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = n_out * cout;
+  if (idx >= total) return;
+  const int64_t row = idx / cout;
+  const int c = (int)(idx - row * cout);
+  float s = 0.f;
+  for (int z = 0; z < ksplit; ++z) s += ws[(int64_t)z * total + idx];
+  y[row * ldy + c] = s + (bias ? bias[c] : 0.f);
+}
+
+// ------------------------------------------------------------------------------ wgrad
+constexpr int WR = 32;  // rows per reduction chunk
+constexpr int WT = 64;  // cin / cout super-tile
+
+struct WgradParams {
+  const float *x;
+  const float *dy;
+  const int *nbr;
+  float *out;  // dw (zsplit == 1) or workspace [zsplit][K][cin][cout]
+  int64_t n_out, rows_per_split;
+  int ldx, cin, ldy, cout, K, ct_tiles;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  __shared__ __attribute__((aligned(16))) float sX[WR * WT];
+  __shared__ __attribute__((aligned(16))) float sD[WR * WT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.x;
+  const int ci0 = (blockIdx.y / p.ct_tiles) * WT, co0 = (blockIdx.y % p.ct_tiles) * WT;
+  const int64_t rbeg = (int64_t)blockIdx.z * p.rows_per_split;
+  const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
+
+  const bool vecx = ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+  const bool vecd = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.dy) & 15) == 0);
+  const int cc = tid & 15, rr = tid >> 4;  // rows rr + 16 i, float4 column cc
+
+  f32x16 acc = {0};
+  float4 rx[2], rd[2];
+  auto load_chunk = [&](int64_t r0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t row = r0 + rr + 16 * i;
+      int src = -1;
+      if (row < rend) src = p.nbr[row * p.K + k];
+      const int ci = ci0 + 4 * cc, co = co0 + 4 * cc;
+      rx[i] = src >= 0 ? ld4_guard(p.x + (int64_t)src * p.ldx + ci, p.cin - ci, vecx) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // rows without a neighbour contribute nothing; skip their dy too
+      rd[i] = src >= 0 ? ld4_guard(p.dy + row * p.ldy + co, p.cout - co, vecd) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, col = lane & 31;
+  if (rbeg < rend) load_chunk(rbeg);
+  for (int64_t r0 = rbeg; r0 < rend; r0 += WR) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4 *>(&sX[(rr + 16 * i) * WT + 4 * cc]) = rx[i];
+      *reinterpret_cast<float4 *>(&sD[(rr + 16 * i) * WT + 4 * cc]) = rd[i];
+    }
+    __syncthreads();
+    if (r0 + WR < rend) load_chunk(r0 + WR);
+#pragma unroll
+    for (int s = 0; s < WR / 2; ++s) {
+      const int r = 2 * s + h;
+      const float a = sX[r * WT + 32 * wm + col];
+      const float b = sD[r * WT + 32 * wn + col];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  float *dst = p.out + ((int64_t)blockIdx.z * p.K + k) * p.cin * p.cout;
+  const int co = co0 + 32 * wn + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (ci < p.cin && co < p.cout) dst[(int64_t)ci * p.cout + co] = acc[r];
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ ws, int64_t count, int nslab,
+                                                          float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int z = 0; z < nslab; ++z) s += ws[(int64_t)z * count + i];
+  out[i] = s;
+}
+
+static int wgrad_zsplit(int64_t n_out, int K, int cin, int cout, int64_t *rows_per_split) {
+  const int64_t xy = (int64_t)K * cdiv(cin, WT) * cdiv(cout, WT);
+  int64_t z = cdiv(2048, xy);
+  const int64_t zmax = cdiv(n_out, 256);
+  if (z > zmax) z = zmax;
+  if (z < 1) z = 1;
+  int64_t rps = align_up(cdiv(n_out, z), WR);
+  z = cdiv(n_out, rps);
+  if (z < 1) z = 1;
+  *rows_per_split = rps;
+  return (int)z;
+}
+
+}  // namespace mink
+
+using namespace mink;
+
+extern "C" {
+
+int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout) {
+  if (n_out <= 0 || K <= 1) return 1;
+  const int64_t tiles = cdiv(n_out, BM) * cdiv(cout, BN);
+  int64_t want = cdiv(768, tiles);
+  if (want < 1) want = 1;
+  if (want > K) want = K;
+  const int64_t kper = cdiv(K, want);
+  return (int)cdiv(K, kper);
+}
+
+int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
+                          int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, float *y, int32_t ldy,
+                          int32_t cout, const float *bias, int32_t ksplit, float *workspace, void *stream) {
+  MINK_REQUIRE(K >= 1 && K <= KMAX, "gather_gemm: kernel volume %d unsupported", K);
+  MINK_REQUIRE(cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0, "gather_gemm: bad shape");
+  MINK_REQUIRE(ksplit >= 1 && ksplit <= K, "gather_gemm: bad ksplit %d", ksplit);
+  MINK_REQUIRE(n_out * (int64_t)K < (1ll << 31), "gather_gemm: table too large");
+  if (n_out == 0) return MINK_OK;
+  MINK_REQUIRE(x && w && nbr && y, "gather_gemm: NULL pointer");
+  MINK_REQUIRE(ksplit == 1 || workspace, "gather_gemm: split-K needs a workspace");
+  GemmParams p;
+  p.x = x, p.w = w, p.nbr = nbr, p.bias = bias, p.y = y, p.ws = workspace;
+  p.n_out = n_out, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K, p.flip_k = flip_k;
+  p.kper = (int)cdiv(K, ksplit);
+  const int zs = (int)cdiv(K, p.kper);
+  const dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(cout, BN), (unsigned)zs);
+  hipStream_t st = (hipStream_t)stream;
+  if (w_transposed)
+    gather_gemm_kernel<true><<<grid, 256, 0, st>>>(p);
+  else
+    gather_gemm_kernel<false><<<grid, 256, 0, st>>>(p);
+  MINK_CHECK_LAUNCH();
+  if (zs > 1) {
+    splitk_reduce_kernel<<<dim3((unsigned)cdiv(n_out * cout, 256)), 256, 0, st>>>(workspace, n_out, cout, zs, bias, y,
+                                                                                  ldy);
+    MINK_CHECK_LAUNCH();
+  }
+  return MINK_OK;
+}
+
+int64_t mink_conv_wgrad_workspace_bytes(int64_t n_out, int32_t K, int32_t cin, int32_t cout) {
+  int64_t rps;
+  const int z = wgrad_zsplit(n_out, K, cin, cout, &rps);
+  return z > 1 ? (int64_t)z * K * cin * cout * 4 : 0;
+}
+
+int mink_conv_wgrad(const float *x, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
+                    const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace, void *stream) {
+  MINK_REQUIRE(K >= 1 && K <= KMAX && cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0,
+               "wgrad: bad shape");
+  MINK_REQUIRE(dw, "wgrad: NULL dw");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_out == 0) {
+    MINK_HIP(hipMemsetAsync(dw, 0, sizeof(float) * K * cin * cout, st));
+    return MINK_OK;
+  }
+  MINK_REQUIRE(x && dy && nbr, "wgrad: NULL pointer");
+  WgradParams p;
+  const int z = wgrad_zsplit(n_out, K, cin, cout, &p.rows_per_split);
+  MINK_REQUIRE(z == 1 || workspace, "wgrad: needs a workspace");
+  p.x = x, p.dy = dy, p.nbr = nbr, p.out = z > 1 ? (float *)workspace : dw;
+  p.n_out = n_out, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K;
+  p.ct_tiles = (int)cdiv(cout, WT);
+  const dim3 grid((unsigned)K, (unsigned)(cdiv(cin, WT) * p.ct_tiles), (unsigned)z);
+  wgrad_kernel<<<grid, 256, 0, st>>>(p);
+  MINK_CHECK_LAUNCH();
+  if (z > 1) {
+    const int64_t count = (int64_t)K * cin * cout;
+    slab_reduce_kernel<<<dim3((unsigned)cdiv(count, 256)), 256, 0, st>>>((const float *)workspace, count, z, dw);
+    MINK_CHECK_LAUNCH();
+  }
+  return MINK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+// Coordinate maps on gfx950: packed-key hash map, first-occurrence unique, stride map,
+// kernel map (neighbour table) and the ME-format rulebook (wave64 ballot + prefix sums).
+// HBM-bound integer work: one thread per row / per (row,offset), coalesced 16-B row
+// loads, hash probes served from L2 / Infinity Cache (table = 12 B per slot, 2-4x rows).
+#include <string.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace mink {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+constexpr int kBlock = 256;  // 4 waves
+
+// ------------------------------------------------------------------------------ keys
+template <int MODE>  // 0 = float field rows, 1 = int32 rows
+__global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restrict__ coords, int64_t n, int out_ts,
+                                                           uint64_t *__restrict__ keys, uint32_t *status) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int b, x, y, z;
+  if (MODE == 0) {
+    const float4 c = reinterpret_cast<const float4 *>(coords)[i];
+    b = (int)floorf(c.x), x = (int)floorf(c.y), y = (int)floorf(c.z), z = (int)floorf(c.w);
+  } else {
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    b = c.x, x = c.y, y = c.z, z = c.w;
+  }
+  if (out_ts > 1) x = floor_to(x, out_ts), y = floor_to(y, out_ts), z = floor_to(z, out_ts);
+  uint64_t key;
+  if (!pack_key(b, x, y, z, key)) {
+    atomicOr(status, MINK_STATUS_RANGE);
+    key = 0;  // keep the pipeline well-defined; the host raises on the status word
+  }
+  keys[i] = key;
+}
+
+// ---------------------------------------------------------------------------- unique
+__global__ __launch_bounds__(kBlock) void insert_kernel(const uint64_t *__restrict__ keys, int64_t n,
+                                                        unsigned long long *tkeys, int *tvals, uint64_t mask,
+                                                        int *__restrict__ slot_of_row) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  uint64_t s = mix64(key) & mask;
+  for (;;) {
+    const unsigned long long prev = atomicCAS(&tkeys[s], (unsigned long long)kEmptyKey, (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) break;
+    s = (s + 1) & mask;
+  }
+  atomicMin(&tvals[s], (int)i);  // first occurrence wins
+  slot_of_row[i] = (int)s;
+}
+
+// flag first occurrences, count them per block
+__global__ __launch_bounds__(kBlock) void flag_kernel(const int *__restrict__ tvals, const int *__restrict__ slot_of_row,
+                                                      int64_t n, uint8_t *__restrict__ flags,
+                                                      int *__restrict__ block_counts) {
+  __shared__ int s_cnt[kBlock / 64];
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool first = false;
+  if (i < n) {
+    first = tvals[slot_of_row[i]] == (int)i;
+    flags[i] = first;
+  }
+  const unsigned long long m = __ballot(first);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// single-workgroup exclusive scan of int32 (n up to a few 1e5); total -> *total_out
+__global__ __launch_bounds__(1024) void scan_kernel(const int *__restrict__ in, int *__restrict__ out, int64_t n,
+                                                    int *total_out) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int v = i < n ? in[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_wave[w];
+    const int carry = s_carry;
+    if (i < n) out[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = s_carry;
+}
+
+__global__ __launch_bounds__(kBlock) void assign_kernel(const uint64_t *__restrict__ keys,
+                                                        const uint8_t *__restrict__ flags,
+                                                        const int *__restrict__ slot_of_row,
+                                                        const int *__restrict__ block_offsets, int64_t n,
+                                                        int *tvals, int *__restrict__ out_coords,
+                                                        int *__restrict__ unique_index) {
+  __shared__ int s_cnt[kBlock / 64];
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool first = i < n && flags[i];
+  const unsigned long long m = __ballot(first);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_cnt[wave] = __popcll(m);
+  __syncthreads();
+  if (first) {
+    int uid = block_offsets[blockIdx.x] + wave_rank(m);
+    for (int w = 0; w < wave; ++w) uid += s_cnt[w];
+    unique_index[uid] = (int)i;
+    reinterpret_cast<int4 *>(out_coords)[uid] = unpack_key(keys[i]);
+    tvals[slot_of_row[i]] = uid;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void inverse_kernel(const int *__restrict__ tvals,
+                                                         const int *__restrict__ slot_of_row, int64_t n,
+                                                         int *__restrict__ inverse) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) inverse[i] = tvals[slot_of_row[i]];
+}
+
+// ------------------------------------------------------------------------ kernel map
+struct Offsets {
+  int d[27 * 3];
+};
+
+__global__ __launch_bounds__(kBlock) void kernel_map_kernel(const uint64_t *__restrict__ tkeys,
+                                                            const int *__restrict__ tvals, uint64_t mask,
+                                                            const int *__restrict__ out_coords, int64_t n_out, int K,
+                                                            Offsets off, int *__restrict__ nbr, int *nbr_t) {
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n_out * K) return;
+  const int64_t o = idx / K;
+  const int k = (int)(idx - o * K);
+  const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];
+  uint64_t key;
+  int v = -1;
+  if (pack_key(c.x, c.y + off.d[3 * k], c.z + off.d[3 * k + 1], c.w + off.d[3 * k + 2], key))
+    v = table_find(tkeys, tvals, mask, key);
+  nbr[idx] = v;
+  if (nbr_t && v >= 0) nbr_t[(int64_t)v * K + k] = (int)o;
+}
+
+// -------------------------------------------------------------------------- rulebook
+// Pass 1: pairs per (offset, 256-row chunk); pass 2 (after the scan): fill, ordered by row.
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void rulebook_kernel(const int *__restrict__ nbr, int64_t n_out, int K,
+                                                          int64_t nchunk, int *__restrict__ chunk_counts,
+                                                          const int *__restrict__ chunk_offsets,
+                                                          int *__restrict__ pairs_in, int *__restrict__ pairs_out) {
+  __shared__ int s_cnt[kBlock / 64][27];
+  const int64_t o = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = 0; k < K; ++k) {
+    const int v = o < n_out ? nbr[o * K + k] : -1;
+    const unsigned long long m = __ballot(v >= 0);
+    if (lane == 0) s_cnt[wave][k] = __popcll(m);
+    if (FILL) {
+      __syncthreads();
+      if (v >= 0) {
+        int pos = chunk_offsets[(int64_t)k * nchunk + blockIdx.x] + wave_rank(m);
+        for (int w = 0; w < wave; ++w) pos += s_cnt[w][k];
+        pairs_in[pos] = v;
+        pairs_out[pos] = (int)o;
+      }
+    }
+  }
+  if (!FILL) {
+    __syncthreads();
+    if (threadIdx.x < K)
+      chunk_counts[(int64_t)threadIdx.x * nchunk + blockIdx.x] =
+          s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+  }
+}
+
+__global__ void rulebook_counts_kernel(const int *__restrict__ chunk_offsets, int64_t nchunk, int K,
+                                       const int *__restrict__ total, int *__restrict__ counts) {
+  const int k = threadIdx.x;
+  if (k < K) counts[k] = chunk_offsets[(int64_t)k * nchunk];
+  if (k == K) counts[K] = *total;
+}
+
+// --------------------------------------------------------------------- batch offsets
+__global__ __launch_bounds__(kBlock) void batch_offsets_kernel(const int *__restrict__ coords, int64_t n, int B,
+                                                               int *__restrict__ batch_offsets, uint32_t *status) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n && i > 0 && coords[4 * i] < coords[4 * (i - 1)]) atomicOr(status, MINK_STATUS_UNSORTED);
+  if (i <= B) {  // lower_bound of batch index i
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (coords[4 * mid] < (int)i) lo = mid + 1;
+      else hi = mid;
+    }
+    batch_offsets[i] = (int)lo;
+  }
+}
+
+}  // namespace mink
+
+using namespace mink;
+
+extern "C" {
+
+const char *mink_last_error(void) { return g_err; }
+int mink_abi_version(void) { return 1; }
+
+int64_t mink_table_capacity(int64_t n) {
+  int64_t cap = 64;
+  while (cap < 2 * n) cap <<= 1;
+  return cap;
+}
+
+static int64_t unique_nblocks(int64_t n) { return cdiv(n > 0 ? n : 1, kBlock); }
+
+int64_t mink_unique_workspace_bytes(int64_t n) {
+  const int64_t nb = unique_nblocks(n);
+  return align_up(4 * n, 256) + align_up(n, 256) + 2 * align_up(4 * nb, 256) + 256;
+}
+
+int mink_coords_make_keys(const void *coords, int mode, int64_t n, int32_t out_ts, uint64_t *keys, uint32_t *status,
+                          void *stream) {
+  MINK_REQUIRE(n >= 0 && out_ts >= 1 && (mode == 0 || mode == 1), "make_keys: bad arguments (n=%lld ts=%d mode=%d)",
+               (long long)n, out_ts, mode);
+  if (n == 0) return MINK_OK;
+  MINK_REQUIRE(coords && keys && status, "make_keys: NULL pointer");
+  MINK_REQUIRE(((uintptr_t)coords & 15) == 0, "make_keys: coords must be 16-byte aligned rows of 4");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)cdiv(n, kBlock));
+  if (mode == 0)
+    make_keys_kernel<0><<<grid, kBlock, 0, st>>>(coords, n, out_ts, keys, status);
+  else
+    make_keys_kernel<1><<<grid, kBlock, 0, st>>>(coords, n, out_ts, keys, status);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_coords_unique(const uint64_t *keys, int64_t n, uint64_t *table_keys, int32_t *table_vals, int64_t cap,
+                       int32_t *out_coords, int32_t *unique_index, int32_t *inverse, int32_t *n_unique,
+                       void *workspace, void *stream) {
+  MINK_REQUIRE(n >= 0 && n < (1ll << 31) - 1, "unique: n out of range");
+  MINK_REQUIRE(cap >= mink_table_capacity(n) && (cap & (cap - 1)) == 0, "unique: table capacity %lld too small for n=%lld",
+               (long long)cap, (long long)n);
+  MINK_REQUIRE(table_keys && table_vals && n_unique, "unique: NULL pointer");
+  hipStream_t st = (hipStream_t)stream;
+  MINK_HIP(hipMemsetAsync(table_keys, 0xFF, cap * sizeof(uint64_t), st));
+  MINK_HIP(hipMemsetAsync(table_vals, 0x7F, cap * sizeof(int32_t), st));
+  if (n == 0) {
+    MINK_HIP(hipMemsetAsync(n_unique, 0, sizeof(int32_t), st));
+    return MINK_OK;
+  }
+  MINK_REQUIRE(keys && out_coords && unique_index && inverse && workspace, "unique: NULL pointer");
+  MINK_REQUIRE(((uintptr_t)out_coords & 15) == 0 && ((uintptr_t)workspace & 255) == 0, "unique: misaligned buffer");
+  const int64_t nb = unique_nblocks(n);
+  char *ws = (char *)workspace;
+  int *slot_of_row = (int *)ws;
+  ws += align_up(4 * n, 256);
+  uint8_t *flags = (uint8_t *)ws;
+  ws += align_up(n, 256);
+  int *block_counts = (int *)ws;
+  ws += align_up(4 * nb, 256);
+  int *block_offsets = (int *)ws;
+  const dim3 grid((unsigned)nb);
+  insert_kernel<<<grid, kBlock, 0, st>>>(keys, n, (unsigned long long *)table_keys, table_vals, (uint64_t)cap - 1,
+                                         slot_of_row);
+  MINK_CHECK_LAUNCH();
+  flag_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, flags, block_counts);
+  MINK_CHECK_LAUNCH();
+  scan_kernel<<<1, 1024, 0, st>>>(block_counts, block_offsets, nb, n_unique);
+  MINK_CHECK_LAUNCH();
+  assign_kernel<<<grid, kBlock, 0, st>>>(keys, flags, slot_of_row, block_offsets, n, table_vals, out_coords,
+                                         unique_index);
+  MINK_CHECK_LAUNCH();
+  inverse_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, inverse);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_kernel_map(const uint64_t *in_table_keys, const int32_t *in_table_vals, int64_t in_cap,
+                    const int32_t *out_coords, int64_t n_out, const int32_t *offsets_host, int32_t K, int32_t *nbr,
+                    int32_t *nbr_t, void *stream) {
+  MINK_REQUIRE(K >= 1 && K <= 27 && offsets_host, "kernel_map: kernel volume %d unsupported (1..27)", K);
+  MINK_REQUIRE(in_cap >= 64 && (in_cap & (in_cap - 1)) == 0, "kernel_map: bad table capacity");
+  MINK_REQUIRE(n_out >= 0 && n_out * K < (1ll << 31), "kernel_map: n_out*K overflows int32 indexing");
+  if (n_out == 0) return MINK_OK;
+  MINK_REQUIRE(in_table_keys && in_table_vals && out_coords && nbr, "kernel_map: NULL pointer");
+  MINK_REQUIRE(((uintptr_t)out_coords & 15) == 0, "kernel_map: out_coords misaligned");
+  Offsets off;
+  memset(&off, 0, sizeof off);
+  memcpy(off.d, offsets_host, sizeof(int) * 3 * K);
+  kernel_map_kernel<<<dim3((unsigned)cdiv(n_out * K, kBlock)), kBlock, 0, (hipStream_t)stream>>>(
+      in_table_keys, in_table_vals, (uint64_t)in_cap - 1, out_coords, n_out, K, off, nbr, nbr_t);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int64_t mink_rulebook_workspace_bytes(int64_t n_out, int32_t K) {
+  const int64_t nchunk = cdiv(n_out > 0 ? n_out : 1, kBlock);
+  return 2 * align_up(4 * nchunk * K, 256) + 256;
+}
+
+int mink_rulebook(const int32_t *nbr, int64_t n_out, int32_t K, int32_t *counts, int32_t *pairs_in,
+                  int32_t *pairs_out, void *workspace, void *stream) {
+  MINK_REQUIRE(K >= 1 && K <= 27 && n_out >= 0 && counts, "rulebook: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_out == 0) {
+    MINK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (K + 1), st));
+    return MINK_OK;
+  }
+  MINK_REQUIRE(nbr && workspace && ((uintptr_t)workspace & 255) == 0, "rulebook: NULL/misaligned pointer");
+  const int64_t nchunk = cdiv(n_out, kBlock);
+  int *chunk_counts = (int *)workspace;
+  int *chunk_offsets = (int *)((char *)workspace + align_up(4 * nchunk * K, 256));
+  int *total = chunk_offsets + nchunk * K;  // inside the trailing 256-byte pad
+  const dim3 grid((unsigned)nchunk);
+  rulebook_kernel<false><<<grid, kBlock, 0, st>>>(nbr, n_out, K, nchunk, chunk_counts, nullptr, nullptr, nullptr);
+  MINK_CHECK_LAUNCH();
+  scan_kernel<<<1, 1024, 0, st>>>(chunk_counts, chunk_offsets, nchunk * K, total);
+  MINK_CHECK_LAUNCH();
+  rulebook_counts_kernel<<<1, 64, 0, st>>>(chunk_offsets, nchunk, K, total, counts);
+  MINK_CHECK_LAUNCH();
+  if (pairs_in && pairs_out) {
+    rulebook_kernel<true><<<grid, kBlock, 0, st>>>(nbr, n_out, K, nchunk, nullptr, chunk_offsets, pairs_in, pairs_out);
+    MINK_CHECK_LAUNCH();
+  }
+  return MINK_OK;
+}
+
+int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *batch_offsets, uint32_t *status,
+                       void *stream) {
+  MINK_REQUIRE(n >= 0 && B >= 0 && batch_offsets && status, "batch_offsets: bad arguments");
+  MINK_REQUIRE(n == 0 || coords, "batch_offsets: NULL coords");
+  const int64_t work = (n > B + 1) ? n : B + 1;
+  batch_offsets_kernel<<<dim3((unsigned)cdiv(work, kBlock)), kBlock, 0, (hipStream_t)stream>>>(coords, n, B,
+                                                                                              batch_offsets, status);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+// Bandwidth-bound feature-matrix kernels on gfx950: batch norm (stats / apply / backward,
+// optional fused ReLU + residual), ReLU, add, sum pooling, global average pooling and the
+// TensorField->SparseTensor segment mean.  All are HBM-roofline work: 16-byte accesses per
+// lane, channels fastest so a wave reads whole feature rows, no atomics (two-stage
+// deterministic reductions through a small workspace).
+#include "common.h"
+
+namespace mink {
+
+constexpr int EB = 256;
+constexpr int kRedBlocks = 512;  // workgroups of the column reductions (2 per CU)
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// ---------------------------------------------------------------------- column sums
+// Generic two-quantity column reduction over rows: each thread owns 4 channels (one float4
+// column) and strides over rows; partial[blk][2][C] in double.
+// MODE 0: (sum x, sum x^2)      MODE 1: (sum g, sum g*xhat) with g = dy * (relu ? y>0 : 1)
+template <int MODE>
+__global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                       const float *__restrict__ yrelu, int64_t n, int C,
+                                                       const float *__restrict__ mean,
+                                                       const float *__restrict__ invstd, double *__restrict__ partial) {
+  extern __shared__ double s_red[];  // [rows_in_block][2][C] reduced over the row lanes
+  const int tpr = C >> 2;            // threads per row
+  const int rlanes = EB / tpr;       // rows handled concurrently
+  const int c4 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
+  float4 mu = make_float4(0, 0, 0, 0), is = make_float4(1, 1, 1, 1);
+  const bool active = rl < rlanes;
+  if (MODE == 1 && active) mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
+  if (active) {
+    for (int64_t row = (int64_t)blockIdx.x * rlanes + rl; row < n; row += (int64_t)gridDim.x * rlanes) {
+      const int64_t off = row * C + 4 * c4;
+      if (MODE == 0) {
+        const float4 v = ld4(a + off);
+        s0.x += v.x, s0.y += v.y, s0.z += v.z, s0.w += v.w;
+        s1.x += v.x * v.x, s1.y += v.y * v.y, s1.z += v.z * v.z, s1.w += v.w * v.w;
+      } else {
+        float4 g = ld4(a + off);
+        const float4 x = ld4(b + off);
+        if (yrelu) {
+          const float4 y = ld4(yrelu + off);
+          g.x = y.x > 0.f ? g.x : 0.f, g.y = y.y > 0.f ? g.y : 0.f, g.z = y.z > 0.f ? g.z : 0.f,
+          g.w = y.w > 0.f ? g.w : 0.f;
+        }
+        s0.x += g.x, s0.y += g.y, s0.z += g.z, s0.w += g.w;
+        s1.x += g.x * (x.x - mu.x) * is.x, s1.y += g.y * (x.y - mu.y) * is.y, s1.z += g.z * (x.z - mu.z) * is.z,
+            s1.w += g.w * (x.w - mu.w) * is.w;
+      }
+    }
+    double *d = s_red + ((int64_t)rl * 2) * C + 4 * c4;
+    d[0] = s0.x, d[1] = s0.y, d[2] = s0.z, d[3] = s0.w;
+    d[C + 0] = s1.x, d[C + 1] = s1.y, d[C + 2] = s1.z, d[C + 3] = s1.w;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * C; e += EB) {
+    double s = 0.0;
+    for (int r = 0; r < rlanes; ++r) s += s_red[(int64_t)r * 2 * C + e];
+    partial[(int64_t)blockIdx.x * 2 * C + e] = s;
+  }
+}
+
+__global__ void bn_stats_finalize_kernel(const double *__restrict__ partial, int nblk, int64_t n, int C, float eps,
+                                         float momentum, float *__restrict__ mean, float *__restrict__ invstd,
+                                         float *running_mean, float *running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * 2 * C + c], ss += partial[(int64_t)b * 2 * C + C + c];
+  const double m = s / (double)n;
+  double var = ss / (double)n - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblk, int C,
+                                       const float *__restrict__ gamma, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * 2 * C + c], ss += partial[(int64_t)b * 2 * C + C + c];
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)ss;
+}
+
+// y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] )
+__global__ __launch_bounds__(EB) void bn_apply_kernel(const float *__restrict__ x, int64_t n4, int C4,
+                                                      const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                      const float *__restrict__ residual, int relu,
+                                                      float *__restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EB) {
+    const int c = (int)(i % C4) * 4;
+    const float4 v = ld4(x + 4 * i), mu = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+    float4 o;
+    o.x = (v.x - mu.x) * is.x * g.x + b.x, o.y = (v.y - mu.y) * is.y * g.y + b.y;
+    o.z = (v.z - mu.z) * is.z * g.z + b.z, o.w = (v.w - mu.w) * is.w * g.w + b.w;
+    if (residual) {
+      const float4 r = ld4(residual + 4 * i);
+      o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
+    }
+    if (relu) o.x = fmaxf(o.x, 0.f), o.y = fmaxf(o.y, 0.f), o.z = fmaxf(o.z, 0.f), o.w = fmaxf(o.w, 0.f);
+    st4(y + 4 * i, o);
+  }
+}
+
+// dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n);  dresidual = g
+__global__ __launch_bounds__(EB) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                          const float *__restrict__ yrelu, int64_t n4, int C4,
+                                                          float inv_n, const float *__restrict__ mean,
+                                                          const float *__restrict__ invstd,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ dgamma,
+                                                          const float *__restrict__ dbeta, float *__restrict__ dx,
+                                                          float *__restrict__ dres) {
+  for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EB) {
+    const int c = (int)(i % C4) * 4;
+    float4 g = ld4(dy + 4 * i);
+    if (yrelu) {
+      const float4 y = ld4(yrelu + 4 * i);
+      g.x = y.x > 0.f ? g.x : 0.f, g.y = y.y > 0.f ? g.y : 0.f, g.z = y.z > 0.f ? g.z : 0.f, g.w = y.w > 0.f ? g.w : 0.f;
+    }
+    if (dres) st4(dres + 4 * i, g);
+    const float4 v = ld4(x + 4 * i), mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c),
+                 dg = ld4(dgamma + c), db = ld4(dbeta + c);
+    float4 o;
+    o.x = ga.x * is.x * (g.x - db.x * inv_n - (v.x - mu.x) * is.x * dg.x * inv_n);
+    o.y = ga.y * is.y * (g.y - db.y * inv_n - (v.y - mu.y) * is.y * dg.y * inv_n);
+    o.z = ga.z * is.z * (g.z - db.z * inv_n - (v.z - mu.z) * is.z * dg.z * inv_n);
+    o.w = ga.w * is.w * (g.w - db.w * inv_n - (v.w - mu.w) * is.w * dg.w * inv_n);
+    st4(dx + 4 * i, o);
+  }
+}
+
+// mode 0: y = max(a,0); mode 1: y = b>0 ? a : 0; mode 2: y = a + b
+__global__ __launch_bounds__(EB) void eltwise_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                     int64_t count, int mode, float *__restrict__ y) {
+  const int64_t n4 = count >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EB) {
+    const float4 va = ld4(a + 4 * i);
+    float4 o;
+    if (mode == 0) {
+      o = make_float4(fmaxf(va.x, 0.f), fmaxf(va.y, 0.f), fmaxf(va.z, 0.f), fmaxf(va.w, 0.f));
+    } else {
+      const float4 vb = ld4(b + 4 * i);
+      if (mode == 1)
+        o = make_float4(vb.x > 0.f ? va.x : 0.f, vb.y > 0.f ? va.y : 0.f, vb.z > 0.f ? va.z : 0.f,
+                        vb.w > 0.f ? va.w : 0.f);
+      else
+        o = make_float4(va.x + vb.x, va.y + vb.y, va.z + vb.z, va.w + vb.w);
+    }
+    st4(y + 4 * i, o);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    y[i] = mode == 0 ? fmaxf(a[i], 0.f) : (mode == 1 ? (b[i] > 0.f ? a[i] : 0.f) : a[i] + b[i]);
+  }
+}
+
+// ------------------------------------------------------------------------- pooling
+__global__ __launch_bounds__(EB) void pool_sum_fwd_kernel(const float *__restrict__ x, int ldx, int C4,
+                                                          const int *__restrict__ nbr, int64_t n_out, int K,
+                                                          float *__restrict__ y) {
+  const int64_t idx = (int64_t)blockIdx.x * EB + threadIdx.x;
+  if (idx >= n_out * C4) return;
+  const int64_t o = idx / C4;
+  const int c = (int)(idx - o * C4) * 4;
+  float4 s = make_float4(0, 0, 0, 0);
+  for (int k = 0; k < K; ++k) {
+    const int i = nbr[o * K + k];
+    if (i >= 0) {
+      const float4 v = ld4(x + (int64_t)i * ldx + c);
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  }
+  st4(y + o * (int64_t)(4 * C4) + c, s);
+}
+
+__global__ __launch_bounds__(EB) void pool_sum_bwd_kernel(const float *__restrict__ dy, int C4,
+                                                          const int *__restrict__ in2out, int64_t n_in,
+                                                          float *__restrict__ dx) {
+  const int64_t idx = (int64_t)blockIdx.x * EB + threadIdx.x;
+  if (idx >= n_in * C4) return;
+  const int64_t i = idx / C4;
+  const int c = (int)(idx - i * C4) * 4;
+  st4(dx + i * (int64_t)(4 * C4) + c, ld4(dy + (int64_t)in2out[i] * (4 * C4) + c));
+}
+
+// one workgroup per (batch, 64-channel slab): 16 float4 columns x 16 row lanes
+__global__ __launch_bounds__(EB) void global_avg_fwd_kernel(const float *__restrict__ x, int C,
+                                                            const int *__restrict__ boff, float *__restrict__ y) {
+  __shared__ float4 s_red[EB];
+  const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 15) * 4, rl = threadIdx.x >> 4;
+  const int beg = boff[b], end = boff[b + 1];
+  float4 s = make_float4(0, 0, 0, 0);
+  if (c < C)
+    for (int r = beg + rl; r < end; r += 16) {
+      const float4 v = ld4(x + (int64_t)r * C + c);
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  s_red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    for (int r = 1; r < 16; ++r) {
+      const float4 v = s_red[r * 16 + (threadIdx.x & 15)];
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    const float inv = end > beg ? 1.f / (float)(end - beg) : 0.f;
+    st4(y + (int64_t)b * C + c, make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv));
+  }
+}
+
+__global__ __launch_bounds__(EB) void global_avg_bwd_kernel(const float *__restrict__ dy, int C4,
+                                                            const int *__restrict__ boff, int B, int64_t n,
+                                                            float *__restrict__ dx) {
+  const int64_t idx = (int64_t)blockIdx.x * EB + threadIdx.x;
+  if (idx >= n * C4) return;
+  const int64_t i = idx / C4;
+  const int c = (int)(idx - i * C4) * 4;
+  int lo = 0, hi = B;  // largest b with boff[b] <= i
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (boff[mid] <= i) lo = mid;
+    else hi = mid;
+  }
+  const float inv = 1.f / (float)(boff[lo + 1] - boff[lo]);
+  const float4 g = ld4(dy + (int64_t)lo * (4 * C4) + c);
+  st4(dx + i * (int64_t)(4 * C4) + c, make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv));
+}
+
+__global__ __launch_bounds__(EB) void segment_mean_kernel(const float *__restrict__ x, int ldx, int C,
+                                                          const int *__restrict__ members,
+                                                          const int *__restrict__ seg, int64_t n_out,
+                                                          float *__restrict__ y) {
+  const int64_t idx = (int64_t)blockIdx.x * EB + threadIdx.x;
+  if (idx >= n_out * C) return;
+  const int64_t u = idx / C;
+  const int c = (int)(idx - u * C);
+  const int beg = seg[u], end = seg[u + 1];
+  float s = 0.f;
+  for (int j = beg; j < end; ++j) s += x[(int64_t)members[j] * ldx + c];  // input-row order
+  y[idx] = s / (float)(end - beg);
+}
+
+static inline unsigned ew_grid(int64_t work) {
+  int64_t g = cdiv(work, EB);
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace mink
+
+using namespace mink;
+
+#define REQ_C4(C, name) MINK_REQUIRE((C) >= 4 && ((C)&3) == 0, name ": channel count %d must be a multiple of 4", (C))
+#define REQ_A16(ptr, name) MINK_REQUIRE(((uintptr_t)(ptr)&15) == 0, name ": pointer must be 16-byte aligned")
+
+extern "C" {
+
+int64_t mink_bn_workspace_bytes(int64_t n, int32_t C) { return (int64_t)kRedBlocks * 2 * C * sizeof(double); }
+
+static int launch_colreduce(int mode, const float *a, const float *b, const float *yrelu, int64_t n, int C,
+                            const float *mean, const float *invstd, double *partial, hipStream_t st, int *nblk_out) {
+  const int tpr = C >> 2;
+  MINK_REQUIRE(tpr <= EB, "bn: at most %d channels supported", 4 * EB);
+  const int rlanes = EB / tpr;
+  int64_t nblk = cdiv(n, (int64_t)rlanes * 8);
+  if (nblk > kRedBlocks) nblk = kRedBlocks;
+  if (nblk < 1) nblk = 1;
+  const size_t shm = (size_t)rlanes * 2 * C * sizeof(double);
+  if (mode == 0)
+    colreduce_kernel<0><<<dim3((unsigned)nblk), EB, shm, st>>>(a, b, yrelu, n, C, mean, invstd, partial);
+  else
+    colreduce_kernel<1><<<dim3((unsigned)nblk), EB, shm, st>>>(a, b, yrelu, n, C, mean, invstd, partial);
+  MINK_CHECK_LAUNCH();
+  *nblk_out = (int)nblk;
+  return MINK_OK;
+}
+
+int mink_bn_stats(const float *x, int64_t n, int32_t C, float eps, float momentum, float *mean, float *invstd,
+                  float *running_mean, float *running_var, void *workspace, void *stream) {
+  REQ_C4(C, "bn_stats");
+  MINK_REQUIRE(n >= 1 && x && mean && invstd && workspace, "bn_stats: bad arguments (n=%lld)", (long long)n);
+  MINK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running stats must come in pairs");
+  REQ_A16(x, "bn_stats");
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = 0;
+  int rc = launch_colreduce(0, x, nullptr, nullptr, n, C, nullptr, nullptr, (double *)workspace, st, &nblk);
+  if (rc) return rc;
+  bn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, 64)), 64, 0, st>>>((const double *)workspace, nblk, n, C, eps,
+                                                                       momentum, mean, invstd, running_mean,
+                                                                       running_var);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_bn_apply(const float *x, int64_t n, int32_t C, const float *mean, const float *invstd, const float *gamma,
+                  const float *beta, const float *residual, int32_t relu, float *y, void *stream) {
+  REQ_C4(C, "bn_apply");
+  MINK_REQUIRE(n >= 0, "bn_apply: bad n");
+  if (n == 0) return MINK_OK;
+  MINK_REQUIRE(x && mean && invstd && gamma && beta && y, "bn_apply: NULL pointer");
+  REQ_A16(x, "bn_apply");
+  REQ_A16(y, "bn_apply");
+  const int64_t n4 = n * (C >> 2);
+  bn_apply_kernel<<<dim3(ew_grid(n4)), EB, 0, (hipStream_t)stream>>>(x, n4, C >> 2, mean, invstd, gamma, beta, residual,
+                                                                    relu, y);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int32_t C, const float *mean,
+                const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual, float *dgamma,
+                float *dbeta, void *workspace, void *stream) {
+  REQ_C4(C, "bn_bwd");
+  MINK_REQUIRE(n >= 1 && dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace,
+               "bn_bwd: bad arguments");
+  MINK_REQUIRE(!relu || y, "bn_bwd: fused ReLU needs the forward output");
+  REQ_A16(dy, "bn_bwd");
+  REQ_A16(x, "bn_bwd");
+  REQ_A16(dx, "bn_bwd");
+  hipStream_t st = (hipStream_t)stream;
+  const float *yr = relu ? y : nullptr;
+  int nblk = 0;
+  int rc = launch_colreduce(1, dy, x, yr, n, C, mean, invstd, (double *)workspace, st, &nblk);
+  if (rc) return rc;
+  bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, 64)), 64, 0, st>>>((const double *)workspace, nblk, C, gamma, dgamma,
+                                                                     dbeta);
+  MINK_CHECK_LAUNCH();
+  const int64_t n4 = n * (C >> 2);
+  bn_bwd_apply_kernel<<<dim3(ew_grid(n4)), EB, 0, st>>>(dy, x, yr, n4, C >> 2, 1.f / (float)n, mean, invstd, gamma,
+                                                       dgamma, dbeta, dx, dresidual);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_eltwise(const float *a, const float *b, int64_t count, int32_t mode, float *y, void *stream) {
+  MINK_REQUIRE(count >= 0 && mode >= 0 && mode <= 2, "eltwise: bad arguments");
+  if (count == 0) return MINK_OK;
+  MINK_REQUIRE(a && y && (mode == 0 || b), "eltwise: NULL pointer");
+  REQ_A16(a, "eltwise");
+  REQ_A16(y, "eltwise");
+  eltwise_kernel<<<dim3(ew_grid(count >> 2)), EB, 0, (hipStream_t)stream>>>(a, b, count, mode, y);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_pool_sum_fwd(const float *x, int32_t ldx, int32_t C, const int32_t *nbr, int64_t n_out, int32_t K, float *y,
+                      void *stream) {
+  REQ_C4(C, "pool_sum_fwd");
+  MINK_REQUIRE(n_out >= 0 && K >= 1 && (ldx & 3) == 0 && ldx >= C, "pool_sum_fwd: bad shape");
+  if (n_out == 0) return MINK_OK;
+  MINK_REQUIRE(x && nbr && y, "pool_sum_fwd: NULL pointer");
+  REQ_A16(x, "pool_sum_fwd");
+  REQ_A16(y, "pool_sum_fwd");
+  pool_sum_fwd_kernel<<<dim3((unsigned)cdiv(n_out * (C >> 2), EB)), EB, 0, (hipStream_t)stream>>>(x, ldx, C >> 2, nbr,
+                                                                                                 n_out, K, y);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_pool_sum_bwd(const float *dy, int32_t C, const int32_t *in2out, int64_t n_in, float *dx, void *stream) {
+  REQ_C4(C, "pool_sum_bwd");
+  MINK_REQUIRE(n_in >= 0, "pool_sum_bwd: bad n");
+  if (n_in == 0) return MINK_OK;
+  MINK_REQUIRE(dy && in2out && dx, "pool_sum_bwd: NULL pointer");
+  REQ_A16(dy, "pool_sum_bwd");
+  REQ_A16(dx, "pool_sum_bwd");
+  pool_sum_bwd_kernel<<<dim3((unsigned)cdiv(n_in * (C >> 2), EB)), EB, 0, (hipStream_t)stream>>>(dy, C >> 2, in2out,
+                                                                                                n_in, dx);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_global_avg_fwd(const float *x, int32_t C, const int32_t *batch_offsets, int32_t B, float *y, void *stream) {
+  REQ_C4(C, "global_avg_fwd");
+  MINK_REQUIRE(B >= 1 && x && batch_offsets && y, "global_avg_fwd: bad arguments");
+  REQ_A16(x, "global_avg_fwd");
+  REQ_A16(y, "global_avg_fwd");
+  global_avg_fwd_kernel<<<dim3((unsigned)B, (unsigned)cdiv(C, 64)), EB, 0, (hipStream_t)stream>>>(x, C, batch_offsets, y);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_global_avg_bwd(const float *dy, int32_t C, const int32_t *batch_offsets, int32_t B, int64_t n, float *dx,
+                        void *stream) {
+  REQ_C4(C, "global_avg_bwd");
+  MINK_REQUIRE(B >= 1 && n >= 0, "global_avg_bwd: bad arguments");
+  if (n == 0) return MINK_OK;
+  MINK_REQUIRE(dy && batch_offsets && dx, "global_avg_bwd: NULL pointer");
+  REQ_A16(dy, "global_avg_bwd");
+  REQ_A16(dx, "global_avg_bwd");
+  global_avg_bwd_kernel<<<dim3((unsigned)cdiv(n * (C >> 2), EB)), EB, 0, (hipStream_t)stream>>>(dy, C >> 2,
+                                                                                               batch_offsets, B, n, dx);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_segment_mean(const float *x, int32_t ldx, int32_t C, const int32_t *members, const int32_t *seg,
+                      int64_t n_out, float *y, void *stream) {
+  MINK_REQUIRE(C >= 1 && ldx >= C && n_out >= 0, "segment_mean: bad shape");
+  if (n_out == 0) return MINK_OK;
+  MINK_REQUIRE(x && members && seg && y, "segment_mean: NULL pointer");
+  segment_mean_kernel<<<dim3((unsigned)cdiv(n_out * C, EB)), EB, 0, (hipStream_t)stream>>>(x, ldx, C, members, seg,
+                                                                                          n_out, y);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+}  // extern "C"

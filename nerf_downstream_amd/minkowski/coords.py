@@ -1,0 +1,214 @@
+"""Coordinate manager of the HIP backend (ME ``CoordinateManager`` counterpart).
+
+One manager is created per input ``TensorField`` -- i.e. rebuilt every iteration and shared
+by forward and backward, exactly like ME.  It owns, in HBM:
+
+* per tensor stride ``ts``: the int32 coordinate rows, and the packed-key hash map over them;
+* per (ts_in, ts_out): the stride map ``in2out``;
+* per (ts_in, ts_out, kernel, dilation): the neighbour table ``nbr[n_out, K]`` and, on demand,
+  its transpose ``nbr_t[n_in, K]`` (consumed by dgrad of strided convolutions).
+
+Row order: FIRST OCCURRENCE in input-row order at every level.
+Accessors mirror the ones the reference touches: ``stride(key, stride)``
+(sparse_conv.py:403-405), ``kernel_map(in_key, out_key, stride, kernel_size, dilation)``
+-> ``{k: IntTensor[2,n]}`` (sparse_conv.py:90-96,124-143), ``size(key)`` (sparse_conv.py:80).
+"""
+import numpy as np
+import torch
+
+from .._lib import check, lib
+
+ORIGIN_TS = 0
+_STATUS_RANGE, _STATUS_UNSORTED = 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _as_int(v):
+    if isinstance(v, (list, tuple)):
+        assert all(int(s) == int(v[0]) for s in v), "anisotropic strides/kernels are not supported"
+        return int(v[0])
+    return int(v)
+
+
+def kernel_offsets(kernel_size, in_ts, dilation=1):
+    """Kernel region (A4): x fastest, z slowest; odd sizes centred, even sizes {0..k-1}."""
+    k = int(kernel_size)
+    r = np.arange(k) - (k - 1) // 2 if k % 2 == 1 else np.arange(k)
+    dz, dy, dx = np.meshgrid(r, r, r, indexing="ij")
+    off = np.stack([dx.ravel(), dy.ravel(), dz.ravel()], 1) * int(dilation) * int(in_ts)
+    return np.ascontiguousarray(off, dtype=np.int32)
+
+
+class CoordinateMapKey:
+    def __init__(self, tensor_stride, name=""):
+        self.ts = int(tensor_stride)
+        self.name = name
+
+    def get_tensor_stride(self):
+        return [self.ts] * 3
+
+    def get_coordinate_size(self):
+        return 4
+
+    def __eq__(self, other):
+        return isinstance(other, CoordinateMapKey) and (self.ts, self.name) == (other.ts, other.name)
+
+    def __hash__(self):
+        return hash((self.ts, self.name))
+
+    def __repr__(self):
+        return f"CoordinateMapKey(tensor_stride={self.get_tensor_stride()})"
+
+
+class _Level:
+    __slots__ = ("coords", "n", "tkeys", "tvals", "cap")
+
+
+class CoordinateManager:
+    def __init__(self, D=3, device=None):
+        assert D == 3, "the HIP backend implements 3 spatial dimensions"
+        self.D = D
+        self.device = device
+        self.levels = {}
+        self.in2out = {}
+        self.tables = {}
+        self.field_inverse = None
+        self.field_unique_index = None
+        self._boff = {}
+        self._batch_size = None
+
+    # ------------------------------------------------------------------ internals
+    def _unique(self, src, mode, n, out_ts):
+        """keys -> hash map + first-occurrence rows.  Returns (_Level, unique_index, inverse)."""
+        L, dev = lib(), self.device
+        n = int(n)
+        keys = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        meta = torch.zeros(2, dtype=torch.int32, device=dev)  # [n_unique, status]
+        check(L.mink_coords_make_keys(src.data_ptr(), mode, n, out_ts, keys.data_ptr(), meta[1:].data_ptr(), _stream()))
+        lev = _Level()
+        lev.cap = int(L.mink_table_capacity(n))
+        lev.tkeys = torch.empty(lev.cap, dtype=torch.int64, device=dev)
+        lev.tvals = torch.empty(lev.cap, dtype=torch.int32, device=dev)
+        coords = torch.empty(max(n, 1), 4, dtype=torch.int32, device=dev)
+        uidx = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        ws = torch.empty(int(L.mink_unique_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        check(
+            L.mink_coords_unique(
+                keys.data_ptr(), n, lev.tkeys.data_ptr(), lev.tvals.data_ptr(), lev.cap, coords.data_ptr(),
+                uidx.data_ptr(), inv.data_ptr(), meta.data_ptr(), ws.data_ptr(), _stream(),
+            )
+        )
+        nu, status = meta.tolist()  # the one host sync of this level
+        if status & _STATUS_RANGE:
+            raise ValueError(
+                "coordinate outside the supported range (batch < 65535, |x|,|y|,|z| < 32768 after quantisation)"
+            )
+        lev.n = nu
+        lev.coords = coords[:nu]
+        return lev, uidx[:nu], inv[:n]
+
+    # ------------------------------------------------------------------ construction
+    def insert_field(self, fcoords):
+        """A1+A2: floor-quantise the float field, insert; returns the tensor-stride-1 key."""
+        assert fcoords.is_cuda and fcoords.dim() == 2 and fcoords.shape[1] == 4
+        self.device = fcoords.device
+        fc = fcoords.contiguous()
+        if fc.dtype in (torch.int32,):
+            lev, ui, inv = self._unique(fc, 1, fc.shape[0], 1)
+        else:
+            lev, ui, inv = self._unique(fc.float(), 0, fc.shape[0], 1)
+        self.levels[1] = lev
+        self.field_unique_index, self.field_inverse = ui, inv
+        return CoordinateMapKey(1)
+
+    def stride(self, key, stride):
+        s = _as_int(stride)
+        if s == 1:
+            return key
+        ts_out = key.ts * s
+        if ts_out not in self.levels:
+            src = self.levels[key.ts]
+            lev, _, inv = self._unique(src.coords, 1, src.n, ts_out)
+            self.levels[ts_out] = lev
+            self.in2out[(key.ts, ts_out)] = inv
+        return CoordinateMapKey(ts_out)
+
+    def stride_map(self, in_key, out_key):
+        k = (in_key.ts, out_key.ts)
+        if k not in self.in2out:
+            raise KeyError(f"no stride map {k}: create the output map with stride() first")
+        return self.in2out[k]
+
+    def kernel_table(self, in_key, out_key, kernel_size, dilation=1, transposed=False):
+        """Neighbour table nbr[n_out,K] (and nbr_t[n_in,K] when `transposed`)."""
+        ks, dil = _as_int(kernel_size), _as_int(dilation)
+        kk = (in_key.ts, out_key.ts, ks, dil)
+        ent = self.tables.get(kk)
+        if ent is None or (transposed and ent[1] is None):
+            lin, lout = self.levels[in_key.ts], self.levels[out_key.ts]
+            off = kernel_offsets(ks, in_key.ts, dil)
+            K = off.shape[0]
+            nbr = torch.empty(max(lout.n, 1), K, dtype=torch.int32, device=self.device)[: lout.n]
+            nbr_t = None
+            if transposed:
+                nbr_t = torch.full((max(lin.n, 1), K), -1, dtype=torch.int32, device=self.device)[: lin.n]
+            check(
+                lib().mink_kernel_map(
+                    lin.tkeys.data_ptr(), lin.tvals.data_ptr(), lin.cap, lout.coords.data_ptr(), lout.n,
+                    off.ctypes.data, K, nbr.data_ptr(), nbr_t.data_ptr() if transposed else None, _stream(),
+                )
+            )
+            ent = (nbr, nbr_t)
+            self.tables[kk] = ent
+        return ent
+
+    def kernel_map(self, in_key, out_key, stride=1, kernel_size=3, dilation=1, is_transpose=False, is_pool=False):
+        """ME-format kernel map {k: IntTensor[2,n]} (row 0 = in rows, row 1 = out rows)."""
+        assert not is_transpose, "transposed kernel maps are out of scope"
+        nbr, _ = self.kernel_table(in_key, out_key, kernel_size, dilation)
+        n_out, K = nbr.shape
+        L = lib()
+        counts = torch.empty(K + 1, dtype=torch.int32, device=self.device)
+        ws = torch.empty(int(L.mink_rulebook_workspace_bytes(n_out, K)), dtype=torch.uint8, device=self.device)
+        pin = torch.empty(max(n_out * K, 1), dtype=torch.int32, device=self.device)
+        pout = torch.empty(max(n_out * K, 1), dtype=torch.int32, device=self.device)
+        check(
+            L.mink_rulebook(nbr.data_ptr(), n_out, K, counts.data_ptr(), pin.data_ptr(), pout.data_ptr(), ws.data_ptr(), _stream())
+        )
+        c = counts.tolist()
+        return {k: torch.stack([pin[c[k] : c[k + 1]], pout[c[k] : c[k + 1]]]) for k in range(K) if c[k + 1] > c[k]}
+
+    # ------------------------------------------------------------------ queries
+    def size(self, key):
+        return self.batch_size() if key.ts == ORIGIN_TS else self.levels[key.ts].n
+
+    def batch_size(self):
+        if self._batch_size is None:
+            c = self.levels[1].coords
+            self._batch_size = int(c[-1, 0].item()) + 1 if c.shape[0] else 0
+            self.batch_offsets(CoordinateMapKey(1))  # also validates batch ordering
+        return self._batch_size
+
+    def batch_offsets(self, key):
+        """int32[B+1] row ranges per batch index (rows of one batch are contiguous)."""
+        if key.ts not in self._boff:
+            B = self._batch_size if self._batch_size is not None else self.batch_size()
+            lev = self.levels[key.ts]
+            boff = torch.empty(B + 1, dtype=torch.int32, device=self.device)
+            status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            check(lib().mink_batch_offsets(lev.coords.data_ptr(), lev.n, B, boff.data_ptr(), status.data_ptr(), _stream()))
+            if key.ts == 1 and int(status.item()) & _STATUS_UNSORTED:
+                raise ValueError("batch indices must be non-decreasing (use ME.utils.sparse_collate)")
+            self._boff[key.ts] = boff
+        return self._boff[key.ts]
+
+    def get_coordinates(self, key):
+        if key.ts == ORIGIN_TS:
+            c = torch.zeros(self.batch_size(), 4, dtype=torch.int32, device=self.device)
+            c[:, 0] = torch.arange(self.batch_size(), device=self.device)
+            return c
+        return self.levels[key.ts].coords

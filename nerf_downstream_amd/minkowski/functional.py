@@ -1,0 +1,236 @@
+"""Autograd functions of the HIP backend: every forward/backward is a call into libmink_hip.so
+(C ABI, include/mink_hip.h) on torch-owned device buffers and the current HIP stream.
+
+Semantics follow SURVEY.md Appendix A (A6 convolution, A8 batch norm, A9 sum pooling,
+A10 global average pooling); the reference call sites are cited on the modules.
+"""
+import torch
+
+from .._lib import check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t):
+    assert t.is_cuda, "the HIP backend has no CPU path"
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _bytes(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------- convolution
+def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None):
+    """y[o] = sum_k x[nbr[o,k]] @ W[k] (+bias) on the fp32 matrix cores."""
+    L = lib()
+    n_out, K = nbr.shape
+    cin = x.shape[1]
+    y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
+    ksplit = int(L.mink_conv_plan_ksplit(n_out, K, cout))
+    ws = torch.empty(ksplit * n_out * cout, dtype=torch.float32, device=x.device) if ksplit > 1 else None
+    check(
+        L.mink_conv_gather_gemm(
+            x.data_ptr(), x.stride(0), cin, w.data_ptr(), int(w_transposed), int(flip_k), nbr.data_ptr(), n_out, K,
+            y.data_ptr(), cout, cout, _ptr(bias), ksplit, _ptr(ws), _stream(),
+        )
+    )
+    return y
+
+
+def conv_wgrad(x, dy, nbr, kernel_shape):
+    L = lib()
+    n_out, K = nbr.shape
+    cin, cout = x.shape[1], dy.shape[1]
+    dw = torch.empty(kernel_shape, dtype=torch.float32, device=x.device)
+    ws = _bytes(L.mink_conv_wgrad_workspace_bytes(n_out, K, cin, cout), x.device)
+    check(
+        L.mink_conv_wgrad(
+            x.data_ptr(), x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K, dw.data_ptr(),
+            ws.data_ptr(), _stream(),
+        )
+    )
+    return dw
+
+
+class ConvolutionFunction(torch.autograd.Function):
+    """MinkowskiConvolution forward/backward (reference modules/common.py:116-125; A6).
+
+    `table_fn(transposed)` returns (nbr, nbr_t) lazily so the transposed table is only built
+    when an input gradient is really needed (the stem conv needs wgrad only).
+    """
+
+    @staticmethod
+    def forward(ctx, x, kernel, table_fn, same_map):
+        x = _f32c(x)
+        w = _f32c(kernel)
+        nbr, _ = table_fn(False)
+        ctx.save_for_backward(x, w)
+        ctx.table_fn, ctx.same_map, ctx.nbr = table_fn, same_map, nbr
+        return gather_gemm(x, w, nbr, w.shape[-1])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _f32c(gy)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.same_map:  # stride 1: nbr_t[i][k] == nbr[i][K-1-k]
+                gx = gather_gemm(gy, w, ctx.nbr, w.shape[-2], w_transposed=True, flip_k=True)
+            else:
+                _, nbr_t = ctx.table_fn(True)
+                gx = gather_gemm(gy, w, nbr_t, w.shape[-2], w_transposed=True)
+        gw = conv_wgrad(x, gy, ctx.nbr, w.shape) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None
+
+
+# -------------------------------------------------------------------------- batch norm
+class BatchNormFunction(torch.autograd.Function):
+    """BatchNorm1d over the rows of F, optionally fused with the residual add and ReLU that
+    follow it in the reference block (modules/resnet_block.py:53-69; A8)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu):
+        L = lib()
+        x = _f32c(x)
+        n, C = x.shape
+        dev = x.device
+        if residual is not None:
+            residual = _f32c(residual)
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            ws = _bytes(L.mink_bn_workspace_bytes(n, C), dev)
+            check(
+                L.mink_bn_stats(
+                    x.data_ptr(), n, C, eps, momentum if running_mean is not None else 0.0, mean.data_ptr(),
+                    invstd.data_ptr(), _ptr(running_mean), _ptr(running_var), ws.data_ptr(), _stream(),
+                )
+            )
+        else:
+            mean = running_mean.float()
+            invstd = torch.rsqrt(running_var.float() + eps)
+        y = torch.empty_like(x)
+        check(
+            L.mink_bn_apply(
+                x.data_ptr(), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                _ptr(residual), int(relu), y.data_ptr(), _stream(),
+            )
+        )
+        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
+        ctx.training, ctx.relu, ctx.has_res = training, relu, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = lib()
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        gy = _f32c(gy)
+        n, C = x.shape
+        dev = x.device
+        if not ctx.training:  # eval-mode BN is an affine map; rarely differentiated
+            g = gy * (y > 0) if ctx.relu else gy
+            xhat = (x - mean) * invstd
+            return (g * (gamma * invstd), (g * xhat).sum(0), g.sum(0), None, None, None, None, None,
+                    g if ctx.has_res else None, None)
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if ctx.has_res else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = _bytes(L.mink_bn_workspace_bytes(n, C), dev)
+        check(
+            L.mink_bn_bwd(
+                gy.data_ptr(), x.data_ptr(), _ptr(y), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                int(ctx.relu), gx.data_ptr(), _ptr(gres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(),
+            )
+        )
+        return gx, dgamma, dbeta, None, None, None, None, None, gres, None
+
+
+# ----------------------------------------------------------------------------- eltwise
+def _eltwise(a, b, mode):
+    y = torch.empty_like(a)
+    check(lib().mink_eltwise(a.data_ptr(), _ptr(b), a.numel(), mode, y.data_ptr(), _stream()))
+    return y
+
+
+class ReLUFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = _eltwise(_f32c(x), None, 0)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return _eltwise(_f32c(gy), y, 1)
+
+
+class AddFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return _eltwise(_f32c(a), _f32c(b), 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, gy
+
+
+# ----------------------------------------------------------------------------- pooling
+class SumPoolFunction(torch.autograd.Function):
+    """MinkowskiSumPooling(kernel==stride) (reference resnet.py:62-64; A9)."""
+
+    @staticmethod
+    def forward(ctx, x, nbr, in2out):
+        x = _f32c(x)
+        n_out, K = nbr.shape
+        C = x.shape[1]
+        y = torch.empty(n_out, C, dtype=torch.float32, device=x.device)
+        check(lib().mink_pool_sum_fwd(x.data_ptr(), x.stride(0), C, nbr.data_ptr(), n_out, K, y.data_ptr(), _stream()))
+        ctx.in2out, ctx.n_in = in2out, x.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = _f32c(gy)
+        C = gy.shape[1]
+        gx = torch.empty(ctx.n_in, C, dtype=torch.float32, device=gy.device)
+        check(lib().mink_pool_sum_bwd(gy.data_ptr(), C, ctx.in2out.data_ptr(), ctx.n_in, gx.data_ptr(), _stream()))
+        return gx, None, None
+
+
+class GlobalAvgPoolFunction(torch.autograd.Function):
+    """MinkowskiGlobalAvgPooling (reference resnet.py:15-22,175; A10)."""
+
+    @staticmethod
+    def forward(ctx, x, boff):
+        x = _f32c(x)
+        B, C = boff.numel() - 1, x.shape[1]
+        y = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        check(lib().mink_global_avg_fwd(x.data_ptr(), C, boff.data_ptr(), B, y.data_ptr(), _stream()))
+        ctx.boff, ctx.n = boff, x.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = _f32c(gy)
+        B, C = gy.shape
+        gx = torch.empty(ctx.n, C, dtype=torch.float32, device=gy.device)
+        check(lib().mink_global_avg_bwd(gy.data_ptr(), C, ctx.boff.data_ptr(), B, ctx.n, gx.data_ptr(), _stream()))
+        return gx, None
+
+
+def segment_mean(x, members, seg, n_out):
+    x = _f32c(x)
+    y = torch.empty(n_out, x.shape[1], dtype=torch.float32, device=x.device)
+    check(
+        lib().mink_segment_mean(x.data_ptr(), x.stride(0), x.shape[1], members.data_ptr(), seg.data_ptr(), n_out, y.data_ptr(), _stream())
+    )
+    return y

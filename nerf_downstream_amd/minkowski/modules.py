@@ -1,0 +1,146 @@
+"""nn.Module layer of the HIP backend: the ME modules the reference hot path instantiates
+(SURVEY.md 8b).  Constructor signatures, parameter names (`kernel`, `bias`, `bn.*`) and
+initialisation follow ME so reference checkpoints / configs map one to one."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from .coords import ORIGIN_TS, CoordinateMapKey, _as_int
+from .tensor import SparseTensor
+
+
+class MinkowskiNetwork(nn.Module):
+    """Base class of reference models (models/mink/base_model.py:6-8)."""
+
+    def __init__(self, D):
+        super().__init__()
+        self.D = D
+
+
+class MinkowskiConvolution(nn.Module):
+    """ME.MinkowskiConvolution as called by `conv()` (modules/common.py:116-125).
+
+    kernel: (K, Cin, Cout), or (Cin, Cout) when the kernel volume is 1 and every stride is 1
+    (`use_mm`, witness sparse_conv.py:323-335); bias: (1, Cout).  Init U(+-1/sqrt(Cin*K))
+    (sparse_conv.py:427-435)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, expand_coordinates=False, convolution_mode=None, dimension=None):
+        super().__init__()
+        assert dimension == 3, "the HIP backend implements dimension=3"
+        assert kernel_generator is None and not expand_coordinates, "custom kernel generators are out of scope"
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.dilation = _as_int(kernel_size), _as_int(stride), _as_int(dilation)
+        assert self.kernel_size in (1, 3) or self.kernel_size % 2 == 1 and self.kernel_size ** 3 <= 27
+        self.kernel_volume = self.kernel_size ** 3
+        self.dimension = dimension
+        self.use_mm = self.kernel_volume == 1 and self.stride == 1
+        shape = (in_channels, out_channels) if self.use_mm else (self.kernel_volume, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(*shape))
+        self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.in_channels * self.kernel_volume)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def forward(self, input, coordinates=None):
+        assert coordinates is None, "explicit output coordinates are out of scope"
+        m = input.coordinate_manager
+        in_key = input.coordinate_map_key
+        if self.use_mm:  # plain matmul on the feature matrix, same coordinates
+            out_key = in_key
+            out = input.F.mm(self.kernel)
+        else:
+            out_key = m.stride(in_key, self.stride)
+            ks, dil = self.kernel_size, self.dilation
+
+            def table_fn(transposed, m=m, in_key=in_key, out_key=out_key):
+                return m.kernel_table(in_key, out_key, ks, dil, transposed=transposed)
+
+            out = Fn.ConvolutionFunction.apply(input.F, self.kernel, table_fn, self.stride == 1)
+        if self.bias is not None:
+            out = out + self.bias
+        return SparseTensor(out, out_key, m)
+
+    def extra_repr(self):
+        return (f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, "
+                f"stride={self.stride}, dilation={self.dilation}")
+
+
+class MinkowskiBatchNorm(nn.Module):
+    """ME.MinkowskiBatchNorm: an `nn.BatchNorm1d` (attribute `bn`, so state-dict keys are
+    `*.bn.weight` ... and the reference init loop resnet.py:101-105 finds it) applied to F.
+
+    Extension used by this repo's fused blocks: `forward(x, relu=True, residual=r)` computes
+    relu(bn(x) + r) in one pass (one HIP kernel forward, one reduction + one pass backward)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+
+    def forward(self, input, relu=False, residual=None):
+        bn = self.bn
+        training = bn.training or not bn.track_running_stats
+        if training and bn.track_running_stats:
+            bn.num_batches_tracked += 1
+        if residual is not None:
+            input._check(residual)
+        gamma = bn.weight if bn.affine else torch.ones(bn.num_features, device=input.F.device)
+        beta = bn.bias if bn.affine else torch.zeros(bn.num_features, device=input.F.device)
+        out = Fn.BatchNormFunction.apply(
+            input.F, gamma, beta, bn.running_mean, bn.running_var, training,
+            bn.momentum if bn.momentum is not None else 0.1, bn.eps,
+            residual.F if residual is not None else None, bool(relu))
+        return SparseTensor(out, input.coordinate_map_key, input.coordinate_manager)
+
+
+class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
+    """Placeholder for ME.MinkowskiSyncBatchNorm (reference train.py:106-107, off by default:
+    `use_sync_batchnorm=False`, train.py:83).  Statistics stay per rank."""
+
+    @classmethod
+    def convert_sync_batchnorm(cls, module, process_group=None):
+        raise NotImplementedError("SyncBatchNorm is optional in the reference (default off) and not built yet")
+
+
+class MinkowskiReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, input):
+        return SparseTensor(Fn.ReLUFunction.apply(input.F), input.coordinate_map_key, input.coordinate_manager)
+
+
+class MinkowskiSumPooling(nn.Module):
+    """ME.MinkowskiSumPooling(kernel_size=2, stride=2, dimension=3) (resnet.py:62-64)."""
+
+    def __init__(self, kernel_size, stride=1, dilation=1, kernel_generator=None, dimension=None):
+        super().__init__()
+        self.kernel_size, self.stride = _as_int(kernel_size), _as_int(stride)
+        assert dimension == 3 and _as_int(dilation) == 1
+        assert self.kernel_size == self.stride and self.kernel_size ** 3 <= 27, \
+            "only non-overlapping pooling (kernel_size == stride) is implemented"
+
+    def forward(self, input):
+        m, in_key = input.coordinate_manager, input.coordinate_map_key
+        out_key = m.stride(in_key, self.stride)
+        nbr, _ = m.kernel_table(in_key, out_key, self.kernel_size, 1)
+        out = Fn.SumPoolFunction.apply(input.F, nbr, m.stride_map(in_key, out_key))
+        return SparseTensor(out, out_key, m)
+
+
+class MinkowskiGlobalAvgPooling(nn.Module):
+    """ME.MinkowskiGlobalAvgPooling() (resnet.py:15-22): row b of the output is batch index b."""
+
+    def forward(self, input):
+        m = input.coordinate_manager
+        out = Fn.GlobalAvgPoolFunction.apply(input.F, m.batch_offsets(input.coordinate_map_key))
+        return SparseTensor(out, CoordinateMapKey(ORIGIN_TS), m)

@@ -1,0 +1,115 @@
+"""SparseTensor / TensorField of the HIP backend (subset of the ME classes used by the
+reference: base_model.py:10-13, resnet.py:164,177, resnet_block.py:66, sparse_conv.py:387-425)."""
+import torch
+
+from . import functional as Fn
+from .coords import CoordinateManager, CoordinateMapKey
+
+
+class SparseTensor:
+    """Feature matrix F [N,C] (ordinary autograd tensor in HBM) + an immutable coordinate map
+    shared by reference through the coordinate manager."""
+
+    def __init__(self, features, coordinate_map_key=None, coordinate_manager=None, coordinates=None, tensor_stride=1):
+        if coordinate_map_key is None:
+            assert coordinates is not None, "give either a coordinate_map_key or coordinates"
+            assert coordinate_manager is None and _is_one(tensor_stride)
+            coordinate_manager = CoordinateManager(D=coordinates.shape[1] - 1, device=coordinates.device)
+            coordinate_map_key = coordinate_manager.insert_field(coordinates.int())
+            if coordinate_manager.levels[1].n != coordinates.shape[0]:
+                raise ValueError("duplicate coordinates: use ME.TensorField(...).sparse() to average them")
+        self._F = features
+        self.coordinate_map_key = coordinate_map_key
+        self._manager = coordinate_manager
+
+    @property
+    def F(self):
+        return self._F
+
+    @property
+    def C(self):
+        return self._manager.get_coordinates(self.coordinate_map_key)
+
+    @property
+    def coordinate_manager(self):
+        return self._manager
+
+    @property
+    def tensor_stride(self):
+        return self.coordinate_map_key.get_tensor_stride()
+
+    @property
+    def D(self):
+        return self._manager.D
+
+    @property
+    def shape(self):
+        return self._F.shape
+
+    @property
+    def device(self):
+        return self._F.device
+
+    def __len__(self):
+        return self._F.shape[0]
+
+    def _check(self, other):
+        if not (self._manager is other._manager and self.coordinate_map_key == other.coordinate_map_key):
+            raise ValueError("SparseTensors must share the coordinate manager and the coordinate map key")
+
+    def __iadd__(self, other):  # `out += residual`, reference resnet_block.py:66
+        self._check(other)
+        self._F = Fn.AddFunction.apply(self._F, other._F)
+        return self
+
+    def __add__(self, other):
+        self._check(other)
+        return SparseTensor(Fn.AddFunction.apply(self._F, other._F), self.coordinate_map_key, self._manager)
+
+    def __repr__(self):
+        return f"SparseTensor(F={tuple(self._F.shape)}, tensor_stride={self.tensor_stride})"
+
+
+def _is_one(ts):
+    return all(int(t) == 1 for t in (ts if isinstance(ts, (list, tuple)) else [ts]))
+
+
+class TensorField:
+    """ME.TensorField(coordinates=[N,1+D] float (batch,x,y,z), features=[N,C]).
+
+    Owns a fresh coordinate manager; `.sparse()` floors the coordinates, inserts them into the
+    hash map and averages the features of rows that collapse onto one voxel (A1, A2)."""
+
+    def __init__(self, features=None, coordinates=None, **kwargs):
+        assert features is not None and coordinates is not None
+        if not coordinates.is_cuda:
+            raise RuntimeError("nerf_downstream_amd.minkowski runs on the GPU only: move the batch to cuda first")
+        self._F, self._C = features, coordinates
+        self._manager = CoordinateManager(D=coordinates.shape[1] - 1, device=coordinates.device)
+        self.coordinate_field_map_key = self._manager.insert_field(coordinates)
+
+    @property
+    def F(self):
+        return self._F
+
+    @property
+    def C(self):
+        return self._C
+
+    @property
+    def coordinate_manager(self):
+        return self._manager
+
+    def sparse(self):
+        m = self._manager
+        n_unique = m.levels[1].n
+        F = self._F
+        if n_unique == F.shape[0]:
+            Fs = F.float()  # no duplicates: unique rows are the input rows, in order
+        else:
+            inv = m.field_inverse.long()
+            order = torch.sort(inv, stable=True).indices.int()  # members of each voxel, input-row order
+            seg = torch.zeros(n_unique + 1, dtype=torch.int32, device=F.device)
+            seg[1:] = torch.cumsum(torch.bincount(inv, minlength=n_unique), 0).int()
+            Fs = Fn.segment_mean(F, order, seg, n_unique)
+        return SparseTensor(Fs, CoordinateMapKey(1), m)

@@ -1,0 +1,107 @@
+"""-m gpu: HIP coordinate maps vs the C oracle, BIT-EXACT (integer work)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import batch_scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _mgr(coords_f):
+    from nerf_downstream_amd import minkowski as ME
+
+    tf = ME.TensorField(coordinates=coords_f.cuda(), features=torch.zeros(coords_f.shape[0], 4).cuda())
+    return ME, tf
+
+
+def _noisy_field(seed, grid, negative, dup):
+    coords, _ = batch_scenes([seed, seed + 1, seed + 2], grid=grid, cin=1, negative=negative)
+    rng = np.random.default_rng(seed)
+    if dup:  # float jitter inside the voxel + repeated rows -> duplicates after flooring
+        extra = coords[rng.integers(0, len(coords), len(coords) // 3)]
+        coords = torch.cat([coords, extra])
+        coords = coords[torch.from_numpy(np.sort(rng.permutation(len(coords))))]
+        order = torch.argsort(coords[:, 0], stable=True)
+        coords = coords[order]
+        coords[:, 1:] += torch.from_numpy(rng.uniform(0, 0.999, (len(coords), 3)).astype(np.float32))
+    return coords
+
+
+@pytest.mark.parametrize("grid,negative,dup", [(16, False, False), (24, True, True), (48, True, False)])
+def test_unique_stride_kernel_maps(oracle_maps, grid, negative, dup):
+    coords = _noisy_field(7, grid, negative, dup)
+    ME, tf = _mgr(coords)
+    m = tf.coordinate_manager
+    q = oracle_maps.quantize(coords.numpy())
+    ui, inv = oracle_maps.unique(q)
+    assert np.array_equal(m.field_unique_index.cpu().numpy(), ui)
+    assert np.array_equal(m.field_inverse.cpu().numpy(), inv)
+    c_ref = {1: q[ui]}
+    assert np.array_equal(m.levels[1].coords.cpu().numpy(), c_ref[1])
+    key = ME.CoordinateMapKey(1)
+    keys = {1: key}
+    for ts in (2, 4, 8):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+        oc, i2o = oracle_maps.stride_map(c_ref[ts // 2], ts)
+        c_ref[ts] = oc
+        assert np.array_equal(m.levels[ts].coords.cpu().numpy(), oc)
+        assert np.array_equal(m.stride_map(keys[ts // 2], keys[ts]).cpu().numpy(), i2o)
+    for ts_in, ts_out, ks in [(1, 1, 3), (1, 2, 2), (2, 4, 3), (2, 4, 1), (4, 4, 3), (4, 8, 3), (8, 8, 3)]:
+        off = oracle_maps.kernel_offsets(ks, ts_in)
+        ref = oracle_maps.kernel_map_table(c_ref[ts_in], c_ref[ts_out], off)
+        nbr, nbr_t = m.kernel_table(keys[ts_in], keys[ts_out], ks, 1, transposed=True)
+        assert np.array_equal(nbr.cpu().numpy(), ref)
+        ref_t = np.full((len(c_ref[ts_in]), off.shape[0]), -1, np.int32)
+        o, k = np.nonzero(ref >= 0)
+        ref_t[ref[o, k], k] = o
+        assert np.array_equal(nbr_t.cpu().numpy(), ref_t)
+        # ME-format rulebook (ballot / prefix-sum compaction), canonical order
+        km = m.kernel_map(keys[ts_in], keys[ts_out], kernel_size=ks)
+        ref_lists = oracle_maps.table_to_lists(ref)
+        assert sorted(km.keys()) == sorted(ref_lists.keys())
+        for kk, v in km.items():
+            assert v.dtype == torch.int32 and np.array_equal(v.cpu().numpy(), ref_lists[kk])
+    boff = m.batch_offsets(keys[4]).cpu().numpy()
+    assert np.array_equal(boff, np.searchsorted(c_ref[4][:, 0], np.arange(4)))
+
+
+def test_full_size_properties():
+    """BASELINE-size grid (128^3 shell, ~50k voxels x 4 samples): size-independent properties."""
+    from nerf_downstream_amd import minkowski as ME
+
+    coords, _ = batch_scenes([1, 2, 3, 4], grid=128, cin=1)
+    tf = ME.TensorField(coordinates=coords.cuda(), features=torch.zeros(len(coords), 4).cuda())
+    m = tf.coordinate_manager
+    k1 = ME.CoordinateMapKey(1)
+    assert m.levels[1].n == len(coords)  # integer coords: no duplicates
+    nbr, _ = m.kernel_table(k1, k1, 3)
+    n = nbr.shape[0]
+    ar = torch.arange(n, device="cuda", dtype=torch.int32)
+    assert torch.equal(nbr[:, 13], ar)  # centre offset = identity
+    for k in range(13):  # symmetry: nbr[nbr[o,k], 26-k] == o
+        v = nbr[:, k] >= 0
+        assert torch.equal(nbr[nbr[v, k].long(), 26 - k], ar[v])
+    k2 = m.stride(k1, 2)
+    i2o = m.stride_map(k1, k2).long()
+    c1, c2 = m.levels[1].coords, m.levels[2].coords
+    assert torch.equal(c2[i2o][:, 0], c1[:, 0])
+    assert torch.equal(c2[i2o][:, 1:], torch.div(c1[:, 1:], 2, rounding_mode="floor") * 2)
+    assert torch.unique(c2, dim=0).shape[0] == c2.shape[0]
+    ch, _ = m.kernel_table(k1, k2, 2)  # children table: every input row appears exactly once
+    flat = ch[ch >= 0]
+    assert flat.numel() == n and torch.equal(torch.sort(flat).values, ar)
+
+
+def test_errors():
+    from nerf_downstream_amd import minkowski as ME
+
+    bad = torch.tensor([[0.0, 40000.0, 0.0, 0.0]])
+    with pytest.raises(ValueError):
+        ME.TensorField(coordinates=bad.cuda(), features=torch.zeros(1, 4).cuda())
+    unsorted = torch.tensor([[1.0, 0, 0, 0], [0.0, 1, 1, 1]])
+    tf = ME.TensorField(coordinates=unsorted.cuda(), features=torch.zeros(2, 4).cuda())
+    with pytest.raises(ValueError):
+        tf.coordinate_manager.batch_size()
+    with pytest.raises(RuntimeError):
+        ME.TensorField(coordinates=unsorted, features=torch.zeros(2, 4))

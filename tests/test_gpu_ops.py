@@ -1,0 +1,158 @@
+"""-m gpu: every float HIP kernel vs the CPU oracle (fp32, tolerances stated per check)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import batch_scenes
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 2e-4  # fp32 accumulation-order differences over <= 27*512 products of O(1) values
+RTOL = 2e-4
+
+
+def _pair(seeds, grid, cin, negative=False):
+    """The same TensorField on the HIP backend and on the oracle."""
+    from nerf_downstream_amd import minkowski as ME
+    from oracle import me_cpu as OME
+
+    coords, feats = batch_scenes(seeds, grid=grid, cin=cin, negative=negative)
+    return ME, OME, ME.TensorField(coordinates=coords.cuda(), features=feats.cuda()), OME.TensorField(coordinates=coords, features=feats)
+
+
+def _to_ts(ME, x, ts):
+    pool = ME.MinkowskiSumPooling(kernel_size=2, stride=2, dimension=3)
+    while x.tensor_stride[0] < ts:
+        x = pool(x)
+    return x
+
+
+@pytest.mark.parametrize(
+    "cin,cout,ksize,stride,ts,grid",
+    [
+        (28, 64, 3, 1, 1, 24),   # stem shape (vector path, Cin not a multiple of 32)
+        (27, 64, 3, 1, 1, 16),   # `features=["sh"]` default: scalar gather path
+        (64, 64, 3, 2, 2, 24),   # layer1.conv1 (strided: dgrad through the transposed table)
+        (64, 64, 3, 1, 4, 24),   # layer1.conv2 (same-map dgrad with flipped offsets)
+        (64, 128, 1, 2, 2, 24),  # downsample 1x1 stride 2
+        (128, 256, 3, 2, 4, 32), # small N: split-K path
+        (256, 256, 3, 1, 8, 32),
+        (5, 7, 3, 1, 1, 12),     # odd channel counts everywhere (fully guarded path)
+    ],
+)
+def test_convolution(oracle_maps, cin, cout, ksize, stride, ts, grid):
+    torch.manual_seed(1)
+    ME, OME, tf, otf = _pair([3, 4], grid, cin, negative=True)
+    x, ox = _to_ts(ME, tf.sparse(), ts), _to_ts(OME, otf.sparse(), ts)
+    assert torch.allclose(x.F.cpu(), ox.F, atol=1e-5)
+    oconv = OME.MinkowskiConvolution(cin, cout, kernel_size=ksize, stride=stride, dimension=3)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=ksize, stride=stride, dimension=3).cuda()
+    conv.load_state_dict(oconv.state_dict())
+    F_g = x.F.detach().clone().requires_grad_(True)
+    F_c = ox.F.detach().clone().requires_grad_(True)
+    y = conv(ME.SparseTensor(F_g, x.coordinate_map_key, x.coordinate_manager))
+    oy = oconv(OME.SparseTensor(F_c, ox.coordinate_map_key, ox.coordinate_manager))
+    assert y.F.shape == oy.F.shape and y.tensor_stride == oy.tensor_stride
+    assert np.array_equal(y.C.cpu().numpy(), oy.C.numpy())
+    assert torch.allclose(y.F.cpu(), oy.F, atol=ATOL, rtol=RTOL)
+    g = torch.randn_like(oy.F)
+    y.F.backward(g.cuda())
+    oy.F.backward(g)
+    assert torch.allclose(F_g.grad.cpu(), F_c.grad, atol=ATOL, rtol=RTOL)
+    scale = max(1.0, float(oconv.kernel.grad.abs().max()))
+    assert torch.allclose(conv.kernel.grad.cpu(), oconv.kernel.grad, atol=ATOL * scale, rtol=RTOL)
+
+
+def test_convolution_is_deterministic():
+    ME, _, tf, _ = _pair([5, 6], 24, 28)
+    x = tf.sparse()
+    conv = ME.MinkowskiConvolution(28, 64, kernel_size=3, dimension=3).cuda()
+    a = conv(x).F
+    b = conv(x).F
+    assert torch.equal(a, b)  # no atomics anywhere: bitwise reproducible
+
+
+@pytest.mark.parametrize("C,relu,res", [(64, False, False), (64, True, False), (128, True, True), (512, False, True)])
+def test_batch_norm(C, relu, res):
+    from nerf_downstream_amd import minkowski as ME
+
+    torch.manual_seed(0)
+    n = 3001
+    x = (torch.randn(n, C) * 2 + 0.5)
+    r = torch.randn(n, C) if res else None
+    bn = ME.MinkowskiBatchNorm(C).cuda()
+    ref = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5), ref.bias.uniform_(-0.5, 0.5)
+    bn.bn.load_state_dict(ref.state_dict())
+    coords = torch.zeros(n, 4)
+    coords[:, 1] = torch.arange(n)
+    m = ME.TensorField(coordinates=coords.cuda(), features=x.cuda()).coordinate_manager
+    key = ME.CoordinateMapKey(1)
+    xg = x.cuda().requires_grad_(True)
+    rg = r.cuda().requires_grad_(True) if res else None
+    y = bn(ME.SparseTensor(xg, key, m), relu=relu, residual=ME.SparseTensor(rg, key, m) if res else None).F
+    xc = x.clone().requires_grad_(True)
+    rc = r.clone().requires_grad_(True) if res else None
+    yc = ref(xc)
+    if res:
+        yc = yc + rc
+    if relu:
+        yc = torch.relu(yc)
+    assert torch.allclose(y.cpu(), yc, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(bn.bn.running_mean.cpu(), ref.running_mean, atol=1e-6)
+    assert torch.allclose(bn.bn.running_var.cpu(), ref.running_var, atol=1e-5)
+    assert int(bn.bn.num_batches_tracked) == 1
+    g = torch.randn(n, C)
+    y.backward(g.cuda())
+    yc.backward(g)
+    assert torch.allclose(xg.grad.cpu(), xc.grad, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(bn.bn.weight.grad.cpu(), ref.weight.grad, atol=2e-3, rtol=1e-4)
+    assert torch.allclose(bn.bn.bias.grad.cpu(), ref.bias.grad, atol=2e-3, rtol=1e-4)
+    if res:
+        assert torch.allclose(rg.grad.cpu(), rc.grad, atol=1e-6)
+    # eval mode uses the running statistics
+    bn.eval(), ref.eval()
+    ye = bn(ME.SparseTensor(x.cuda(), key, m)).F
+    assert torch.allclose(ye.cpu(), ref(x), atol=1e-5, rtol=1e-5)
+
+
+def test_relu_add_pool_globalavg(oracle_maps):
+    ME, OME, tf, otf = _pair([8, 9, 10], 24, 8, negative=True)
+    x, ox = tf.sparse(), otf.sparse()
+    F_g = x.F.detach().clone().requires_grad_(True)
+    F_c = ox.F.detach().clone().requires_grad_(True)
+    xs = ME.SparseTensor(F_g, x.coordinate_map_key, x.coordinate_manager)
+    oxs = OME.SparseTensor(F_c, ox.coordinate_map_key, ox.coordinate_manager)
+    a = ME.MinkowskiReLU()(xs)
+    a += xs
+    oa = OME.MinkowskiReLU()(oxs)
+    oa += oxs
+    p = ME.MinkowskiSumPooling(kernel_size=2, stride=2, dimension=3)(a)
+    op = OME.MinkowskiSumPooling(kernel_size=2, stride=2, dimension=3)(oa)
+    assert np.array_equal(p.C.cpu().numpy(), op.C.numpy())
+    assert torch.allclose(p.F.cpu(), op.F, atol=1e-5)
+    g = ME.MinkowskiGlobalAvgPooling()(p)
+    og = OME.MinkowskiGlobalAvgPooling()(op)
+    assert g.F.shape == (3, 8) and torch.allclose(g.F.cpu(), og.F, atol=1e-5)
+    assert np.array_equal(g.C.cpu().numpy(), og.C.numpy())
+    w = torch.randn(3, 8)
+    (g.F * w.cuda()).sum().backward()
+    (og.F * w).sum().backward()
+    assert torch.allclose(F_g.grad.cpu(), F_c.grad, atol=1e-6)
+
+
+def test_field_to_sparse_average(oracle_maps):
+    from nerf_downstream_amd import minkowski as ME
+    from oracle import me_cpu as OME
+
+    rng = np.random.default_rng(0)
+    coords, feats = batch_scenes([1, 2], grid=12, cin=6, negative=True)
+    rep = torch.from_numpy(np.sort(rng.integers(0, len(coords), 3 * len(coords))))
+    coords, feats = coords[rep].clone(), torch.from_numpy(rng.standard_normal((len(rep), 6)).astype(np.float32))
+    coords[:, 1:] += torch.from_numpy(rng.uniform(0, 0.99, (len(rep), 3)).astype(np.float32))
+    x = ME.TensorField(coordinates=coords.cuda(), features=feats.cuda()).sparse()
+    ox = OME.TensorField(coordinates=coords, features=feats).sparse()
+    assert x.F.shape[0] < len(rep)
+    assert np.array_equal(x.C.cpu().numpy(), ox.C.numpy())
+    assert torch.allclose(x.F.cpu(), ox.F, atol=1e-6)
