@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- voxels/s, forward+backward(+all-reduce+SGD) of Mink-ResNet14 on synthetic
+PeRFception-CO3D-shaped plenoxel grids (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one full training iteration over one batch of `--batch` scenes per GPU
+(~51.6 k voxels x 28 features each, resident in HBM before the timed region): coordinate maps
++ kernel maps rebuilt from the raw float coordinates (as ME does every iteration), forward,
+cross-entropy, backward, bucketed gradient all-reduce (N>1) and the SGD(momentum) update.
+Weak scaling: per-GPU batch is fixed (reference semantics: train.batch_size is per GPU).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside the
+timed region) and `cpu_baseline` (the CPU oracle = restatement of ME's CPU algorithm, timed on
+the host cores on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def make_batches(n_batches, batch, rank, num_classes, grid, cin):
+    from nerf_downstream_amd.co3d_3d.src.data.synthetic import SparseVoxelDataset
+    from nerf_downstream_amd.co3d_3d.src.data.utils import collate_mink
+
+    feats = ["density", "sh"] if cin == 28 else ["sh"]
+    ds = SparseVoxelDataset(phase="train", num_samples=1 << 20, num_classes=num_classes, grid=grid, features=feats)
+    out = []
+    for b in range(n_batches):
+        base = (rank * n_batches + b) * batch
+        out.append(collate_mink([ds[base + i] for i in range(batch)]))
+    return out
+
+
+def cpu_baseline(model_name, cin, num_classes, grid, state_dict, seconds_budget=25.0):
+    """Times the CPU oracle (oracle/me_cpu.py + oracle/mink_maps.c: sequential hash insert, per
+    offset gather -> SGEMM -> scatter-add, torch BatchNorm1d) on a bounded sample: full
+    fwd+bwd steps of 2-scene batches (BASELINE config #0) until ~seconds_budget is spent."""
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from oracle import me_cpu as OME
+
+    ref = get_model(model_name, cin, num_classes, ME=OME)
+    ref.load_state_dict(state_dict)
+    batches = make_batches(1, 2, 977, num_classes, grid, cin)
+    vox, t_total, steps = 0, 0.0, 0
+    while t_total < seconds_budget and steps < 8:
+        b = batches[0]
+        t0 = time.perf_counter()
+        out = ref(ref.process_input(b))
+        loss = F.cross_entropy(out, b["labels"].long())
+        loss.backward()
+        t_total += time.perf_counter() - t0
+        vox += b["coordinates"].shape[0]
+        steps += 1
+        ref.zero_grad(set_to_none=True)
+    return {
+        "value": vox / t_total,
+        "unit": "voxels/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{steps} fwd+bwd steps of {model_name} on 2-scene batches ({vox // max(steps,1)} voxels/step), "
+        f"CPU restatement of the ME CPU algorithm (ME binary unavailable), {t_total:.1f} s",
+    }
+
+
+def roofline_from_timings(timings):
+    """Dominant conv kernel of the timed region: achieved = algorithmic FLOPs per launch
+    (2 * pairs * Cin * Cout, pairs = valid neighbour-table entries) / mean HIP-event duration."""
+    best = None
+    for tag, ent in timings.items():
+        ms = [s.elapsed_time(e) for s, e in ent["events"]]
+        if not ms:
+            continue
+        tot = sum(ms)
+        if best is None or tot > best[1]:
+            best = (tag, tot, ms, ent["meta"])
+    if best is None:
+        return None
+    tag, tot, ms, meta = best
+    pairs = int((meta["nbr"] >= 0).sum().item())
+    flops = 2.0 * pairs * meta["cin"] * meta["cout"]
+    nbytes = 4.0 * (meta["n_in"] * meta["cin"] + meta["n_out"] * meta["cout"] + meta["K"] * meta["cin"] * meta["cout"]) + 8.0 * pairs
+    avg_ms = tot / len(ms)
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma",
+        "kernel": tag,
+        "achieved": achieved,
+        "peak": MFMA_F32_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+        "traffic": None,
+        "avg_ms": avg_ms,
+        "launches": len(ms),
+        "flops_per_launch": flops,
+        "algorithmic_bytes_per_launch": nbytes,
+        "hbm_frac_at_algorithmic_bytes": nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "pairs": pairs,
+        "share_of_conv_kernel_time": tot / sum(sum(s.elapsed_time(e) for s, e in v["events"]) for v in timings.values()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="scenes per GPU (co3d_cls.gin: train.batch_size = 16)")
+    ap.add_argument("--model", default="ResNet14")
+    ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--in-channel", type=int, default=28)
+    ap.add_argument("--num-classes", type=int, default=51)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from nerf_downstream_amd import _lib
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from nerf_downstream_amd.minkowski import functional as Fn
+    from nerf_downstream_amd.parallel import BucketedGradAllReduce
+
+    _lib.lib()  # fail loudly if the HIP backend is missing
+
+    torch.manual_seed(777)  # same initial weights on every rank (reference: pl.seed_everything)
+    model = get_model(args.model, args.in_channel, args.num_classes).to(dev)
+    state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=200000)
+    reducer = BucketedGradAllReduce(model)
+
+    batches = make_batches(2, args.batch, rank, args.num_classes, args.grid, args.in_channel)
+    batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+    vox_per_step = [int(b["coordinates"].shape[0]) for b in batches]
+
+    def step(i):
+        b = batches[i % len(batches)]
+        reducer.zero_grad()
+        out = model(model.process_input(b))
+        loss = F.cross_entropy(out, b["labels"].long())
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        sched.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    if not args.no_kernel_timing:
+        Fn.enable_kernel_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    timings = Fn.kernel_timings()
+    Fn.enable_kernel_timing(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    vox = torch.tensor([float(sum(vox_per_step[(args.warmup + i) % len(batches)] for i in range(args.steps)))],
+                       dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vox, op=dist.ReduceOp.SUM)
+    loss_val = float(loss.item())
+    if not (loss_val == loss_val and abs(loss_val) < 1e30):
+        raise SystemExit(f"non-finite loss {loss_val}: invalid run")
+
+    if rank == 0:
+        res = {
+            "metric": "voxels/sec fwd+bwd Mink-ResNet14 on CO3D plenoxels",
+            "value": vox.item() / tmax.item(),
+            "unit": "voxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": tmax.item() / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Mink-{args.model} full CO3D-category classification ({args.num_classes} classes), "
+                f"batch={args.batch}/GPU, {args.grid}^3 synthetic plenoxel grids (~{vox_per_step[0] // args.batch} voxels x "
+                f"{args.in_channel} SH+density features per scene), fp32, fwd+bwd+SGD step incl. coordinate/kernel map build",
+                "global_batch": args.batch * world,
+                "voxels_per_step_per_gpu": vox_per_step[0],
+                "parallelism": f"dp{world}",
+                "final_loss": loss_val,
+            },
+        }
+        if timings:
+            res["roofline"] = roofline_from_timings(timings)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.model, args.in_channel, args.num_classes, args.grid, state0)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

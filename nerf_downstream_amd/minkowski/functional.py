@@ -26,6 +26,37 @@ def _bytes(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# ---------------------------------------------------------------------- kernel timing
+# bench.py measures the dominant kernel live with HIP events recorded on the launch stream.
+_TIMING = None  # None = off; else {tag: {"events": [(start, end)], "meta": {...}}}
+
+
+def enable_kernel_timing(on=True):
+    global _TIMING
+    _TIMING = {} if on else None
+
+
+def kernel_timings():
+    return _TIMING
+
+
+class _timed:
+    def __init__(self, tag, **meta):
+        self.tag, self.meta = tag, meta
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *exc):
+        if _TIMING is not None:
+            self.e.record()
+            ent = _TIMING.setdefault(self.tag, {"events": [], "meta": self.meta})
+            ent["events"].append((self.s, self.e))
+            ent["meta"] = self.meta
+
+
 # ------------------------------------------------------------------------- convolution
 def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None):
     """y[o] = sum_k x[nbr[o,k]] @ W[k] (+bias) on the fp32 matrix cores."""
@@ -35,12 +66,14 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None):
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
     ksplit = int(L.mink_conv_plan_ksplit(n_out, K, cout))
     ws = torch.empty(ksplit * n_out * cout, dtype=torch.float32, device=x.device) if ksplit > 1 else None
-    check(
-        L.mink_conv_gather_gemm(
-            x.data_ptr(), x.stride(0), cin, w.data_ptr(), int(w_transposed), int(flip_k), nbr.data_ptr(), n_out, K,
-            y.data_ptr(), cout, cout, _ptr(bias), ksplit, _ptr(ws), _stream(),
+    tag = f"{'dgrad' if w_transposed else 'fwd'}[{n_out}x{K}:{cin}->{cout}]"
+    with _timed(tag, kind="gather_gemm", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr, ksplit=ksplit):
+        check(
+            L.mink_conv_gather_gemm(
+                x.data_ptr(), x.stride(0), cin, w.data_ptr(), int(w_transposed), int(flip_k), nbr.data_ptr(), n_out, K,
+                y.data_ptr(), cout, cout, _ptr(bias), ksplit, _ptr(ws), _stream(),
+            )
         )
-    )
     return y
 
 
@@ -50,12 +83,13 @@ def conv_wgrad(x, dy, nbr, kernel_shape):
     cin, cout = x.shape[1], dy.shape[1]
     dw = torch.empty(kernel_shape, dtype=torch.float32, device=x.device)
     ws = _bytes(L.mink_conv_wgrad_workspace_bytes(n_out, K, cin, cout), x.device)
-    check(
-        L.mink_conv_wgrad(
-            x.data_ptr(), x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K, dw.data_ptr(),
-            ws.data_ptr(), _stream(),
+    with _timed(f"wgrad[{n_out}x{K}:{cin}->{cout}]", kind="wgrad", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr):
+        check(
+            L.mink_conv_wgrad(
+                x.data_ptr(), x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K,
+                dw.data_ptr(), ws.data_ptr(), _stream(),
+            )
         )
-    )
     return dw
 
 
