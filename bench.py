@@ -150,7 +150,7 @@ def main():
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=200000)
-    reducer = BucketedGradAllReduce(model)
+    reducer = BucketedGradAllReduce(model) if world > 1 else None  # N=1: autograd hands gradients over without a copy
 
     batches = make_batches(2, args.batch, rank, args.num_classes, args.grid, args.in_channel)
     batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
@@ -158,11 +158,15 @@ def main():
 
     def step(i):
         b = batches[i % len(batches)]
-        reducer.zero_grad()
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
         out = model(model.process_input(b))
         loss = F.cross_entropy(out, b["labels"].long())
         loss.backward()
-        reducer.finish()
+        if reducer is not None:
+            reducer.finish()
         opt.step()
         sched.step()
         return loss

@@ -201,70 +201,149 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------------------ wgrad
-constexpr int WR = 32;  // rows per reduction chunk
-constexpr int WT = 64;  // cin / cout super-tile
+// dW[k][ci][co] = sum over pairs (i,o) of offset k:  x[i][ci] * dy[o][co].
+//
+// Workgroup = (group of G offsets) x (64x64 ci/co super-tile) x (row range).  Per 128-row tile
+// of the range the dy tile is staged ONCE in LDS and shared by the G offsets; for each offset
+// the rows that really have a neighbour are compacted with a wave64 ballot + prefix rank (the
+// rulebook of that tile, built on the fly), only those x rows are gathered, and the MFMA
+// contraction runs over the compacted pairs -- no work is spent on missing neighbours.
+// Partial sums stay in registers over the whole row range; row splits are reduced
+// deterministically through a slab workspace (no atomics).
+constexpr int WT = 64;      // ci / co super-tile
+constexpr int WROWS = 128;  // rows per tile
+constexpr int WLD = WT + 4; // LDS row stride (floats)
 
 struct WgradParams {
   const float *x;
   const float *dy;
   const int *nbr;
-  float *out;  // dw (zsplit == 1) or workspace [zsplit][K][cin][cout]
+  float *out;  // dw (nsplit == 1) or workspace [nsplit][K][cin][cout]
   int64_t n_out, rows_per_split;
-  int ldx, cin, ldy, cout, K, ct_tiles;
+  int ldx, cin, ldy, cout, K, ct_tiles, ngroups;
 };
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
-  __shared__ __attribute__((aligned(16))) float sX[WR * WT];
-  __shared__ __attribute__((aligned(16))) float sD[WR * WT];
+// G: offsets per workgroup.  PAIRSPLIT: cin <= 32, the two wave rows split the pair list
+// instead of the (empty) second ci tile.
+template <int G, bool PAIRSPLIT>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
+  __shared__ __attribute__((aligned(16))) float sD[WROWS * WLD];
+  __shared__ __attribute__((aligned(16))) float sX[WROWS * WLD];
+  __shared__ int s_row[WROWS + 4];
+  __shared__ int s_src[WROWS + 4];
+  __shared__ int s_cnt[2];
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k = blockIdx.x;
-  const int ci0 = (blockIdx.y / p.ct_tiles) * WT, co0 = (blockIdx.y % p.ct_tiles) * WT;
-  const int64_t rbeg = (int64_t)blockIdx.z * p.rows_per_split;
+  const int grp = blockIdx.x % p.ngroups;
+  const int tile_id = blockIdx.x / p.ngroups;
+  const int ci0 = (tile_id / p.ct_tiles) * WT, co0 = (tile_id % p.ct_tiles) * WT;
+  const int k0 = grp * G;
+  const int64_t rbeg = (int64_t)blockIdx.y * p.rows_per_split;
   const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
 
   const bool vecx = ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
   const bool vecd = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.dy) & 15) == 0);
-  const int cc = tid & 15, rr = tid >> 4;  // rows rr + 16 i, float4 column cc
+  const int c4 = tid & 15, rr = tid >> 4;  // staging: float4 column c4, rows rr + 16 i
 
-  f32x16 acc = {0};
-  float4 rx[2], rd[2];
-  auto load_chunk = [&](int64_t r0) {
+  const int wa = wave >> 1, wn = wave & 1, h = lane >> 5, col = lane & 31;
+  const int wm = PAIRSPLIT ? 0 : wa;
+
+  f32x16 acc[G];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t row = r0 + rr + 16 * i;
-      int src = -1;
-      if (row < rend) src = p.nbr[row * p.K + k];
-      const int ci = ci0 + 4 * cc, co = co0 + 4 * cc;
-      rx[i] = src >= 0 ? ld4_guard(p.x + (int64_t)src * p.ldx + ci, p.cin - ci, vecx) : make_float4(0.f, 0.f, 0.f, 0.f);
-      // rows without a neighbour contribute nothing; skip their dy too
-      rd[i] = src >= 0 ? ld4_guard(p.dy + row * p.ldy + co, p.cout - co, vecd) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = 0; g < G; ++g) acc[g] = (f32x16){0};
+
+  for (int64_t r0 = rbeg; r0 < rend; r0 += WROWS) {
+    __syncthreads();  // previous tile fully consumed
+    // ---- dy tile: rows r0.., columns co0..co0+63
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = rr + 16 * i;
+      const int64_t row = r0 + r;
+      const int co = co0 + 4 * c4;
+      const float4 v = row < rend ? ld4_guard(p.dy + row * p.ldy + co, p.cout - co, vecd) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(&sD[r * WLD + 4 * c4]) = v;
     }
-  };
-  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, col = lane & 31;
-  if (rbeg < rend) load_chunk(rbeg);
-  for (int64_t r0 = rbeg; r0 < rend; r0 += WR) {
-    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<float4 *>(&sX[(rr + 16 * i) * WT + 4 * cc]) = rx[i];
-      *reinterpret_cast<float4 *>(&sD[(rr + 16 * i) * WT + 4 * cc]) = rd[i];
-    }
-    __syncthreads();
-    if (r0 + WR < rend) load_chunk(r0 + WR);
-#pragma unroll
-    for (int s = 0; s < WR / 2; ++s) {
-      const int r = 2 * s + h;
-      const float a = sX[r * WT + 32 * wm + col];
-      const float b = sD[r * WT + 32 * wn + col];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int g = 0; g < G; ++g) {
+      const int k = k0 + g;
+      if (k >= p.K) break;  // uniform
+      // ---- compact the rows of this tile that have a neighbour at offset k
+      if (g > 0) __syncthreads();  // MFMAs of the previous offset are done with sX / the lists
+      int v = -1, rank = 0;
+      if (tid < WROWS) {  // waves 0 and 1 (wave-uniform branch)
+        const int64_t row = r0 + tid;
+        v = row < rend ? p.nbr[row * p.K + k] : -1;
+        const unsigned long long mm = __ballot(v >= 0);
+        rank = wave_rank(mm);
+        if (lane == 0) s_cnt[wave] = __popcll(mm);
+      }
+      __syncthreads();
+      const int cnt0 = s_cnt[0];
+      const int m = cnt0 + s_cnt[1];
+      const int mpad = (m + 3) & ~3;
+      if (v >= 0) {
+        const int pos = (wave == 1 ? cnt0 : 0) + rank;
+        s_row[pos] = tid;
+        s_src[pos] = v;
+      }
+      if (tid >= WROWS && tid - WROWS < mpad - m) {  // tail pairs: dy row 0 times a zero x row
+        s_row[m + tid - WROWS] = 0;
+        s_src[m + tid - WROWS] = -1;
+      }
+      __syncthreads();
+      // ---- gather the x rows of the compacted pairs (zero rows for the tail)
+      for (int pr = rr; pr < mpad; pr += 16) {
+        const int src = s_src[pr];
+        const int ci = ci0 + 4 * c4;
+        const float4 xv = src >= 0 ? ld4_guard(p.x + (int64_t)src * p.ldx + ci, p.cin - ci, vecx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(&sX[pr * WLD + 4 * c4]) = xv;
+      }
+      __syncthreads();
+      // ---- contraction over the compacted pairs, two pairs per MFMA
+      const int nsteps = mpad >> 1;
+      if (PAIRSPLIT) {
+        for (int s = wa; s < nsteps; s += 2) {
+          const int r = 2 * s + h;
+          const float a = sX[r * WLD + col];
+          const float b = sD[s_row[r] * WLD + 32 * wn + col];
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
+        }
+      } else {
+        for (int s = 0; s < nsteps; ++s) {
+          const int r = 2 * s + h;
+          const float a = sX[r * WLD + 32 * wm + col];
+          const float b = sD[s_row[r] * WLD + 32 * wn + col];
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
+        }
+      }
     }
   }
-  float *dst = p.out + ((int64_t)blockIdx.z * p.K + k) * p.cin * p.cout;
+
+  // ---- epilogue: (pair-split: add the two halves through LDS) then store the partial slab
+  float *dst = p.out + (int64_t)blockIdx.y * p.K * p.cin * p.cout;
   const int co = co0 + 32 * wn + col;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (ci < p.cin && co < p.cout) dst[(int64_t)ci * p.cout + co] = acc[r];
+  for (int g = 0; g < G; ++g) {
+    const int k = k0 + g;
+    if (k >= p.K) break;
+    if (PAIRSPLIT) {
+      __syncthreads();
+      if (wa == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sX[(wn * 16 + r) * 64 + lane] = acc[g][r];
+      }
+      __syncthreads();
+      if (wa == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] += sX[(wn * 16 + r) * 64 + lane];
+      }
+      if (wa == 1) continue;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (ci < p.cin && co < p.cout) dst[((int64_t)k * p.cin + ci) * p.cout + co] = acc[g][r];
+    }
   }
 }
 
@@ -277,17 +356,36 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
   out[i] = s;
 }
 
-static int wgrad_zsplit(int64_t n_out, int K, int cin, int cout, int64_t *rows_per_split) {
-  const int64_t xy = (int64_t)K * cdiv(cin, WT) * cdiv(cout, WT);
-  int64_t z = cdiv(2048, xy);
-  const int64_t zmax = cdiv(n_out, 256);
-  if (z > zmax) z = zmax;
+struct WgradPlan {
+  int G, ngroups, nsplit;
+  int64_t rows_per_split;
+};
+
+static WgradPlan wgrad_plan(int64_t n_out, int K, int cin, int cout) {
+  WgradPlan pl;
+  const int64_t tiles = cdiv(cin, WT) * cdiv(cout, WT);
+  const int64_t row_tiles = cdiv(n_out, WROWS);
+  // offsets per workgroup: share the dy tile between as many offsets as parallelism allows
+  pl.G = 1;
+  if (K >= 9 && tiles * cdiv(K, 9) * row_tiles >= 1024) pl.G = 9;
+  else if (K >= 3 && tiles * cdiv(K, 3) * row_tiles >= 1024) pl.G = 3;
+  pl.ngroups = (int)cdiv(K, pl.G);
+  const int64_t xy = tiles * pl.ngroups;
+  int64_t z = cdiv(1024, xy);
+  if (z > row_tiles) z = row_tiles;
   if (z < 1) z = 1;
-  int64_t rps = align_up(cdiv(n_out, z), WR);
-  z = cdiv(n_out, rps);
-  if (z < 1) z = 1;
-  *rows_per_split = rps;
-  return (int)z;
+  pl.rows_per_split = align_up(cdiv(n_out, z), WROWS);
+  pl.nsplit = (int)cdiv(n_out, pl.rows_per_split);
+  if (pl.nsplit < 1) pl.nsplit = 1;
+  return pl;
+}
+
+template <int G>
+static void launch_wgrad(const WgradParams &p, dim3 grid, hipStream_t st) {
+  if (p.cin <= 32)
+    wgrad_kernel<G, true><<<grid, 256, 0, st>>>(p);
+  else
+    wgrad_kernel<G, false><<<grid, 256, 0, st>>>(p);
 }
 
 }  // namespace mink
@@ -337,9 +435,8 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
 }
 
 int64_t mink_conv_wgrad_workspace_bytes(int64_t n_out, int32_t K, int32_t cin, int32_t cout) {
-  int64_t rps;
-  const int z = wgrad_zsplit(n_out, K, cin, cout, &rps);
-  return z > 1 ? (int64_t)z * K * cin * cout * 4 : 0;
+  const WgradPlan pl = wgrad_plan(n_out, K, cin, cout);
+  return pl.nsplit > 1 ? (int64_t)pl.nsplit * K * cin * cout * 4 : 0;
 }
 
 int mink_conv_wgrad(const float *x, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
@@ -353,18 +450,21 @@ int mink_conv_wgrad(const float *x, int32_t ldx, int32_t cin, const float *dy, i
     return MINK_OK;
   }
   MINK_REQUIRE(x && dy && nbr, "wgrad: NULL pointer");
+  const WgradPlan pl = wgrad_plan(n_out, K, cin, cout);
+  MINK_REQUIRE(pl.nsplit == 1 || workspace, "wgrad: needs a workspace");
   WgradParams p;
-  const int z = wgrad_zsplit(n_out, K, cin, cout, &p.rows_per_split);
-  MINK_REQUIRE(z == 1 || workspace, "wgrad: needs a workspace");
-  p.x = x, p.dy = dy, p.nbr = nbr, p.out = z > 1 ? (float *)workspace : dw;
-  p.n_out = n_out, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K;
+  p.x = x, p.dy = dy, p.nbr = nbr, p.out = pl.nsplit > 1 ? (float *)workspace : dw;
+  p.n_out = n_out, p.rows_per_split = pl.rows_per_split, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K;
   p.ct_tiles = (int)cdiv(cout, WT);
-  const dim3 grid((unsigned)K, (unsigned)(cdiv(cin, WT) * p.ct_tiles), (unsigned)z);
-  wgrad_kernel<<<grid, 256, 0, st>>>(p);
+  p.ngroups = pl.ngroups;
+  const dim3 grid((unsigned)(pl.ngroups * cdiv(cin, WT) * p.ct_tiles), (unsigned)pl.nsplit);
+  if (pl.G == 9) launch_wgrad<9>(p, grid, st);
+  else if (pl.G == 3) launch_wgrad<3>(p, grid, st);
+  else launch_wgrad<1>(p, grid, st);
   MINK_CHECK_LAUNCH();
-  if (z > 1) {
+  if (pl.nsplit > 1) {
     const int64_t count = (int64_t)K * cin * cout;
-    slab_reduce_kernel<<<dim3((unsigned)cdiv(count, 256)), 256, 0, st>>>((const float *)workspace, count, z, dw);
+    slab_reduce_kernel<<<dim3((unsigned)cdiv(count, 256)), 256, 0, st>>>((const float *)workspace, count, pl.nsplit, dw);
     MINK_CHECK_LAUNCH();
   }
   return MINK_OK;

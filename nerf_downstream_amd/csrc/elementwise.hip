@@ -62,13 +62,31 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
   }
 }
 
-__global__ void bn_stats_finalize_kernel(const double *__restrict__ partial, int nblk, int64_t n, int C, float eps,
-                                         float momentum, float *__restrict__ mean, float *__restrict__ invstd,
-                                         float *running_mean, float *running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * 2 * C + c], ss += partial[(int64_t)b * 2 * C + C + c];
+// Sum the per-workgroup partials of 16 channels with 16 slices of workgroups each; returns
+// (sum0, sum1) of channel c to the slice-0 thread.
+__device__ __forceinline__ bool finalize_sums(const double *__restrict__ partial, int nblk, int C, int &c, double &s,
+                                              double &ss) {
+  __shared__ double s_a[256], s_b[256];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  c = blockIdx.x * 16 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int blk = sl; blk < nblk; blk += 16) a += partial[(int64_t)blk * 2 * C + c], b += partial[(int64_t)blk * 2 * C + C + c];
+  s_a[threadIdx.x] = a, s_b[threadIdx.x] = b;
+  __syncthreads();
+  if (sl != 0 || c >= C) return false;
+  for (int j = 1; j < 16; ++j) a += s_a[j * 16 + cl], b += s_b[j * 16 + cl];
+  s = a, ss = b;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double *__restrict__ partial, int nblk, int64_t n,
+                                                                int C, float eps, float momentum,
+                                                                float *__restrict__ mean, float *__restrict__ invstd,
+                                                                float *running_mean, float *running_var) {
+  int c;
+  double s, ss;
+  if (!finalize_sums(partial, nblk, C, c, s, ss)) return;
   const double m = s / (double)n;
   double var = ss / (double)n - m * m;
   if (var < 0.0) var = 0.0;
@@ -81,13 +99,12 @@ __global__ void bn_stats_finalize_kernel(const double *__restrict__ partial, int
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblk, int C,
-                                       const float *__restrict__ gamma, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * 2 * C + c], ss += partial[(int64_t)b * 2 * C + C + c];
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblk, int C,
+                                                              const float *__restrict__ gamma,
+                                                              float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  int c;
+  double s, ss;
+  if (!finalize_sums(partial, nblk, C, c, s, ss)) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)ss;
 }
@@ -297,7 +314,7 @@ int mink_bn_stats(const float *x, int64_t n, int32_t C, float eps, float momentu
   int nblk = 0;
   int rc = launch_colreduce(0, x, nullptr, nullptr, n, C, nullptr, nullptr, (double *)workspace, st, &nblk);
   if (rc) return rc;
-  bn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, 64)), 64, 0, st>>>((const double *)workspace, nblk, n, C, eps,
+  bn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, 16)), 256, 0, st>>>((const double *)workspace, nblk, n, C, eps,
                                                                        momentum, mean, invstd, running_mean,
                                                                        running_var);
   MINK_CHECK_LAUNCH();
@@ -334,7 +351,7 @@ int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int3
   int nblk = 0;
   int rc = launch_colreduce(1, dy, x, yr, n, C, mean, invstd, (double *)workspace, st, &nblk);
   if (rc) return rc;
-  bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, 64)), 64, 0, st>>>((const double *)workspace, nblk, C, gamma, dgamma,
+  bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, 16)), 256, 0, st>>>((const double *)workspace, nblk, C, gamma, dgamma,
                                                                      dbeta);
   MINK_CHECK_LAUNCH();
   const int64_t n4 = n * (C >> 2);
