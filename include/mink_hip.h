@@ -105,6 +105,16 @@ int64_t mink_rulebook_workspace_bytes(int64_t n_out, int32_t K);
 int mink_rulebook(const int32_t *nbr, int64_t n_out, int32_t K, int32_t *counts, int32_t *pairs_in,
                   int32_t *pairs_out, void *workspace, void *stream);
 
+/* Parity-class permutation of the rows of a tensor-stride-`ts` map: rows grouped by the parity
+ * of (coordinate / ts) per axis (8 classes), each class segment padded to a multiple of `pad`
+ * rows with -1.  perm[mink_class_partition_rows(n,pad)].  Used by the input-gradient of
+ * stride-2 convolutions (resnet_block.py:29-37 with stride 2): all rows of one class are reached
+ * through the same 2^p kernel offsets, so class-pure tiles skip the other offsets. */
+int64_t mink_class_partition_rows(int64_t n, int32_t pad);
+int64_t mink_class_partition_workspace_bytes(int64_t n);
+int mink_class_partition(const int32_t *coords, int64_t n, int32_t ts, int32_t pad, int32_t *perm,
+                         void *workspace, void *stream);
+
 /* Row ranges of each batch index in a coordinate list whose batch column is
  * non-decreasing (guaranteed by ME.utils.sparse_collate, data/utils.py:25-30).
  * batch_offsets[B+1].  Sets MINK_STATUS_UNSORTED otherwise.  (ME origin_map.) */
@@ -126,15 +136,18 @@ int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *bat
  *                        re-uses the forward table: nbr_t[i][k] == nbr[i][K-1-k])
  *   nbr[n_out][K]      : neighbour table;  y[n_out][ldy] receives cout columns
  *   bias[cout] or NULL
+ *   row_perm/n_virtual : optional row permutation (NULL/0 = identity): tile row v computes
+ *                        output row row_perm[v], -1 entries are padding (mink_class_partition)
  *   ksplit             : >1 splits the K offsets over `ksplit` workgroups per tile and
  *                        reduces through `workspace` (ksplit*n_out*cout floats)
  */
 /* Split-K factor the library recommends for a layer (1 for large row counts). */
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout);
 int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
-                          int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, float *y,
-                          int32_t ldy, int32_t cout, const float *bias, int32_t ksplit,
-                          float *workspace, void *stream);
+                          int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K,
+                          const int32_t *row_perm, int64_t n_virtual, float *y, int32_t ldy,
+                          int32_t cout, const float *bias, int32_t ksplit, float *workspace,
+                          void *stream);
 
 /* Weight gradient dW[k] = X[nbr[.][k]]^T @ dY, split over row blocks and reduced
  * deterministically (no atomics).  workspace >= mink_conv_wgrad_workspace_bytes(). */

@@ -24,11 +24,14 @@ SIGNATURES = {
     "mink_kernel_map": (ctypes.c_int, [_p, _p, _i64, _p, _i64, _p, _i32, _p, _p, _p]),
     "mink_rulebook_workspace_bytes": (_i64, [_i64, _i32]),
     "mink_rulebook": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "mink_class_partition_rows": (_i64, [_i64, _i32]),
+    "mink_class_partition_workspace_bytes": (_i64, [_i64]),
+    "mink_class_partition": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _p]),
     "mink_batch_offsets": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p]),
     "mink_conv_plan_ksplit": (ctypes.c_int, [_i64, _i32, _i32]),
     "mink_conv_gather_gemm": (
         ctypes.c_int,
-        [_p, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _i32, _i32, _p, _i32, _p, _p],
+        [_p, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _p, _i32, _p, _p],
     ),
     "mink_conv_wgrad_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32]),
     "mink_conv_wgrad": (ctypes.c_int, [_p, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _p, _p]),

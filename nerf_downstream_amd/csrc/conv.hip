@@ -25,7 +25,9 @@ struct GemmParams {
   const float *bias;
   float *y;
   float *ws;
-  int64_t n_out;
+  const int *row_perm;  // optional: tile row v computes output row row_perm[v] (-1 = padding)
+  int64_t n_out;        // rows of y / of the neighbour table
+  int64_t n_virtual;    // rows iterated (== n_out without a permutation)
   int ldx, cin, ldy, cout, K, flip_k, kper;
 };
 
@@ -46,6 +48,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float sA[BM * LDA];
   __shared__ __attribute__((aligned(16))) float sB[BK * BN];
   __shared__ int s_nbr[BM * KMAX];
+  __shared__ int s_orow[BM];
   __shared__ unsigned s_kmask;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,16 +60,21 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
 
   // ---- stage this tile's slice of the neighbour table; find offsets with any neighbour
   if (tid == 0) s_kmask = 0u;
+  if (tid < BM) {
+    const int64_t v = o0 + tid;
+    int orow = -1;
+    if (v < p.n_virtual) orow = p.row_perm ? p.row_perm[v] : (int)v;
+    s_orow[tid] = orow;
+  }
   __syncthreads();
   {
     unsigned m = 0u;
-    const int64_t base = o0 * K;
-    const int64_t lim = p.n_out * K;
     for (int e = tid; e < BM * K; e += 256) {
-      const int64_t g = base + e;
-      const int v = g < lim ? p.nbr[g] : -1;
+      const int lr = e / K, kk = e - lr * K;
+      const int orow = s_orow[lr];
+      const int v = orow >= 0 ? p.nbr[(int64_t)orow * K + kk] : -1;
       s_nbr[e] = v;
-      if (v >= 0) m |= 1u << (e % K);
+      if (v >= 0) m |= 1u << kk;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d);
@@ -178,8 +186,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
   const float bias_b = (direct && p.bias && c_b < p.cout) ? p.bias[c_b] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int64_t row = o0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (row < p.n_out) {
+    const int64_t row = s_orow[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+    if (row >= 0) {
       if (c_a < p.cout) dst[row * ldd + c_a] = acc0[r] + bias_a;
       if (c_b < p.cout) dst[row * ldd + c_b] = acc1[r] + bias_b;
     }
@@ -223,126 +231,169 @@ struct WgradParams {
   int ldx, cin, ldy, cout, K, ct_tiles, ngroups;
 };
 
-// G: offsets per workgroup.  PAIRSPLIT: cin <= 32, the two wave rows split the pair list
-// instead of the (empty) second ci tile.
-template <int G, bool PAIRSPLIT>
+// G: offsets per workgroup.  NARROW: cin <= 32 -- the x tile is 32 floats wide and the two
+// wave rows split the pair list instead of the (empty) second ci tile.
+// Software pipeline per tile: all G pair lists are built up front from one nbr load per row;
+// then for each offset the x gather of offset g+1 is in flight (registers) while the MFMAs
+// of offset g run from LDS.
+template <int G, bool NARROW>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
+  constexpr int XW = NARROW ? 32 : 64;      // x tile width (floats)
+  constexpr int XLD = XW + 4;               // LDS row stride
+  constexpr int XC4 = XW / 4;               // float4 columns per x row
+  constexpr int XRP = 256 / XC4;            // x rows per staging pass
+  constexpr int XNI = WROWS / XRP;          // staging passes (float4 registers per thread)
+  constexpr int LL = WROWS;                 // list length (pair count is padded to 16, <= 128)
   __shared__ __attribute__((aligned(16))) float sD[WROWS * WLD];
-  __shared__ __attribute__((aligned(16))) float sX[WROWS * WLD];
-  __shared__ int s_row[WROWS + 4];
-  __shared__ int s_src[WROWS + 4];
-  __shared__ int s_cnt[2];
+  __shared__ __attribute__((aligned(16))) float sX[WROWS * XLD];
+  __shared__ __attribute__((aligned(16))) int s_row[G * LL];
+  __shared__ int s_src[G * LL];
+  __shared__ int s_cnt[G * 2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = blockIdx.x % p.ngroups;
   const int tile_id = blockIdx.x / p.ngroups;
   const int ci0 = (tile_id / p.ct_tiles) * WT, co0 = (tile_id % p.ct_tiles) * WT;
   const int k0 = grp * G;
+  const int ng = min(G, p.K - k0);  // offsets handled by this workgroup (uniform)
   const int64_t rbeg = (int64_t)blockIdx.y * p.rows_per_split;
   const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
 
   const bool vecx = ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
   const bool vecd = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.dy) & 15) == 0);
-  const int c4 = tid & 15, rr = tid >> 4;  // staging: float4 column c4, rows rr + 16 i
+  const int d_c4 = tid & 15, d_rr = tid >> 4;       // dy staging: float4 column, rows d_rr + 16 i
+  const int x_c4 = tid % XC4, x_rr = tid / XC4;     // x staging: float4 column, rows x_rr + XRP i
 
   const int wa = wave >> 1, wn = wave & 1, h = lane >> 5, col = lane & 31;
-  const int wm = PAIRSPLIT ? 0 : wa;
+  const int wm = NARROW ? 0 : wa;
 
   f32x16 acc[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = (f32x16){0};
 
+  float4 rx[XNI];
+  auto gather = [&](int g) {  // x rows of the compacted pairs of offset g -> registers
+    const int m = s_cnt[2 * g] + s_cnt[2 * g + 1];
+    const int mpad = (m + 15) & ~15;
+#pragma unroll
+    for (int i = 0; i < XNI; ++i) {
+      const int pr = x_rr + XRP * i;
+      int src = -1;
+      if (pr < mpad) src = s_src[g * LL + pr];
+      const int ci = ci0 + 4 * x_c4;
+      rx[i] = src >= 0 ? ld4_guard(p.x + (int64_t)src * p.ldx + ci, p.cin - ci, vecx) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < XNI; ++i) *reinterpret_cast<float4 *>(&sX[(x_rr + XRP * i) * XLD + 4 * x_c4]) = rx[i];
+  };
+
   for (int64_t r0 = rbeg; r0 < rend; r0 += WROWS) {
     __syncthreads();  // previous tile fully consumed
-    // ---- dy tile: rows r0.., columns co0..co0+63
+    // ---- this tile's neighbour entries (one row per thread of waves 0/1) and dy tile
+    int nb[G], rank[G];
+    if (tid < WROWS) {
+      const int64_t row = r0 + tid;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = rr + 16 * i;
-      const int64_t row = r0 + r;
-      const int co = co0 + 4 * c4;
-      const float4 v = row < rend ? ld4_guard(p.dy + row * p.ldy + co, p.cout - co, vecd) : make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4 *>(&sD[r * WLD + 4 * c4]) = v;
+      for (int g = 0; g < G; ++g) nb[g] = (row < rend && g < ng) ? p.nbr[row * p.K + k0 + g] : -1;
     }
 #pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = d_rr + 16 * i;
+      const int64_t row = r0 + r;
+      const int co = co0 + 4 * d_c4;
+      const float4 v = row < rend ? ld4_guard(p.dy + row * p.ldy + co, p.cout - co, vecd) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(&sD[r * WLD + 4 * d_c4]) = v;
+    }
+    // ---- rulebook of the tile: wave64 ballot + prefix rank per offset
+    if (tid < WROWS) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const unsigned long long mm = __ballot(nb[g] >= 0);
+        rank[g] = wave_rank(mm);
+        if (lane == 0) s_cnt[2 * g + wave] = __popcll(mm);
+      }
+    }
+    __syncthreads();
+    if (tid < WROWS) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (nb[g] >= 0) {
+          const int pos = (wave == 1 ? s_cnt[2 * g] : 0) + rank[g];
+          s_row[g * LL + pos] = tid * WLD;  // LDS offset of the dy row
+          s_src[g * LL + pos] = nb[g];
+        }
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {  // tail pairs: dy row 0 times a zero x row
+        const int m = s_cnt[2 * g] + s_cnt[2 * g + 1];
+        const int t = tid - WROWS;
+        if (t < ((m + 15) & ~15) - m) {
+          s_row[g * LL + m + t] = 0;
+          s_src[g * LL + m + t] = -1;
+        }
+      }
+    }
+    __syncthreads();
+    gather(0);
+    stash();
+    __syncthreads();
+#pragma unroll
     for (int g = 0; g < G; ++g) {
-      const int k = k0 + g;
-      if (k >= p.K) break;  // uniform
-      // ---- compact the rows of this tile that have a neighbour at offset k
-      if (g > 0) __syncthreads();  // MFMAs of the previous offset are done with sX / the lists
-      int v = -1, rank = 0;
-      if (tid < WROWS) {  // waves 0 and 1 (wave-uniform branch)
-        const int64_t row = r0 + tid;
-        v = row < rend ? p.nbr[row * p.K + k] : -1;
-        const unsigned long long mm = __ballot(v >= 0);
-        rank = wave_rank(mm);
-        if (lane == 0) s_cnt[wave] = __popcll(mm);
+      if (g < ng) {  // uniform
+      if (g + 1 < ng) gather(g + 1);  // in flight during the MFMAs below
+      const int m = s_cnt[2 * g] + s_cnt[2 * g + 1];
+      const int nsteps = ((m + 15) & ~15) >> 1;  // multiple of 8; lane half h takes pairs [h*nsteps, (h+1)*nsteps)
+      const int *lrow = s_row + g * LL + h * nsteps;
+      const float *xa = sX + (h * nsteps) * XLD + 32 * wm + col;
+      const float *db = sD + 32 * wn + col;
+      const int sbeg = NARROW ? wa * (nsteps >> 1) : 0;
+      const int send = NARROW ? sbeg + (nsteps >> 1) : nsteps;
+      for (int s = sbeg; s < send; s += 4) {  // 4 MFMAs per trip, all operands loaded up front
+        const int4 ro = *reinterpret_cast<const int4 *>(lrow + s);
+        const float a0 = xa[(s + 0) * XLD], a1 = xa[(s + 1) * XLD], a2 = xa[(s + 2) * XLD], a3 = xa[(s + 3) * XLD];
+        const float b0 = db[ro.x], b1 = db[ro.y], b2 = db[ro.z], b3 = db[ro.w];
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc[g], 0, 0, 0);
       }
-      __syncthreads();
-      const int cnt0 = s_cnt[0];
-      const int m = cnt0 + s_cnt[1];
-      const int mpad = (m + 3) & ~3;
-      if (v >= 0) {
-        const int pos = (wave == 1 ? cnt0 : 0) + rank;
-        s_row[pos] = tid;
-        s_src[pos] = v;
+      if (g + 1 < ng) {
+        __syncthreads();  // everyone done reading sX
+        stash();
+        __syncthreads();
       }
-      if (tid >= WROWS && tid - WROWS < mpad - m) {  // tail pairs: dy row 0 times a zero x row
-        s_row[m + tid - WROWS] = 0;
-        s_src[m + tid - WROWS] = -1;
-      }
-      __syncthreads();
-      // ---- gather the x rows of the compacted pairs (zero rows for the tail)
-      for (int pr = rr; pr < mpad; pr += 16) {
-        const int src = s_src[pr];
-        const int ci = ci0 + 4 * c4;
-        const float4 xv = src >= 0 ? ld4_guard(p.x + (int64_t)src * p.ldx + ci, p.cin - ci, vecx) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>(&sX[pr * WLD + 4 * c4]) = xv;
-      }
-      __syncthreads();
-      // ---- contraction over the compacted pairs, two pairs per MFMA
-      const int nsteps = mpad >> 1;
-      if (PAIRSPLIT) {
-        for (int s = wa; s < nsteps; s += 2) {
-          const int r = 2 * s + h;
-          const float a = sX[r * WLD + col];
-          const float b = sD[s_row[r] * WLD + 32 * wn + col];
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
-        }
-      } else {
-        for (int s = 0; s < nsteps; ++s) {
-          const int r = 2 * s + h;
-          const float a = sX[r * WLD + 32 * wm + col];
-          const float b = sD[s_row[r] * WLD + 32 * wn + col];
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
-        }
       }
     }
   }
 
-  // ---- epilogue: (pair-split: add the two halves through LDS) then store the partial slab
+  // ---- epilogue: (narrow: add the two pair halves through LDS) then store the partial slab
   float *dst = p.out + (int64_t)blockIdx.y * p.K * p.cin * p.cout;
   const int co = co0 + 32 * wn + col;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const int k = k0 + g;
-    if (k >= p.K) break;
-    if (PAIRSPLIT) {
-      __syncthreads();
-      if (wa == 1) {
+    if (g < ng) {  // uniform
+      const int k = k0 + g;
+      if (NARROW) {
+        __syncthreads();
+        if (wa == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sX[(wn * 16 + r) * 64 + lane] = acc[g][r];
+          for (int r = 0; r < 16; ++r) sD[(wn * 16 + r) * 64 + lane] = acc[g][r];
+        }
+        __syncthreads();
+        if (wa == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[g][r] += sD[(wn * 16 + r) * 64 + lane];
+        }
       }
-      __syncthreads();
-      if (wa == 0) {
+      if (!NARROW || wa == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] += sX[(wn * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) {
+          const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (ci < p.cin && co < p.cout) dst[((int64_t)k * p.cin + ci) * p.cout + co] = acc[g][r];
+        }
       }
-      if (wa == 1) continue;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (ci < p.cin && co < p.cout) dst[((int64_t)k * p.cin + ci) * p.cout + co] = acc[g][r];
     }
   }
 }
@@ -405,8 +456,9 @@ int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout) {
 }
 
 int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
-                          int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, float *y, int32_t ldy,
-                          int32_t cout, const float *bias, int32_t ksplit, float *workspace, void *stream) {
+                          int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, const int32_t *row_perm,
+                          int64_t n_virtual, float *y, int32_t ldy, int32_t cout, const float *bias, int32_t ksplit,
+                          float *workspace, void *stream) {
   MINK_REQUIRE(K >= 1 && K <= KMAX, "gather_gemm: kernel volume %d unsupported", K);
   MINK_REQUIRE(cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0, "gather_gemm: bad shape");
   MINK_REQUIRE(ksplit >= 1 && ksplit <= K, "gather_gemm: bad ksplit %d", ksplit);
@@ -414,12 +466,15 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
   if (n_out == 0) return MINK_OK;
   MINK_REQUIRE(x && w && nbr && y, "gather_gemm: NULL pointer");
   MINK_REQUIRE(ksplit == 1 || workspace, "gather_gemm: split-K needs a workspace");
+  if (!row_perm) n_virtual = n_out;
+  MINK_REQUIRE(n_virtual >= n_out, "gather_gemm: the row permutation must cover every output row");
   GemmParams p;
+  p.row_perm = row_perm, p.n_virtual = n_virtual;
   p.x = x, p.w = w, p.nbr = nbr, p.bias = bias, p.y = y, p.ws = workspace;
   p.n_out = n_out, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K, p.flip_k = flip_k;
   p.kper = (int)cdiv(K, ksplit);
   const int zs = (int)cdiv(K, p.kper);
-  const dim3 grid((unsigned)cdiv(n_out, BM), (unsigned)cdiv(cout, BN), (unsigned)zs);
+  const dim3 grid((unsigned)cdiv(n_virtual, BM), (unsigned)cdiv(cout, BN), (unsigned)zs);
   hipStream_t st = (hipStream_t)stream;
   if (w_transposed)
     gather_gemm_kernel<true><<<grid, 256, 0, st>>>(p);

@@ -197,6 +197,58 @@ __global__ void rulebook_counts_kernel(const int *__restrict__ chunk_offsets, in
   if (k == K) counts[K] = *total;
 }
 
+
+// ------------------------------------------------------------------- parity classes
+// Rows of a stride-ts map grouped by the parity of (c / ts) per axis (8 classes).  For the
+// dgrad of a stride-2 convolution every row of one class can only be reached through the same
+// 2^p kernel offsets, so class-pure 128-row tiles skip the other offsets entirely.
+// Same count -> scan -> fill scheme as the rulebook; each class segment starts at a multiple of
+// `pad` rows in the output permutation (pre-filled with -1).
+__device__ __forceinline__ int parity_class(int4 c, int ts) {
+  return ((c.y / ts) & 1) | (((c.z / ts) & 1) << 1) | (((c.w / ts) & 1) << 2);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void class_partition_kernel(const int *__restrict__ coords, int64_t n, int ts,
+                                                                 int64_t nchunk, int pad,
+                                                                 int *__restrict__ chunk_counts,
+                                                                 const int *__restrict__ chunk_offsets,
+                                                                 const int *__restrict__ total, int *__restrict__ perm) {
+  __shared__ int s_cnt[kBlock / 64][8];
+  __shared__ int s_shift[8];
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cls = i < n ? parity_class(reinterpret_cast<const int4 *>(coords)[i], ts) : -1;
+  if (FILL && threadIdx.x == 0) {  // padding inserted in front of each class segment
+    int shift = 0;
+    for (int c = 0; c < 8; ++c) {
+      s_shift[c] = shift;
+      const int beg = chunk_offsets[(int64_t)c * nchunk];
+      const int end = c < 7 ? chunk_offsets[(int64_t)(c + 1) * nchunk] : *total;
+      const int cnt = end - beg;
+      shift += (cnt + pad - 1) / pad * pad - cnt;
+    }
+  }
+  int my_rank = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (lane == 0) s_cnt[wave][c] = __popcll(m);
+    if (cls == c) my_rank = wave_rank(m);
+  }
+  __syncthreads();
+  if (FILL) {
+    if (cls >= 0) {
+      int pos = chunk_offsets[(int64_t)cls * nchunk + blockIdx.x] + s_shift[cls] + my_rank;
+      for (int w = 0; w < wave; ++w) pos += s_cnt[w][cls];
+      perm[pos] = (int)i;
+    }
+  } else if (threadIdx.x < 8) {
+    chunk_counts[(int64_t)threadIdx.x * nchunk + blockIdx.x] =
+        s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+  }
+}
+
 // --------------------------------------------------------------------- batch offsets
 __global__ __launch_bounds__(kBlock) void batch_offsets_kernel(const int *__restrict__ coords, int64_t n, int B,
                                                                int *__restrict__ batch_offsets, uint32_t *status) {
@@ -340,6 +392,36 @@ int mink_rulebook(const int32_t *nbr, int64_t n_out, int32_t K, int32_t *counts,
     rulebook_kernel<true><<<grid, kBlock, 0, st>>>(nbr, n_out, K, nchunk, nullptr, chunk_offsets, pairs_in, pairs_out);
     MINK_CHECK_LAUNCH();
   }
+  return MINK_OK;
+}
+
+
+int64_t mink_class_partition_rows(int64_t n, int32_t pad) { return n + 8 * (int64_t)(pad - 1); }
+
+int64_t mink_class_partition_workspace_bytes(int64_t n) {
+  const int64_t nchunk = cdiv(n > 0 ? n : 1, kBlock);
+  return 2 * align_up(4 * nchunk * 8, 256) + 256;
+}
+
+int mink_class_partition(const int32_t *coords, int64_t n, int32_t ts, int32_t pad, int32_t *perm, void *workspace,
+                         void *stream) {
+  MINK_REQUIRE(n >= 0 && ts >= 1 && pad >= 1 && perm, "class_partition: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  MINK_HIP(hipMemsetAsync(perm, 0xFF, sizeof(int32_t) * mink_class_partition_rows(n, pad), st));
+  if (n == 0) return MINK_OK;
+  MINK_REQUIRE(coords && workspace && ((uintptr_t)coords & 15) == 0 && ((uintptr_t)workspace & 255) == 0,
+               "class_partition: NULL/misaligned pointer");
+  const int64_t nchunk = cdiv(n, kBlock);
+  int *chunk_counts = (int *)workspace;
+  int *chunk_offsets = (int *)((char *)workspace + align_up(4 * nchunk * 8, 256));
+  int *total = chunk_offsets + nchunk * 8;
+  const dim3 grid((unsigned)nchunk);
+  class_partition_kernel<false><<<grid, kBlock, 0, st>>>(coords, n, ts, nchunk, pad, chunk_counts, nullptr, nullptr, nullptr);
+  MINK_CHECK_LAUNCH();
+  scan_kernel<<<1, 1024, 0, st>>>(chunk_counts, chunk_offsets, nchunk * 8, total);
+  MINK_CHECK_LAUNCH();
+  class_partition_kernel<true><<<grid, kBlock, 0, st>>>(coords, n, ts, nchunk, pad, nullptr, chunk_offsets, total, perm);
+  MINK_CHECK_LAUNCH();
   return MINK_OK;
 }
 

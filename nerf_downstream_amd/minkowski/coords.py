@@ -182,6 +182,17 @@ class CoordinateManager:
         c = counts.tolist()
         return {k: torch.stack([pin[c[k] : c[k + 1]], pout[c[k] : c[k + 1]]]) for k in range(K) if c[k + 1] > c[k]}
 
+    def class_perm(self, key, pad=128):
+        """Parity-class row permutation of the map `key` (for dgrad of stride-2 convolutions)."""
+        ck = ("perm", key.ts, pad)
+        if ck not in self.tables:
+            L, lev = lib(), self.levels[key.ts]
+            perm = torch.empty(int(L.mink_class_partition_rows(lev.n, pad)), dtype=torch.int32, device=self.device)
+            ws = torch.empty(int(L.mink_class_partition_workspace_bytes(lev.n)), dtype=torch.uint8, device=self.device)
+            check(L.mink_class_partition(lev.coords.data_ptr(), lev.n, key.ts, pad, perm.data_ptr(), ws.data_ptr(), _stream()))
+            self.tables[ck] = perm
+        return self.tables[ck]
+
     # ------------------------------------------------------------------ queries
     def size(self, key):
         return self.batch_size() if key.ts == ORIGIN_TS else self.levels[key.ts].n

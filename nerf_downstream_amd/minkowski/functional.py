@@ -58,7 +58,7 @@ class _timed:
 
 
 # ------------------------------------------------------------------------- convolution
-def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None):
+def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, row_perm=None):
     """y[o] = sum_k x[nbr[o,k]] @ W[k] (+bias) on the fp32 matrix cores."""
     L = lib()
     n_out, K = nbr.shape
@@ -71,6 +71,7 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None):
         check(
             L.mink_conv_gather_gemm(
                 x.data_ptr(), x.stride(0), cin, w.data_ptr(), int(w_transposed), int(flip_k), nbr.data_ptr(), n_out, K,
+                _ptr(row_perm), 0 if row_perm is None else row_perm.numel(),
                 y.data_ptr(), cout, cout, _ptr(bias), ksplit, _ptr(ws), _stream(),
             )
         )
@@ -104,7 +105,7 @@ class ConvolutionFunction(torch.autograd.Function):
     def forward(ctx, x, kernel, table_fn, same_map):
         x = _f32c(x)
         w = _f32c(kernel)
-        nbr, _ = table_fn(False)
+        nbr = table_fn(False)[0]
         ctx.save_for_backward(x, w)
         ctx.table_fn, ctx.same_map, ctx.nbr = table_fn, same_map, nbr
         return gather_gemm(x, w, nbr, w.shape[-1])
@@ -118,8 +119,8 @@ class ConvolutionFunction(torch.autograd.Function):
             if ctx.same_map:  # stride 1: nbr_t[i][k] == nbr[i][K-1-k]
                 gx = gather_gemm(gy, w, ctx.nbr, w.shape[-2], w_transposed=True, flip_k=True)
             else:
-                _, nbr_t = ctx.table_fn(True)
-                gx = gather_gemm(gy, w, nbr_t, w.shape[-2], w_transposed=True)
+                _, nbr_t, perm = ctx.table_fn(True)
+                gx = gather_gemm(gy, w, nbr_t, w.shape[-2], w_transposed=True, row_perm=perm)
         gw = conv_wgrad(x, gy, ctx.nbr, w.shape) if ctx.needs_input_grad[1] else None
         return gx, gw, None, None
 

@@ -61,7 +61,9 @@ class MinkowskiConvolution(nn.Module):
             ks, dil = self.kernel_size, self.dilation
 
             def table_fn(transposed, m=m, in_key=in_key, out_key=out_key):
-                return m.kernel_table(in_key, out_key, ks, dil, transposed=transposed)
+                nbr, nbr_t = m.kernel_table(in_key, out_key, ks, dil, transposed=transposed)
+                perm = m.class_perm(in_key) if transposed and self.stride == 2 else None
+                return nbr, nbr_t, perm
 
             out = Fn.ConvolutionFunction.apply(input.F, self.kernel, table_fn, self.stride == 1)
         if self.bias is not None:

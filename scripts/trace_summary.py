@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace CSV: per (kernel, grid) time per step."""
+import collections
+import csv
+import glob
+import sys
+
+d, steps = sys.argv[1], int(sys.argv[2])
+f = glob.glob(f"{d}/*/*kernel_trace.csv")[0]
+rows = list(csv.DictReader(open(f)))
+agg = collections.defaultdict(list)
+for r in rows:
+    name = r["Kernel_Name"].split("(")[0][:46]
+    g = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
+    agg[(name, g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+tot = sum(sum(v) for v in agg.values())
+print(f"total GPU kernel time per step: {tot / steps / 1e6:.3f} ms over {len(rows) / steps:.0f} launches/step")
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+for (name, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:top]:
+    print(f"{name:48s} grid={str(g):18s} calls={len(v):4d} avg={sum(v) / len(v) / 1e3:8.1f}us per-step={sum(v) / steps / 1e3:7.1f}us")
