@@ -85,6 +85,24 @@ int mink_coords_unique(const uint64_t *keys, int64_t n, uint64_t *table_keys, in
                        int64_t cap, int32_t *out_coords, int32_t *unique_index, int32_t *inverse,
                        int32_t *n_unique, void *workspace, void *stream);
 
+/* The whole coordinate pyramid of one batch in ONE call and with NO host synchronisation:
+ * level 0 = insert_and_map of the input rows (mode as in mink_coords_make_keys, floored to
+ * out_ts_host[0], normally 1); level l>0 = stride map of level l-1 floored to out_ts_host[l].
+ * Row counts of the levels stay on the device (each level's kernels read the previous count
+ * from `meta`), so every buffer is sized for the upper bound `n`:
+ *   table_keys[l][cap], table_vals[l][cap], out_coords[l][n][4], index_b[l][n] (inverse map /
+ *   in2out of level l), index_a[l][n] (first-occurrence rows; may be NULL for l > 0).
+ *   meta[nlev+2] (device int32): unique rows per level, then the status word, then the batch
+ *   count (batch index of the last row + 1).  The caller reads `meta` back once.
+ * Replaces the chain TensorField.sparse() -> stride() x5 of one forward pass
+ * (resnet.py:164-173, sparse_conv.py:403-405). */
+int64_t mink_levels_workspace_bytes(int64_t n);
+int mink_coords_build_levels(const void *coords, int mode, int64_t n, int32_t nlev,
+                             const int32_t *out_ts_host, uint64_t *const *table_keys,
+                             int32_t *const *table_vals, int64_t cap, int32_t *const *out_coords,
+                             int32_t *const *index_a, int32_t *const *index_b, int32_t *meta,
+                             void *workspace, void *stream);
+
 /* Kernel map as a neighbour table: for every output row o and offset k probe the INPUT
  * map at out_coords[o] + offsets[k].  offsets_host[K][3] are already scaled by
  * dilation * input tensor stride.  If nbr_t != NULL it must be pre-filled with -1

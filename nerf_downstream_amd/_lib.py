@@ -21,6 +21,8 @@ SIGNATURES = {
     "mink_unique_workspace_bytes": (_i64, [_i64]),
     "mink_coords_make_keys": (ctypes.c_int, [_p, ctypes.c_int, _i64, _i32, _p, _p, _p]),
     "mink_coords_unique": (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "mink_levels_workspace_bytes": (_i64, [_i64]),
+    "mink_coords_build_levels": (ctypes.c_int, [_p, ctypes.c_int, _i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "mink_kernel_map": (ctypes.c_int, [_p, _p, _i64, _p, _i64, _p, _i32, _p, _p, _p]),
     "mink_rulebook_workspace_bytes": (_i64, [_i64, _i32]),
     "mink_rulebook": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p]),

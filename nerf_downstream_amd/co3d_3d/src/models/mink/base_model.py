@@ -12,10 +12,34 @@ class InputInterface(ABC):
 
 
 class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
+    """`process_input(batch)` -> TensorField, as in the reference.  On the HIP backend it also
+    prepares, on a side HIP stream, every coordinate / kernel map the network asked for on the
+    previous batch (hash build, stride maps, neighbour tables are pure functions of the
+    coordinates), so calling it for batch i+1 while batch i is still in backward hides the map
+    construction and its host synchronisations behind compute."""
+
     def __init__(self, dimension=3, ME=None):
         _HIP_ME.MinkowskiNetwork.__init__(self, dimension)
         self._ME = ME or _HIP_ME
+        self._coord_plan = None
+        self._last_manager = None
+        self._side = None
+        self.prepare_ahead = True
 
     def process_input(self, batch):
-        """collated batch dict -> TensorField (float (b,x,y,z) coordinates + features)."""
-        return self._ME.TensorField(coordinates=batch["coordinates"], features=batch["features"])
+        ME = self._ME
+        coords, feats = batch["coordinates"], batch["features"]
+        if not (self.prepare_ahead and getattr(ME, "SUPPORTS_PREPARE_AHEAD", False) and coords.is_cuda):
+            return ME.TensorField(coordinates=coords, features=feats)
+        import torch
+
+        if self._last_manager is not None and self._last_manager.trace:
+            plan = ME.CoordinateManager.compile_plan(self._last_manager.trace)
+            if self._coord_plan is None or len(plan) > len(self._coord_plan):
+                self._coord_plan = plan
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=coords.device)
+        with torch.cuda.stream(self._side):
+            tf = ME.TensorField(coordinates=coords, features=feats, plan=self._coord_plan or [])
+        self._last_manager = tf.coordinate_manager
+        return tf

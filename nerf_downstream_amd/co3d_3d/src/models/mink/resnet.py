@@ -9,6 +9,7 @@ co3d_3d/src/models/mink/resnet.py:25-192).  Topology, tensor strides and paramet
 State-dict keys: conv1.kernel, bn1.bn.*, layer{i}.{j}.{conv1,conv2}.kernel,
 layer{i}.{j}.{norm1,norm2}.bn.*, layer{i}.0.downsample.{0.kernel,1.bn.*}, final.{kernel,bias}.
 Bottleneck variants (ResNet50/101) are out of scope (not in BASELINE configs)."""
+import torch
 import torch.nn as nn
 
 from .base_model import MinkowskiBaseModel
@@ -47,6 +48,11 @@ class ResNetBase(MinkowskiBaseModel):
         self.glob_avg = GlobalAvgPool(ME)
         self.final = conv(self.PLANES[3] * self.BLOCK.expansion, out_channel, kernel_size=1, bias=True, D=D, ME=ME)
         self.weight_initialization()
+        self._norms = []
+        if self._fused:  # HIP backend: one foreach launch bumps every BN step counter
+            self._norms = [m for m in self.modules() if isinstance(m, ME.MinkowskiBatchNorm)]
+            for m in self._norms:
+                m.counted_by_parent = True
 
     def weight_initialization(self):
         for m in self.modules():
@@ -68,6 +74,8 @@ class ResNetBase(MinkowskiBaseModel):
         return nn.Sequential(*seq)
 
     def forward(self, x):
+        if self.training and self._norms:
+            torch._foreach_add_([m.bn.num_batches_tracked for m in self._norms], 1)
         out = self.conv1(x.sparse())
         out = self.bn1(out, relu=True) if self._fused else self.relu(self.bn1(out))
         out = self.pool(out)

@@ -22,8 +22,10 @@ constexpr int kBlock = 256;  // 4 waves
 
 // ------------------------------------------------------------------------------ keys
 template <int MODE>  // 0 = float field rows, 1 = int32 rows
-__global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restrict__ coords, int64_t n, int out_ts,
+__global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restrict__ coords, int64_t n_host,
+                                                           const int *__restrict__ n_dev, int out_ts,
                                                            uint64_t *__restrict__ keys, uint32_t *status) {
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;  // device-resident row count (level chains)
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   int b, x, y, z;
@@ -44,9 +46,10 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restric
 }
 
 // ---------------------------------------------------------------------------- unique
-__global__ __launch_bounds__(kBlock) void insert_kernel(const uint64_t *__restrict__ keys, int64_t n,
-                                                        unsigned long long *tkeys, int *tvals, uint64_t mask,
-                                                        int *__restrict__ slot_of_row) {
+__global__ __launch_bounds__(kBlock) void insert_kernel(const uint64_t *__restrict__ keys, int64_t n_host,
+                                                        const int *__restrict__ n_dev, unsigned long long *tkeys,
+                                                        int *tvals, uint64_t mask, int *__restrict__ slot_of_row) {
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const uint64_t key = keys[i];
@@ -62,9 +65,10 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const uint64_t *__restri
 
 // flag first occurrences, count them per block
 __global__ __launch_bounds__(kBlock) void flag_kernel(const int *__restrict__ tvals, const int *__restrict__ slot_of_row,
-                                                      int64_t n, uint8_t *__restrict__ flags,
-                                                      int *__restrict__ block_counts) {
+                                                      int64_t n_host, const int *__restrict__ n_dev,
+                                                      uint8_t *__restrict__ flags, int *__restrict__ block_counts) {
   __shared__ int s_cnt[kBlock / 64];
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   bool first = false;
   if (i < n) {
@@ -110,10 +114,11 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int *__restrict__ in, 
 __global__ __launch_bounds__(kBlock) void assign_kernel(const uint64_t *__restrict__ keys,
                                                         const uint8_t *__restrict__ flags,
                                                         const int *__restrict__ slot_of_row,
-                                                        const int *__restrict__ block_offsets, int64_t n,
-                                                        int *tvals, int *__restrict__ out_coords,
-                                                        int *__restrict__ unique_index) {
+                                                        const int *__restrict__ block_offsets, int64_t n_host,
+                                                        const int *__restrict__ n_dev, int *tvals,
+                                                        int *__restrict__ out_coords, int *__restrict__ unique_index) {
   __shared__ int s_cnt[kBlock / 64];
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool first = i < n && flags[i];
   const unsigned long long m = __ballot(first);
@@ -123,17 +128,23 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint64_t *__restri
   if (first) {
     int uid = block_offsets[blockIdx.x] + wave_rank(m);
     for (int w = 0; w < wave; ++w) uid += s_cnt[w];
-    unique_index[uid] = (int)i;
+    if (unique_index) unique_index[uid] = (int)i;
     reinterpret_cast<int4 *>(out_coords)[uid] = unpack_key(keys[i]);
     tvals[slot_of_row[i]] = uid;
   }
 }
 
 __global__ __launch_bounds__(kBlock) void inverse_kernel(const int *__restrict__ tvals,
-                                                         const int *__restrict__ slot_of_row, int64_t n,
-                                                         int *__restrict__ inverse) {
+                                                         const int *__restrict__ slot_of_row, int64_t n_host,
+                                                         const int *__restrict__ n_dev, int *__restrict__ inverse) {
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) inverse[i] = tvals[slot_of_row[i]];
+}
+
+__global__ void last_batch_kernel(const int *__restrict__ coords0, const int *__restrict__ n0, int *out) {
+  const int n = *n0;
+  *out = n > 0 ? coords0[4 * (n - 1)] + 1 : 0;  // batch column is non-decreasing (checked by batch_offsets)
 }
 
 // ------------------------------------------------------------------------ kernel map
@@ -282,6 +293,35 @@ int64_t mink_table_capacity(int64_t n) {
 
 static int64_t unique_nblocks(int64_t n) { return cdiv(n > 0 ? n : 1, kBlock); }
 
+// enqueue the five kernels of insert_and_map; n_dev (optional) holds the row count on the device
+static int unique_launch(const uint64_t *keys, int64_t n, const int *n_dev, uint64_t *table_keys, int32_t *table_vals,
+                         int64_t cap, int32_t *out_coords, int32_t *unique_index, int32_t *inverse, int32_t *n_unique,
+                         void *workspace, hipStream_t st) {
+  const int64_t nb = unique_nblocks(n);
+  char *ws = (char *)workspace;
+  int *slot_of_row = (int *)ws;
+  ws += align_up(4 * n, 256);
+  uint8_t *flags = (uint8_t *)ws;
+  ws += align_up(n, 256);
+  int *block_counts = (int *)ws;
+  ws += align_up(4 * nb, 256);
+  int *block_offsets = (int *)ws;
+  const dim3 grid((unsigned)nb);
+  insert_kernel<<<grid, kBlock, 0, st>>>(keys, n, n_dev, (unsigned long long *)table_keys, table_vals,
+                                         (uint64_t)cap - 1, slot_of_row);
+  MINK_CHECK_LAUNCH();
+  flag_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, n_dev, flags, block_counts);
+  MINK_CHECK_LAUNCH();
+  scan_kernel<<<1, 1024, 0, st>>>(block_counts, block_offsets, nb, n_unique);
+  MINK_CHECK_LAUNCH();
+  assign_kernel<<<grid, kBlock, 0, st>>>(keys, flags, slot_of_row, block_offsets, n, n_dev, table_vals, out_coords,
+                                         unique_index);
+  MINK_CHECK_LAUNCH();
+  inverse_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, n_dev, inverse);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
 int64_t mink_unique_workspace_bytes(int64_t n) {
   const int64_t nb = unique_nblocks(n);
   return align_up(4 * n, 256) + align_up(n, 256) + 2 * align_up(4 * nb, 256) + 256;
@@ -297,9 +337,9 @@ int mink_coords_make_keys(const void *coords, int mode, int64_t n, int32_t out_t
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)cdiv(n, kBlock));
   if (mode == 0)
-    make_keys_kernel<0><<<grid, kBlock, 0, st>>>(coords, n, out_ts, keys, status);
+    make_keys_kernel<0><<<grid, kBlock, 0, st>>>(coords, n, nullptr, out_ts, keys, status);
   else
-    make_keys_kernel<1><<<grid, kBlock, 0, st>>>(coords, n, out_ts, keys, status);
+    make_keys_kernel<1><<<grid, kBlock, 0, st>>>(coords, n, nullptr, out_ts, keys, status);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }
@@ -320,27 +360,49 @@ int mink_coords_unique(const uint64_t *keys, int64_t n, uint64_t *table_keys, in
   }
   MINK_REQUIRE(keys && out_coords && unique_index && inverse && workspace, "unique: NULL pointer");
   MINK_REQUIRE(((uintptr_t)out_coords & 15) == 0 && ((uintptr_t)workspace & 255) == 0, "unique: misaligned buffer");
-  const int64_t nb = unique_nblocks(n);
-  char *ws = (char *)workspace;
-  int *slot_of_row = (int *)ws;
-  ws += align_up(4 * n, 256);
-  uint8_t *flags = (uint8_t *)ws;
-  ws += align_up(n, 256);
-  int *block_counts = (int *)ws;
-  ws += align_up(4 * nb, 256);
-  int *block_offsets = (int *)ws;
-  const dim3 grid((unsigned)nb);
-  insert_kernel<<<grid, kBlock, 0, st>>>(keys, n, (unsigned long long *)table_keys, table_vals, (uint64_t)cap - 1,
-                                         slot_of_row);
-  MINK_CHECK_LAUNCH();
-  flag_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, flags, block_counts);
-  MINK_CHECK_LAUNCH();
-  scan_kernel<<<1, 1024, 0, st>>>(block_counts, block_offsets, nb, n_unique);
-  MINK_CHECK_LAUNCH();
-  assign_kernel<<<grid, kBlock, 0, st>>>(keys, flags, slot_of_row, block_offsets, n, table_vals, out_coords,
-                                         unique_index);
-  MINK_CHECK_LAUNCH();
-  inverse_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, inverse);
+  int rc = unique_launch(keys, n, nullptr, table_keys, table_vals, cap, out_coords, unique_index, inverse, n_unique,
+                         workspace, st);
+  return rc;
+}
+
+
+/* ---- whole coordinate pyramid in one call ------------------------------------------------- */
+int64_t mink_levels_workspace_bytes(int64_t n) { return align_up(8 * (n > 0 ? n : 1), 256) + mink_unique_workspace_bytes(n); }
+
+int mink_coords_build_levels(const void *coords, int mode, int64_t n, int32_t nlev, const int32_t *out_ts_host,
+                             uint64_t *const *table_keys, int32_t *const *table_vals, int64_t cap,
+                             int32_t *const *out_coords, int32_t *const *index_a, int32_t *const *index_b,
+                             int32_t *meta, void *workspace, void *stream) {
+  MINK_REQUIRE(n >= 1 && n < (1ll << 31) - 1 && nlev >= 1 && nlev <= 16, "build_levels: bad sizes");
+  MINK_REQUIRE(coords && out_ts_host && table_keys && table_vals && out_coords && index_a && index_b && meta && workspace,
+               "build_levels: NULL pointer");
+  MINK_REQUIRE(cap >= mink_table_capacity(n) && (cap & (cap - 1)) == 0, "build_levels: table capacity too small");
+  MINK_REQUIRE(((uintptr_t)coords & 15) == 0 && ((uintptr_t)workspace & 255) == 0, "build_levels: misaligned buffer");
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t *keys = (uint64_t *)workspace;
+  void *uws = (char *)workspace + align_up(8 * n, 256);
+  uint32_t *status = (uint32_t *)(meta + nlev);
+  MINK_HIP(hipMemsetAsync(meta, 0, sizeof(int32_t) * (nlev + 2), st));
+  const dim3 grid((unsigned)cdiv(n, kBlock));
+  for (int l = 0; l < nlev; ++l) {
+    MINK_REQUIRE(table_keys[l] && table_vals[l] && out_coords[l] && index_b[l] && (l > 0 || index_a[0]),
+                 "build_levels: NULL level buffer");
+    const void *src = l == 0 ? coords : (const void *)out_coords[l - 1];
+    const int *n_dev = l == 0 ? nullptr : meta + (l - 1);
+    if (l == 0 && mode == 0)
+      make_keys_kernel<0><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status);
+    else
+      make_keys_kernel<1><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status);
+    MINK_CHECK_LAUNCH();
+    MINK_HIP(hipMemsetAsync(table_keys[l], 0xFF, cap * sizeof(uint64_t), st));
+    MINK_HIP(hipMemsetAsync(table_vals[l], 0x7F, cap * sizeof(int32_t), st));
+    // index_a: first-occurrence rows (optional, kept for level 0), index_b: inverse / in2out
+    int rc = unique_launch(keys, n, n_dev, table_keys[l], table_vals[l], cap, out_coords[l],
+                           index_a[l], index_b[l], meta + l, uws, st);
+    if (rc) return rc;
+  }
+  // meta[nlev] = status word, meta[nlev+1] = batch index of the last input row + 1
+  last_batch_kernel<<<1, 1, 0, st>>>((const int *)out_coords[0], meta, meta + nlev + 1);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

@@ -16,3 +16,4 @@ from .tensor import SparseTensor, TensorField  # noqa: F401
 
 BACKEND = "hip-gfx950"
 SUPPORTS_FUSED_NORM = True  # MinkowskiBatchNorm.forward(x, relu=, residual=)
+SUPPORTS_PREPARE_AHEAD = True  # TensorField.prepare_ahead(plan) + CoordinateManager.trace

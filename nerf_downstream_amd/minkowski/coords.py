@@ -79,6 +79,61 @@ class CoordinateManager:
         self.field_unique_index = None
         self._boff = {}
         self._batch_size = None
+        self._batch_checked = False
+        self.trace = []  # every map request, in order: lets the next batch be prepared ahead of use
+
+    # ------------------------------------------------------------------ plan record / replay
+    @staticmethod
+    def compile_plan(trace):
+        """De-duplicate a recorded request trace (keeping first-use order); a kernel table that is
+        ever requested transposed is built transposed from the start."""
+        want_t = {op[1:5] for op in trace if op[0] == "ktable" and op[5]}
+        plan, seen = [], set()
+        for op in trace:
+            if op[0] == "ktable":
+                op = op[:5] + (op[1:5] in want_t,)
+            if op not in seen:
+                seen.add(op)
+                plan.append(op)
+        return plan
+
+    @staticmethod
+    def plan_stride_chain(plan):
+        """Strides of `plan` that form the chain ts 1 -> s0 -> s0*s1 ... (built with the field)."""
+        chain, ts = [], 1
+        for op in plan or ():
+            if op[0] == "stride" and op[1] == ts:
+                chain.append(op[2])
+                ts *= op[2]
+        return tuple(chain)
+
+    def replay(self, plan):
+        """Build every map of `plan` now (on the current stream) so the forward/backward pass that
+        follows finds them cached."""
+        for op in plan:
+            if op[0] == "stride":
+                self.stride(CoordinateMapKey(op[1]), op[2])
+            elif op[0] == "ktable":
+                self.kernel_table(CoordinateMapKey(op[1]), CoordinateMapKey(op[2]), op[3], op[4], transposed=op[5])
+            elif op[0] == "perm":
+                self.class_perm(CoordinateMapKey(op[1]), op[2])
+            elif op[0] == "boff":
+                self.batch_offsets(CoordinateMapKey(op[1]))
+
+    def tensors(self):
+        out = [self.field_inverse, self.field_unique_index]
+        for lev in self.levels.values():
+            out += [lev.coords, lev.tkeys, lev.tvals]
+        out += list(self.in2out.values()) + list(self._boff.values())
+        for v in self.tables.values():
+            out += list(v) if isinstance(v, tuple) else [v]
+        return [t for t in out if t is not None]
+
+    def hand_over(self, stream):
+        """Maps built on a side stream are about to be used on `stream`: tell the caching
+        allocator so their memory is not recycled while kernels of `stream` still read it."""
+        for t in self.tensors():
+            t.record_stream(stream)
 
     # ------------------------------------------------------------------ internals
     def _unique(self, src, mode, n, out_ts):
@@ -112,23 +167,66 @@ class CoordinateManager:
         return lev, uidx[:nu], inv[:n]
 
     # ------------------------------------------------------------------ construction
-    def insert_field(self, fcoords):
-        """A1+A2: floor-quantise the float field, insert; returns the tensor-stride-1 key."""
+    def insert_field(self, fcoords, ahead_strides=()):
+        """A1+A2: floor-quantise the float field and insert it (tensor stride 1); optionally also
+        build the chain of stride maps `ahead_strides` (e.g. (2,2,2,2,2) -> ts 2..32) in the same
+        native call.  Row counts stay on the device until ONE read-back at the end."""
         assert fcoords.is_cuda and fcoords.dim() == 2 and fcoords.shape[1] == 4
-        self.device = fcoords.device
+        import ctypes
+
+        self.device = dev = fcoords.device
         fc = fcoords.contiguous()
-        if fc.dtype in (torch.int32,):
-            lev, ui, inv = self._unique(fc, 1, fc.shape[0], 1)
-        else:
-            lev, ui, inv = self._unique(fc.float(), 0, fc.shape[0], 1)
-        self.levels[1] = lev
-        self.field_unique_index, self.field_inverse = ui, inv
+        mode = 1 if fc.dtype == torch.int32 else 0
+        if mode == 0:
+            fc = fc.float()
+        n = fc.shape[0]
+        ts_list = [1]
+        for s in ahead_strides:
+            ts_list.append(ts_list[-1] * _as_int(s))
+        if n == 0:
+            raise ValueError("empty coordinate field")
+        L, nlev = lib(), len(ts_list)
+        cap = int(L.mink_table_capacity(n))
+        tkeys = torch.empty(nlev, cap, dtype=torch.int64, device=dev)
+        tvals = torch.empty(nlev, cap, dtype=torch.int32, device=dev)
+        coords = torch.empty(nlev, n, 4, dtype=torch.int32, device=dev)
+        index_b = torch.empty(nlev, n, dtype=torch.int32, device=dev)
+        index_a = torch.empty(n, dtype=torch.int32, device=dev)
+        meta = torch.empty(nlev + 2, dtype=torch.int32, device=dev)
+        ws = torch.empty(int(L.mink_levels_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        arr = lambda ptrs: (ctypes.c_void_p * nlev)(*ptrs)  # noqa: E731
+        check(
+            L.mink_coords_build_levels(
+                fc.data_ptr(), mode, n, nlev, (ctypes.c_int32 * nlev)(*ts_list),
+                arr([tkeys[l].data_ptr() for l in range(nlev)]), arr([tvals[l].data_ptr() for l in range(nlev)]), cap,
+                arr([coords[l].data_ptr() for l in range(nlev)]), arr([index_a.data_ptr()] + [None] * (nlev - 1)),
+                arr([index_b[l].data_ptr() for l in range(nlev)]), meta.data_ptr(), ws.data_ptr(), _stream(),
+            )
+        )
+        m = meta.tolist()  # the one host synchronisation of the whole pyramid
+        if m[nlev] & _STATUS_RANGE:
+            raise ValueError(
+                "coordinate outside the supported range (batch < 65535, |x|,|y|,|z| < 32768 after quantisation)"
+            )
+        self._batch_size = m[nlev + 1]
+        n_prev = n
+        for l, ts in enumerate(ts_list):
+            lev = _Level()
+            lev.n, lev.cap, lev.tkeys, lev.tvals = m[l], cap, tkeys[l], tvals[l]
+            lev.coords = coords[l, : m[l]]
+            self.levels[ts] = lev
+            if l == 0:
+                self.field_unique_index, self.field_inverse = index_a[: m[0]], index_b[0, :n]
+            else:
+                self.in2out[(ts_list[l - 1], ts)] = index_b[l, :n_prev]
+            n_prev = m[l]
         return CoordinateMapKey(1)
 
     def stride(self, key, stride):
         s = _as_int(stride)
         if s == 1:
             return key
+        self.trace.append(("stride", key.ts, s))
         ts_out = key.ts * s
         if ts_out not in self.levels:
             src = self.levels[key.ts]
@@ -147,6 +245,7 @@ class CoordinateManager:
         """Neighbour table nbr[n_out,K] (and nbr_t[n_in,K] when `transposed`)."""
         ks, dil = _as_int(kernel_size), _as_int(dilation)
         kk = (in_key.ts, out_key.ts, ks, dil)
+        self.trace.append(("ktable",) + kk + (bool(transposed),))
         ent = self.tables.get(kk)
         if ent is None or (transposed and ent[1] is None):
             lin, lout = self.levels[in_key.ts], self.levels[out_key.ts]
@@ -185,6 +284,7 @@ class CoordinateManager:
     def class_perm(self, key, pad=128):
         """Parity-class row permutation of the map `key` (for dgrad of stride-2 convolutions)."""
         ck = ("perm", key.ts, pad)
+        self.trace.append(ck)
         if ck not in self.tables:
             L, lev = lib(), self.levels[key.ts]
             perm = torch.empty(int(L.mink_class_partition_rows(lev.n, pad)), dtype=torch.int32, device=self.device)
@@ -198,16 +298,16 @@ class CoordinateManager:
         return self.batch_size() if key.ts == ORIGIN_TS else self.levels[key.ts].n
 
     def batch_size(self):
-        if self._batch_size is None:
-            c = self.levels[1].coords
-            self._batch_size = int(c[-1, 0].item()) + 1 if c.shape[0] else 0
-            self.batch_offsets(CoordinateMapKey(1))  # also validates batch ordering
+        if not self._batch_checked:
+            self._batch_checked = True
+            self.batch_offsets(CoordinateMapKey(1))  # validates that the batch column is sorted
         return self._batch_size
 
     def batch_offsets(self, key):
         """int32[B+1] row ranges per batch index (rows of one batch are contiguous)."""
+        self.trace.append(("boff", key.ts))
         if key.ts not in self._boff:
-            B = self._batch_size if self._batch_size is not None else self.batch_size()
+            B = self._batch_size
             lev = self.levels[key.ts]
             boff = torch.empty(B + 1, dtype=torch.int32, device=self.device)
             status = torch.zeros(1, dtype=torch.int32, device=self.device)

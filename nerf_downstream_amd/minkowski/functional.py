@@ -28,12 +28,16 @@ def _bytes(nbytes, device):
 
 # ---------------------------------------------------------------------- kernel timing
 # bench.py measures the dominant kernel live with HIP events recorded on the launch stream.
+# HIP event records are not free on this stack (each one is a barrier packet that drains the
+# queue), so the timed region instruments ONE kernel tag only; the warm-up instruments all.
 _TIMING = None  # None = off; else {tag: {"events": [(start, end)], "meta": {...}}}
+_TIMING_ONLY = None  # restrict event recording to this tag
 
 
-def enable_kernel_timing(on=True):
-    global _TIMING
+def enable_kernel_timing(on=True, only=None):
+    global _TIMING, _TIMING_ONLY
     _TIMING = {} if on else None
+    _TIMING_ONLY = only
 
 
 def kernel_timings():
@@ -45,12 +49,13 @@ class _timed:
         self.tag, self.meta = tag, meta
 
     def __enter__(self):
-        if _TIMING is not None:
+        self.on = _TIMING is not None and (_TIMING_ONLY is None or _TIMING_ONLY == self.tag)
+        if self.on:
             self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.s.record()
 
     def __exit__(self, *exc):
-        if _TIMING is not None:
+        if self.on:
             self.e.record()
             ent = _TIMING.setdefault(self.tag, {"events": [], "meta": self.meta})
             ent["events"].append((self.s, self.e))

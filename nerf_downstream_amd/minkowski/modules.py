@@ -86,11 +86,12 @@ class MinkowskiBatchNorm(nn.Module):
         super().__init__()
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
+        self.counted_by_parent = False  # a parent network may bump all BN step counters in one launch
 
     def forward(self, input, relu=False, residual=None):
         bn = self.bn
         training = bn.training or not bn.track_running_stats
-        if training and bn.track_running_stats:
+        if training and bn.track_running_stats and not self.counted_by_parent:
             bn.num_batches_tracked += 1
         if residual is not None:
             input._check(residual)

@@ -80,13 +80,19 @@ class TensorField:
     Owns a fresh coordinate manager; `.sparse()` floors the coordinates, inserts them into the
     hash map and averages the features of rows that collapse onto one voxel (A1, A2)."""
 
-    def __init__(self, features=None, coordinates=None, **kwargs):
+    def __init__(self, features=None, coordinates=None, plan=None, **kwargs):
+        """`plan` (extension): a compiled CoordinateManager request plan; all its maps are built
+        right here, on the current (side) stream, and `.sparse()` makes the consumer stream wait."""
         assert features is not None and coordinates is not None
         if not coordinates.is_cuda:
             raise RuntimeError("nerf_downstream_amd.minkowski runs on the GPU only: move the batch to cuda first")
         self._F, self._C = features, coordinates
-        self._manager = CoordinateManager(D=coordinates.shape[1] - 1, device=coordinates.device)
-        self.coordinate_field_map_key = self._manager.insert_field(coordinates)
+        m = self._manager = CoordinateManager(D=coordinates.shape[1] - 1, device=coordinates.device)
+        self.coordinate_field_map_key = m.insert_field(coordinates, CoordinateManager.plan_stride_chain(plan))
+        self._ready = None
+        if plan is not None:
+            m.replay(plan)
+            self._ready = torch.cuda.current_stream().record_event()
 
     @property
     def F(self):
@@ -102,6 +108,11 @@ class TensorField:
 
     def sparse(self):
         m = self._manager
+        if self._ready is not None:  # maps were built ahead of time on another stream
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._ready)
+            m.hand_over(cur)
+            self._ready = None
         n_unique = m.levels[1].n
         F = self._F
         if n_unique == F.shape[0]:

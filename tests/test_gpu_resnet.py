@@ -47,3 +47,34 @@ def test_resnet_matches_oracle(oracle_maps, name, cin, grid, fused):
     hb, rb = dict(hip.named_buffers()), dict(ref.named_buffers())
     for k in hb:
         assert torch.allclose(hb[k].float().cpu(), rb[k].float(), atol=1e-3, rtol=1e-3), k
+
+
+def test_prepare_ahead_is_bitwise_identical(oracle_maps):
+    """Maps built ahead on the side stream (plan replay) == maps built lazily in forward."""
+    hip, _ = _models("ResNet14", 28, 51)
+    coords, feats = batch_scenes([21, 22], grid=32, cin=28)
+    batch = {"coordinates": coords.cuda(), "features": feats.cuda()}
+    hip.prepare_ahead = False
+    a = hip(hip.process_input(batch))
+    a.sum().backward()
+    ga = hip.layer1[0].conv1.kernel.grad.clone()
+    hip.zero_grad()
+    hip.prepare_ahead = True
+    tf0 = hip.process_input(batch)  # records the plan (first use builds lazily)
+    hip(tf0).sum().backward()
+    hip.zero_grad()
+    tf1 = hip.process_input(batch)  # now replays the compiled plan on the side stream
+    assert hip._coord_plan and any(op[0] == "perm" for op in hip._coord_plan)
+    n_tables = len(tf1.coordinate_manager.tables)
+    b = hip(tf1)
+    assert len(tf1.coordinate_manager.tables) == n_tables  # nothing left to build in forward
+    b.sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(hip.layer1[0].conv1.kernel.grad, ga)
+    # BN running stats differ between calls (momentum), logits of the same weights must not
+    hip.eval()
+    with torch.no_grad():
+        e1 = hip(hip.process_input(batch))
+        hip.prepare_ahead = False
+        e2 = hip(hip.process_input(batch))
+    assert torch.equal(e1, e2)
