@@ -159,6 +159,12 @@ int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *bat
  *   ksplit             : >1 splits the K offsets over `ksplit` workgroups per tile and
  *                        reduces through `workspace` (ksplit*n_out*cout floats)
  */
+/* Kernel selection knob (tests / A-B benchmarks): 1 = LDS-free direct gather-GEMM where it
+ * applies (default), 0 = always the LDS-staged kernel.  Returns the previous setting. */
+int mink_conv_set_direct(int on);
+/* Tuning knob: start-up stagger (units of 1024 clocks per phase) between workgroups that share a
+ * CU in the gather-GEMM; 0 = off.  Returns the previous value. */
+int mink_conv_set_stagger(int units);
 /* Split-K factor the library recommends for a layer (1 for large row counts). */
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout);
 int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,

@@ -28,7 +28,7 @@ struct GemmParams {
   const int *row_perm;  // optional: tile row v computes output row row_perm[v] (-1 = padding)
   int64_t n_out;        // rows of y / of the neighbour table
   int64_t n_virtual;    // rows iterated (== n_out without a permutation)
-  int ldx, cin, ldy, cout, K, flip_k, kper;
+  int ldx, cin, ldy, cout, K, flip_k, kper, stagger;
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float *p, int valid, bool vec) {
@@ -42,8 +42,17 @@ __device__ __forceinline__ float4 ld4_guard(const float *p, int valid, bool vec)
   return v;
 }
 
+// Branch-free 16-byte load: `ok == false` reads element 0 of `base` (always mapped) and returns
+// zeros.  Keeps every load of a staging pass independent so they are all in flight together
+// (the guarded form above compiles to serialized load/wait branches).
+__device__ __forceinline__ float4 ld4_sel(const float *base, int64_t off, bool ok) {
+  const float4 v = *reinterpret_cast<const float4 *>(base + (ok ? off : 0));
+  return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // W_T = false: w[K][cin][cout];  W_T = true: w[K][cout][cin] (dgrad reads the forward kernel)
-template <bool W_T>
+// VEC: every operand is 16-byte aligned with channel counts that are multiples of 4.
+template <bool W_T, bool VEC>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float sA[BM * LDA];
   __shared__ __attribute__((aligned(16))) float sB[BK * BN];
@@ -58,6 +67,12 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
   const int kbeg = blockIdx.z * p.kper;
   const int kend = min(K, kbeg + p.kper);
 
+  // De-phase the workgroups that share a CU: identical programs started together run their
+  // MFMA and their load/barrier phases in lockstep and leave the matrix pipe idle in between.
+  if (p.stagger & 63) {
+    const int ph = (blockIdx.x / 256) % 3;
+    for (int i = 0; i < ph * (p.stagger & 63); ++i) __builtin_amdgcn_s_sleep(16);  // 16 * 64 clocks
+  }
   // ---- stage this tile's slice of the neighbour table; find offsets with any neighbour
   if (tid == 0) s_kmask = 0u;
   if (tid < BM) {
@@ -87,32 +102,53 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
 
   f32x16 acc0 = {0}, acc1 = {0};
 
-  const bool vecx = ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
-  const bool vecw = W_T ? (((p.cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0))
-                        : (((p.cout & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0));
-
   // per-thread staging coordinates
   const int a_cc = tid & 7, a_r = tid >> 3;       // A: rows a_r + 32 i, float4 column a_cc
   const int b_n4 = tid & 15, b_kk = tid >> 4;     // B (!W_T): rows b_kk + 16 i, float4 column b_n4
   const int bt_n = tid & 63, bt_k4 = tid >> 6;    // B (W_T) : column bt_n, float4 of k at 4*(bt_k4 + 4 i)
 
-  float4 ra[4], rb[2];
+  float4 ra[4] = {}, rb[2] = {};
 
   auto load_chunk = [&](int k, int c0) {
     const int kw = p.flip_k ? (K - 1 - k) : k;
+    if (p.stagger & 64) return;  // ablation: no global loads
+    if (VEC) {
+      const int c = c0 + 4 * a_cc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int src = s_nbr[(a_r + 32 * i) * K + k];
+        ra[i] = ld4_sel(p.x, (int64_t)src * p.ldx + c, src >= 0 && c < p.cin);
+      }
+      if (!W_T) {
+        const int n = n0 + 4 * b_n4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int kk = c0 + b_kk + 16 * i;
+          rb[i] = ld4_sel(p.w, ((int64_t)kw * p.cin + kk) * p.cout + n, kk < p.cin && n < p.cout);
+        }
+      } else {
+        const int n = n0 + bt_n;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int kk = c0 + 4 * (bt_k4 + 4 * i);
+          rb[i] = ld4_sel(p.w, ((int64_t)kw * p.cout + n) * p.cin + kk, n < p.cout && kk < p.cin);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = a_r + 32 * i;
       const int src = s_nbr[r * K + k];
       const int c = c0 + 4 * a_cc;
-      ra[i] = src >= 0 ? ld4_guard(p.x + (int64_t)src * p.ldx + c, p.cin - c, vecx) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[i] = src >= 0 ? ld4_guard(p.x + (int64_t)src * p.ldx + c, p.cin - c, false) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (!W_T) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int kk = c0 + b_kk + 16 * i;
         const int n = n0 + 4 * b_n4;
-        rb[i] = kk < p.cin ? ld4_guard(p.w + ((int64_t)kw * p.cin + kk) * p.cout + n, p.cout - n, vecw)
+        rb[i] = kk < p.cin ? ld4_guard(p.w + ((int64_t)kw * p.cin + kk) * p.cout + n, p.cout - n, false)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
@@ -120,7 +156,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
       for (int i = 0; i < 2; ++i) {
         const int kk = c0 + 4 * (bt_k4 + 4 * i);
         const int n = n0 + bt_n;
-        rb[i] = n < p.cout ? ld4_guard(p.w + ((int64_t)kw * p.cout + n) * p.cin + kk, p.cin - kk, vecw)
+        rb[i] = n < p.cout ? ld4_guard(p.w + ((int64_t)kw * p.cout + n) * p.cin + kk, p.cin - kk, false)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -160,17 +196,29 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
       nk = rest ? (k + 1 + __builtin_ctz(rest)) : -1;
     }
     if (nk >= 0) load_chunk(nk, nc0);
+    {
+      float4 av[4];
+      float b0[16], b1[16];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float4 a = *reinterpret_cast<const float4 *>(&sA[arow * LDA + 8 * t + 4 * h]);
-      const float av[4] = {a.x, a.y, a.z, a.w};
+      for (int t = 0; t < 4; ++t) av[t] = *reinterpret_cast<const float4 *>(&sA[arow * LDA + 8 * t + 4 * h]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kk = 8 * t + 4 * h + j;
-        const float b0 = sB[kk * BN + col];
-        const float b1 = sB[kk * BN + 32 + col];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b1, acc1, 0, 0, 0);
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kk = 8 * t + 4 * h + j;
+          b0[4 * t + j] = sB[kk * BN + col];
+          b1[4 * t + j] = sB[kk * BN + 32 + col];
+        }
+      __builtin_amdgcn_sched_barrier(0);  // keep all LDS reads ahead of the MFMA chain
+      if (!(p.stagger & 128))  // ablation: no MFMA
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float a4[4] = {av[t].x, av[t].y, av[t].z, av[t].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b0[4 * t + j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b1[4 * t + j], acc1, 0, 0, 0);
+        }
       }
     }
     k = nk;
@@ -190,6 +238,117 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
     if (row >= 0) {
       if (c_a < p.cout) dst[row * ldd + c_a] = acc0[r] + bias_a;
       if (c_b < p.cout) dst[row * ldd + c_b] = acc1[r] + bias_b;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------- direct
+// Barrier-free variant of the gather-GEMM for w[K][cin][cout] weights: every wave owns 32
+// output rows x 64 columns and feeds the MFMA straight from global memory / L1 -- the A
+// fragment of v_mfma_f32_32x32x2_f32 is (row = lane&31, k = lane>>5), so lane (r,h) loads the
+// h-th half of ITS neighbour row's channel chunk with 8/16-byte loads (a row gather needs no
+// LDS transpose), and the B fragment (k = lane>>5, col = lane&31) is a coalesced 128-byte read
+// of one weight row served by L1/L2.  No LDS, no __syncthreads: waves of a SIMD overlap each
+// other's load latency, and the next chunk's A fragment is prefetched under the MFMAs.
+// KH = input channels per lane half and chunk (cin is processed in chunks of 2*KH).
+template <int KH>
+__global__ __launch_bounds__(256) void conv_direct_kernel(GemmParams p) {
+  constexpr int VW = (KH % 4 == 0) ? 4 : 2;  // floats per A load
+  constexpr int NV = KH / VW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * BN;
+  const int K = p.K;
+  const int kbeg = blockIdx.z * p.kper;
+  const int kend = min(K, kbeg + p.kper);
+  const int64_t v = (int64_t)blockIdx.x * BM + wave * 32 + lr;
+  int orow = -1;
+  if (v < p.n_virtual) orow = p.row_perm ? p.row_perm[v] : (int)v;
+  const int *nb = p.nbr + (int64_t)(orow >= 0 ? orow : 0) * K;
+  const int nchunk = (p.cin + 2 * KH - 1) / (2 * KH);
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  const int ca = n0 + lr, cb = n0 + 32 + lr;
+  const bool va = ca < p.cout, vb = cb < p.cout;
+
+  float a_cur[KH], a_nxt[KH];
+  auto load_a = [&](int idx, int c0, float (&a)[KH]) {
+    const int cbase = c0 + h * KH;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = cbase + j * VW;
+      if (idx >= 0 && c + VW <= p.cin) {
+        const float *src = p.x + (int64_t)idx * p.ldx + c;
+        if (VW == 4) {
+          const float4 t = *reinterpret_cast<const float4 *>(src);
+          a[4 * j] = t.x, a[4 * j + 1] = t.y, a[4 * j + 2] = t.z, a[4 * j + 3] = t.w;
+        } else {
+          const float2 t = *reinterpret_cast<const float2 *>(src);
+          a[2 * j] = t.x, a[2 * j + 1] = t.y;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) a[VW * j + e] = (idx >= 0 && c + e < p.cin) ? p.x[(int64_t)idx * p.ldx + c + e] : 0.f;
+      }
+    }
+  };
+
+  // work items = (offset k with at least one neighbour in this wave, channel chunk)
+  int k = kbeg, idx = -1;
+  auto next_k = [&](int from) {  // first offset >= from with a neighbour (wave-uniform), or kend
+    int kk = from;
+    for (; kk < kend; ++kk) {
+      const int t = orow >= 0 ? nb[kk] : -1;
+      if (__ballot(t >= 0)) {
+        idx = t;
+        break;
+      }
+    }
+    return kk;
+  };
+  k = next_k(kbeg);
+  int ch = 0;
+  if (k < kend) load_a(idx, 0, a_cur);
+  while (k < kend) {
+    // prefetch the A fragment of the next work item
+    int nk = k, nch = ch + 1, nidx = idx;
+    if (nch == nchunk) {
+      nch = 0;
+      const int save = idx;
+      nk = next_k(k + 1);
+      nidx = idx;
+      idx = save;
+    }
+    if (nk < kend) load_a(nidx, nch * 2 * KH, a_nxt);
+    const int kw = p.flip_k ? (K - 1 - k) : k;
+    const float *wrow = p.w + ((int64_t)kw * p.cin + ch * 2 * KH + h * KH) * p.cout;
+    const int krem = p.cin - (ch * 2 * KH + h * KH);  // valid channels in this lane half
+#pragma unroll
+    for (int s = 0; s < KH; ++s) {
+      const bool kv = s < krem;
+      const float b0 = (kv && va) ? wrow[(int64_t)s * p.cout + ca] : 0.f;
+      const float b1 = (kv && vb) ? wrow[(int64_t)s * p.cout + cb] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], b1, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < KH; ++s) a_cur[s] = a_nxt[s];
+    k = nk, ch = nch, idx = nidx;
+  }
+
+  // ---- epilogue (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+  const bool direct = gridDim.z == 1;
+  float *dst = direct ? p.y : p.ws + (int64_t)blockIdx.z * p.n_out * p.cout;
+  const int ldd = direct ? p.ldy : p.cout;
+  const float bias_a = (direct && p.bias && va) ? p.bias[ca] : 0.f;
+  const float bias_b = (direct && p.bias && vb) ? p.bias[cb] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int src_lane = (r & 3) + 8 * (r >> 2) + 4 * h;  // tile row held by this accumulator register
+    const int64_t row = __shfl(orow, src_lane);           // lanes 0..31 hold the tile's output rows
+    if (row >= 0) {
+      if (va) dst[row * ldd + ca] = acc0[r] + bias_a;
+      if (vb) dst[row * ldd + cb] = acc1[r] + bias_b;
     }
   }
 }
@@ -236,7 +395,7 @@ struct WgradParams {
 // Software pipeline per tile: all G pair lists are built up front from one nbr load per row;
 // then for each offset the x gather of offset g+1 is in flight (registers) while the MFMAs
 // of offset g run from LDS.
-template <int G, bool NARROW>
+template <int G, bool NARROW, bool VEC>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   constexpr int XW = NARROW ? 32 : 64;      // x tile width (floats)
   constexpr int XLD = XW + 4;               // LDS row stride
@@ -259,8 +418,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   const int64_t rbeg = (int64_t)blockIdx.y * p.rows_per_split;
   const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
 
-  const bool vecx = ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
-  const bool vecd = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.dy) & 15) == 0);
   const int d_c4 = tid & 15, d_rr = tid >> 4;       // dy staging: float4 column, rows d_rr + 16 i
   const int x_c4 = tid % XC4, x_rr = tid / XC4;     // x staging: float4 column, rows x_rr + XRP i
 
@@ -281,7 +438,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       int src = -1;
       if (pr < mpad) src = s_src[g * LL + pr];
       const int ci = ci0 + 4 * x_c4;
-      rx[i] = src >= 0 ? ld4_guard(p.x + (int64_t)src * p.ldx + ci, p.cin - ci, vecx) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (VEC)
+        rx[i] = ld4_sel(p.x, (int64_t)src * p.ldx + ci, src >= 0 && ci < p.cin);
+      else
+        rx[i] = src >= 0 ? ld4_guard(p.x + (int64_t)src * p.ldx + ci, p.cin - ci, false) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto stash = [&]() {
@@ -303,7 +463,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       const int r = d_rr + 16 * i;
       const int64_t row = r0 + r;
       const int co = co0 + 4 * d_c4;
-      const float4 v = row < rend ? ld4_guard(p.dy + row * p.ldy + co, p.cout - co, vecd) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v;
+      if (VEC)
+        v = ld4_sel(p.dy, row * p.ldy + co, row < rend && co < p.cout);
+      else
+        v = row < rend ? ld4_guard(p.dy + row * p.ldy + co, p.cout - co, false) : make_float4(0.f, 0.f, 0.f, 0.f);
       *reinterpret_cast<float4 *>(&sD[r * WLD + 4 * d_c4]) = v;
     }
     // ---- rulebook of the tile: wave64 ballot + prefix rank per offset
@@ -433,17 +597,37 @@ static WgradPlan wgrad_plan(int64_t n_out, int K, int cin, int cout) {
 
 template <int G>
 static void launch_wgrad(const WgradParams &p, dim3 grid, hipStream_t st) {
-  if (p.cin <= 32)
-    wgrad_kernel<G, true><<<grid, 256, 0, st>>>(p);
-  else
-    wgrad_kernel<G, false><<<grid, 256, 0, st>>>(p);
+  const bool vec = (((uintptr_t)p.x | (uintptr_t)p.dy) & 15) == 0 && ((p.ldx | p.ldy | p.cin | p.cout) & 3) == 0;
+  if (p.cin <= 32) {
+    if (vec) wgrad_kernel<G, true, true><<<grid, 256, 0, st>>>(p);
+    else wgrad_kernel<G, true, false><<<grid, 256, 0, st>>>(p);
+  } else {
+    if (vec) wgrad_kernel<G, false, true><<<grid, 256, 0, st>>>(p);
+    else wgrad_kernel<G, false, false><<<grid, 256, 0, st>>>(p);
+  }
 }
 
 }  // namespace mink
 
 using namespace mink;
 
+static int g_stagger = 0;
+static int g_use_direct = 0;  // measured slower than the LDS-staged kernel (B operand traffic)
+
 extern "C" {
+
+/* 0 = always use the LDS-staged kernel, 1 = use the LDS-free direct kernel where it applies */
+int mink_conv_set_direct(int on) {
+  const int old = g_use_direct;
+  g_use_direct = on;
+  return old;
+}
+
+int mink_conv_set_stagger(int units) {
+  const int old = g_stagger;
+  g_stagger = units;
+  return old;
+}
 
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout) {
   if (n_out <= 0 || K <= 1) return 1;
@@ -470,16 +654,29 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
   MINK_REQUIRE(n_virtual >= n_out, "gather_gemm: the row permutation must cover every output row");
   GemmParams p;
   p.row_perm = row_perm, p.n_virtual = n_virtual;
+  p.stagger = g_stagger;
   p.x = x, p.w = w, p.nbr = nbr, p.bias = bias, p.y = y, p.ws = workspace;
   p.n_out = n_out, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K, p.flip_k = flip_k;
   p.kper = (int)cdiv(K, ksplit);
   const int zs = (int)cdiv(K, p.kper);
   const dim3 grid((unsigned)cdiv(n_virtual, BM), (unsigned)cdiv(cout, BN), (unsigned)zs);
   hipStream_t st = (hipStream_t)stream;
-  if (w_transposed)
-    gather_gemm_kernel<true><<<grid, 256, 0, st>>>(p);
-  else
-    gather_gemm_kernel<false><<<grid, 256, 0, st>>>(p);
+  // direct (LDS-free) path: natural weight layout, 8-byte aligned channel halves
+  const bool a8 = ((ldx & 1) == 0) && (((uintptr_t)x & 15) == 0);
+  if (!w_transposed && g_use_direct && a8 && cin == 28)
+    conv_direct_kernel<14><<<grid, 256, 0, st>>>(p);
+  else if (!w_transposed && g_use_direct && a8 && (ldx & 3) == 0 && (cin % 64) == 0)
+    conv_direct_kernel<32><<<grid, 256, 0, st>>>(p);
+  else if (!w_transposed && g_use_direct && a8 && (ldx & 3) == 0 && (cin % 32) == 0)
+    conv_direct_kernel<16><<<grid, 256, 0, st>>>(p);
+  else {
+    const bool al = (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && (ldx & 3) == 0 && (cin & 3) == 0;
+    const bool vec = al && (w_transposed ? true : (cout & 3) == 0);
+    if (w_transposed && vec) gather_gemm_kernel<true, true><<<grid, 256, 0, st>>>(p);
+    else if (w_transposed) gather_gemm_kernel<true, false><<<grid, 256, 0, st>>>(p);
+    else if (vec) gather_gemm_kernel<false, true><<<grid, 256, 0, st>>>(p);
+    else gather_gemm_kernel<false, false><<<grid, 256, 0, st>>>(p);
+  }
   MINK_CHECK_LAUNCH();
   if (zs > 1) {
     splitk_reduce_kernel<<<dim3((unsigned)cdiv(n_out * cout, 256)), 256, 0, st>>>(workspace, n_out, cout, zs, bias, y,

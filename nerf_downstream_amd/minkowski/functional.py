@@ -121,11 +121,15 @@ class ConvolutionFunction(torch.autograd.Function):
         gy = _f32c(gy)
         gx = None
         if ctx.needs_input_grad[0]:
+            # dgrad = the same gather-GEMM over the transposed map with W[k]^T; transposing the
+            # (small) kernel once lets it run on the LDS-free direct path like the forward
+            direct = w.shape[-1] % 32 == 0
+            wd = w.transpose(1, 2).contiguous() if direct else w
             if ctx.same_map:  # stride 1: nbr_t[i][k] == nbr[i][K-1-k]
-                gx = gather_gemm(gy, w, ctx.nbr, w.shape[-2], w_transposed=True, flip_k=True)
+                gx = gather_gemm(gy, wd, ctx.nbr, w.shape[-2], w_transposed=not direct, flip_k=True)
             else:
                 _, nbr_t, perm = ctx.table_fn(True)
-                gx = gather_gemm(gy, w, nbr_t, w.shape[-2], w_transposed=True, row_perm=perm)
+                gx = gather_gemm(gy, wd, nbr_t, w.shape[-2], w_transposed=not direct, row_perm=perm)
         gw = conv_wgrad(x, gy, ctx.nbr, w.shape) if ctx.needs_input_grad[1] else None
         return gx, gw, None, None
 

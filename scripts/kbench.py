@@ -1,0 +1,70 @@
+"""Micro-benchmark of the convolution kernels on one BASELINE-shape batch (run on the GPU box).
+usage: python scripts/kbench.py [stem|l1|l4|all] [reps]"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+from bench import make_batches
+from nerf_downstream_amd import minkowski as ME
+from nerf_downstream_amd.minkowski import functional as Fn
+
+which = sys.argv[1] if len(sys.argv) > 1 else "stem"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+dev = torch.device("cuda", 0)
+b = make_batches(1, 16, 0, 51, 128, 28)[0]
+tf = ME.TensorField(coordinates=b["coordinates"].to(dev), features=b["features"].to(dev))
+x = tf.sparse()
+m = x.coordinate_manager
+torch.manual_seed(0)
+
+def timeit(fn, reps):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+def bench_layer(name, xin, in_key, out_key, ks, cin, cout, stride):
+    nbr, nbr_t = m.kernel_table(in_key, out_key, ks, 1, transposed=(stride != 1))
+    pairs = int((nbr >= 0).sum())
+    w = torch.randn(ks ** 3, cin, cout, device=dev) * 0.05
+    gy = torch.randn(nbr.shape[0], cout, device=dev)
+    fl = 2.0 * pairs * cin * cout
+    t = timeit(lambda: Fn.gather_gemm(xin, w, nbr, cout), reps)
+    print(f"{name:10s} fwd   n_out={nbr.shape[0]:7d} pairs={pairs:9d} {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s")
+    if stride == 1:
+        wt = w.transpose(1, 2).contiguous()
+        t = timeit(lambda: Fn.gather_gemm(gy, wt, nbr, cin, flip_k=True), reps)
+    else:
+        perm = m.class_perm(in_key) if stride == 2 else None
+        wt = w.transpose(1, 2).contiguous()
+        t = timeit(lambda: Fn.gather_gemm(gy, wt, nbr_t, cin, row_perm=perm), reps)
+    print(f"{name:10s} dgrad n_in ={xin.shape[0]:7d}                 {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s")
+    t = timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, w.shape), reps)
+    print(f"{name:10s} wgrad                                {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s")
+
+k1 = ME.CoordinateMapKey(1)
+if which == "stagger":
+    from nerf_downstream_amd._lib import lib
+    nbr, _ = m.kernel_table(k1, k1, 3, 1)
+    w = torch.randn(27, 28, 64, device=dev) * 0.05
+    xin = x.F.contiguous()
+    for st in (0, 0, 64, 128, 192, 0, 64, 128):
+        lib().mink_conv_set_stagger(st)
+        t = timeit(lambda: Fn.gather_gemm(xin, w, nbr, 64), reps)
+        print(f"stagger {st}: stem fwd {t*1e3:8.1f} us")
+if which in ("stem", "all"):
+    bench_layer("stem", x.F.contiguous(), k1, k1, 3, 28, 64, 1)
+if which in ("l1", "l4", "all"):
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    for ts in (2, 4, 8, 16):
+        if which == "l1" and ts > 2: break
+        if which == "l4" and ts < 16: continue
+        cin, cout = chans[ts], chans[ts * 2]
+        xin = torch.randn(m.levels[ts].n, cin, device=dev)
+        bench_layer(f"l@{ts}.c1", xin, keys[ts], keys[ts * 2], 3, cin, cout, 2)
+        xin2 = torch.randn(m.levels[ts * 2].n, cout, device=dev)
+        bench_layer(f"l@{ts*2}.c2", xin2, keys[ts * 2], keys[ts * 2], 3, cout, cout, 1)
