@@ -242,6 +242,208 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------------ pipelined
+// Software-pipelined gather-GEMM (the production kernel for 16-byte aligned operands).
+// Per work item (kernel offset k, 32-channel chunk):
+//     global loads   run THREE items ahead   (registers ga/gb)
+//     LDS tiles      hold items c+1 and c+2  (double buffer, ONE raw s_barrier per item)
+//     MFMA operands  are read from LDS ONE item ahead (register sets R0/R1)
+// so the 32 MFMAs of an item never wait for a load issued in the same iteration, and the wave's
+// own LDS reads / writes / global loads issue in the shadow of the 64-cycle MFMAs.
+// STAGE: the tile's slice of the neighbour table is staged in LDS and offsets without any
+// neighbour in the tile are skipped (essential for the class-permuted dgrad of strided convs);
+// otherwise indices are read straight from the table one offset ahead.
+#define MINK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <bool W_T, bool STAGE>
+__global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float sA[2][BM * LDA];
+  __shared__ __attribute__((aligned(16))) float sB[2][BK * BN];
+  __shared__ int s_nbr[STAGE ? BM * KMAX : 1];
+  __shared__ int s_orow[BM];
+  __shared__ unsigned s_kmask;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t o0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int K = p.K;
+  const int kbeg = blockIdx.z * p.kper;
+  const int kend = min(K, kbeg + p.kper);
+
+  if (tid == 0) s_kmask = 0u;
+  if (tid < BM) {
+    const int64_t v = o0 + tid;
+    int orow = -1;
+    if (v < p.n_virtual) orow = p.row_perm ? p.row_perm[v] : (int)v;
+    s_orow[tid] = orow;
+  }
+  __syncthreads();
+  unsigned kmask = (kend < 32 ? (1u << kend) - 1u : 0xFFFFFFFFu) & ~((1u << kbeg) - 1u);
+  if (STAGE) {
+    unsigned m = 0u;
+    int lr = tid / K, kk = tid - lr * K;  // element e = tid + 256 i  ->  (row lr, offset kk)
+    const int dlr = 256 / K, dkk = 256 - dlr * K;
+    for (int e = tid; e < BM * K; e += 256) {
+      const int orow = s_orow[lr];
+      const int v = orow >= 0 ? p.nbr[(int64_t)orow * K + kk] : -1;
+      s_nbr[e] = v;
+      if (v >= 0) m |= 1u << kk;
+      lr += dlr, kk += dkk;
+      if (kk >= K) kk -= K, ++lr;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m |= __shfl_xor(m, d);
+    if (lane == 0 && m) atomicOr(&s_kmask, m);
+    __syncthreads();
+    kmask &= s_kmask;
+  }
+  const int ncc = (p.cin + BK - 1) / BK;
+  const int n_items = __popc(kmask) * ncc;
+
+  // per-thread staging coordinates
+  const int a_cc = tid & 7, a_r = tid >> 3;     // A: rows a_r + 32 i, float4 column a_cc
+  const int b_n4 = tid & 15, b_kk = tid >> 4;   // B (!W_T): rows b_kk + 16 i, float4 column b_n4
+  const int bt_n = tid & 63, bt_k4 = tid >> 6;  // B (W_T) : column bt_n, float4 of k at 4*(bt_k4 + 4 i)
+  int my_orow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) my_orow[i] = s_orow[a_r + 32 * i];
+
+  int gk = kmask ? __builtin_ctz(kmask) : -1, gc0 = 0;  // iterator of the global-load stage
+  int idx_g[4] = {-1, -1, -1, -1};
+  auto load_idx = [&](int k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (STAGE)
+        idx_g[i] = s_nbr[(a_r + 32 * i) * K + k];
+      else
+        idx_g[i] = my_orow[i] >= 0 ? p.nbr[(int64_t)my_orow[i] * K + k] : -1;
+    }
+  };
+  float4 ga[4], gb[2];
+  auto gload = [&]() {  // item (gk, gc0) -> registers; then advance (prefetching the next indices)
+    const int kw = p.flip_k ? (K - 1 - gk) : gk;
+    const int c = gc0 + 4 * a_cc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ga[i] = ld4_sel(p.x, (int64_t)idx_g[i] * p.ldx + c, idx_g[i] >= 0 && c < p.cin);
+    if (!W_T) {
+      const int n = n0 + 4 * b_n4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = gc0 + b_kk + 16 * i;
+        gb[i] = ld4_sel(p.w, ((int64_t)kw * p.cin + kk) * p.cout + n, kk < p.cin && n < p.cout);
+      }
+    } else {
+      const int n = n0 + bt_n;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = gc0 + 4 * (bt_k4 + 4 * i);
+        gb[i] = ld4_sel(p.w, ((int64_t)kw * p.cout + n) * p.cin + kk, n < p.cout && kk < p.cin);
+      }
+    }
+    gc0 += BK;
+    if (gc0 >= p.cin) {
+      gc0 = 0;
+      const unsigned rest = (gk + 1 < 32) ? (kmask >> (gk + 1)) : 0u;
+      gk = rest ? (gk + 1 + __builtin_ctz(rest)) : -1;
+      if (gk >= 0) load_idx(gk);
+    }
+  };
+  auto sts = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&sA[buf][(a_r + 32 * i) * LDA + 4 * a_cc]) = ga[i];
+    if (!W_T) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<float4 *>(&sB[buf][(b_kk + 16 * i) * BN + 4 * b_n4]) = gb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = 4 * (bt_k4 + 4 * i);
+        sB[buf][(kk + 0) * BN + bt_n] = gb[i].x;
+        sB[buf][(kk + 1) * BN + bt_n] = gb[i].y;
+        sB[buf][(kk + 2) * BN + bt_n] = gb[i].z;
+        sB[buf][(kk + 3) * BN + bt_n] = gb[i].w;
+      }
+    }
+  };
+  const int arow = wave * 32 + (lane & 31), h = lane >> 5, col = lane & 31;
+  struct Ops {
+    float4 a[4];
+    float b0[16], b1[16];
+  };
+  auto lds_read = [&](int buf, Ops &r) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r.a[t] = *reinterpret_cast<const float4 *>(&sA[buf][arow * LDA + 8 * t + 4 * h]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = 8 * t + 4 * h + j;
+        r.b0[4 * t + j] = sB[buf][kk * BN + col];
+        r.b1[4 * t + j] = sB[buf][kk * BN + 32 + col];
+      }
+  };
+  f32x16 acc0 = {0}, acc1 = {0};
+  auto mfma_half = [&](const Ops &r, int t0) {
+#pragma unroll
+    for (int t = t0; t < t0 + 2; ++t) {
+      const float a4[4] = {r.a[t].x, r.a[t].y, r.a[t].z, r.a[t].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], r.b0[4 * t + j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], r.b1[4 * t + j], acc1, 0, 0, 0);
+      }
+    }
+  };
+
+  Ops R0, R1;
+  // ---- prologue: items 0,1 -> LDS, item 2 in flight, operands of item 0 in registers
+  if (n_items > 0) {
+    load_idx(gk);
+    gload();
+    sts(0);
+  }
+  if (n_items > 1) {
+    gload();
+    sts(1);
+  }
+  if (n_items > 2) gload();
+  MINK_LDS_BARRIER();
+  if (n_items > 0) lds_read(0, R0);
+  MINK_LDS_BARRIER();
+
+  auto body = [&](int c, const Ops &cur, Ops &nxt) {
+    if (c + 1 < n_items) lds_read((c + 1) & 1, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(cur, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 2 < n_items) sts(c & 1);  // item c+2 replaces item c (every wave read it last iteration)
+    if (c + 3 < n_items) gload();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(cur, 2);
+    MINK_LDS_BARRIER();
+  };
+  for (int c = 0; c < n_items; c += 2) {
+    body(c, R0, R1);
+    if (c + 1 < n_items) body(c + 1, R1, R0);
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool direct = gridDim.z == 1;
+  float *dst = direct ? p.y : p.ws + (int64_t)blockIdx.z * p.n_out * p.cout;
+  const int ldd = direct ? p.ldy : p.cout;
+  const int c_a = n0 + col, c_b = n0 + 32 + col;
+  const float bias_a = (direct && p.bias && c_a < p.cout) ? p.bias[c_a] : 0.f;
+  const float bias_b = (direct && p.bias && c_b < p.cout) ? p.bias[c_b] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = s_orow[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+    if (row >= 0) {
+      if (c_a < p.cout) dst[row * ldd + c_a] = acc0[r] + bias_a;
+      if (c_b < p.cout) dst[row * ldd + c_b] = acc1[r] + bias_b;
+    }
+  }
+}
+
 // --------------------------------------------------------------------------- direct
 // Barrier-free variant of the gather-GEMM for w[K][cin][cout] weights: every wave owns 32
 // output rows x 64 columns and feeds the MFMA straight from global memory / L1 -- the A
@@ -612,6 +814,7 @@ static void launch_wgrad(const WgradParams &p, dim3 grid, hipStream_t st) {
 using namespace mink;
 
 static int g_stagger = 0;
+static int g_pipeline = 1;
 static int g_use_direct = 0;  // measured slower than the LDS-staged kernel (B operand traffic)
 
 extern "C" {
@@ -625,7 +828,8 @@ int mink_conv_set_direct(int on) {
 
 int mink_conv_set_stagger(int units) {
   const int old = g_stagger;
-  g_stagger = units;
+  g_stagger = units & 255;
+  g_pipeline = !(units & 256);  // bit 8: fall back to the un-pipelined kernel (A/B benchmarks)
   return old;
 }
 
@@ -672,7 +876,13 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
   else {
     const bool al = (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && (ldx & 3) == 0 && (cin & 3) == 0;
     const bool vec = al && (w_transposed ? true : (cout & 3) == 0);
-    if (w_transposed && vec) gather_gemm_kernel<true, true><<<grid, 256, 0, st>>>(p);
+    const bool stage = row_perm != nullptr;
+    if (vec && g_pipeline) {
+      if (w_transposed && stage) gather_gemm2_kernel<true, true><<<grid, 256, 0, st>>>(p);
+      else if (w_transposed) gather_gemm2_kernel<true, false><<<grid, 256, 0, st>>>(p);
+      else if (stage) gather_gemm2_kernel<false, true><<<grid, 256, 0, st>>>(p);
+      else gather_gemm2_kernel<false, false><<<grid, 256, 0, st>>>(p);
+    } else if (w_transposed && vec) gather_gemm_kernel<true, true><<<grid, 256, 0, st>>>(p);
     else if (w_transposed) gather_gemm_kernel<true, false><<<grid, 256, 0, st>>>(p);
     else if (vec) gather_gemm_kernel<false, true><<<grid, 256, 0, st>>>(p);
     else gather_gemm_kernel<false, false><<<grid, 256, 0, st>>>(p);
