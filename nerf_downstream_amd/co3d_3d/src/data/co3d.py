@@ -1,0 +1,80 @@
+"""PeRFception-CO3D plenoxel dataset (counterpart of the reference's
+co3d_3d/src/data/co3d.py:70-268; on-disk format documented by scripts/preprocess.py:30-57).
+
+Scene directory `<data_root>/plenoxel_co3d_<scene>/data.npz` holds
+    links   int32 [N]     flat index into the 128^3 grid (x*128*128 + y*128 + z)
+    density f32   [N,1]
+    sh      uint8 [N,27]  de-quantised as sh * sh_scale + sh_min
+`filelist/<phase>.txt` (relative to the CWD, like the reference :100) lists "<class> <scene>".
+Sample dict / feature selection follow co3d.py:185-242.  Augmentations (transforms.py) are out
+of scope (the classification configs run with none: co3d_cls.gin:9-10)."""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from nerf_downstream_amd import gin_lite as gin
+
+CLASSES = (
+    "apple backpack ball banana baseballbat baseballglove bench bicycle book bottle bowl broccoli cake car carrot "
+    "cellphone chair couch cup donut frisbee hairdryer handbag hotdog hydrant keyboard kite laptop microwave "
+    "motorcycle mouse orange parkingmeter pizza plant remote sandwich skateboard stopsign suitcase teddybear toaster "
+    "toilet toybus toyplane toytrain toytruck tv umbrella vase wineglass"
+).split()
+assert len(CLASSES) == 51
+
+
+def links_to_coordinates(links, reso):
+    """flat grid index -> float (x,y,z) voxel coordinates (co3d.py:196-203)."""
+    links = torch.as_tensor(links).long()
+    yz = reso[1] * reso[2]
+    return torch.stack([links // yz, (links % yz) // reso[2], links % reso[2]], 1).float()
+
+
+def select_features(coordinates, density, sh, names):
+    """raw columns [xyzs | density | sh] selected by name (co3d.py:205-229)."""
+    xyzs = coordinates - coordinates.mean(dim=1, keepdim=True)  # per-point mean, as the reference (:211)
+    xyzs = xyzs / torch.linalg.norm(xyzs, dim=1).max()
+    cols = {"xyzs": xyzs, "density": density, "sh": sh, "ones": torch.ones_like(density)}
+    return torch.cat([cols[n] for n in names], dim=1).float(), xyzs
+
+
+@gin.configurable()
+class Co3DDatasetBase(Dataset):
+    def __init__(self, phase, data_root="co3d_3d/datasets/co3d", train_transformations=(), eval_transformations=(),
+                 downsample_mode=1, downsample_stride=2, num_points=-1, features=("sh",), filelist_dir="filelist"):
+        phase = "test" if phase in ("val", "test") else "train"  # reference :84 (val == test list)
+        if (train_transformations if phase == "train" else eval_transformations):
+            raise NotImplementedError("CPU augmentations (reference transforms.py) are outside the MI355X hot path")
+        self.phase, self.data_root, self.features = phase, data_root, list(features)
+        with open(os.path.join(filelist_dir, f"{phase}.txt")) as f:
+            self.files = [line.split()[:2] for line in f if line.strip()]
+        self.CLASS_LABELS, self.NUM_CLASSES = CLASSES, len(CLASSES)
+
+    def load_data(self, inst_id):
+        path = os.path.join(self.data_root, f"plenoxel_co3d_{inst_id}", "data.npz")
+        if not os.path.exists(path):
+            raise ValueError(f"{inst_id} not exist in {self.data_root} (only the data.npz format is supported)")
+        z = np.load(path)
+        sh = z["sh"].astype(np.float32) * z["sh_scale"] + z["sh_min"]
+        return torch.from_numpy(z["links"]), torch.from_numpy(z["density"].astype(np.float32)), torch.from_numpy(sh)
+
+    def __getitem__(self, index):
+        label, inst_id = self.files[index]
+        links, density, sh = self.load_data(inst_id)
+        coordinates = links_to_coordinates(links, [128, 128, 128])
+        feats, xyzs = select_features(coordinates, density.reshape(-1, 1), sh.reshape(len(links), -1), self.features)
+        return {"coordinates": coordinates, "features": feats, "xyzs": xyzs,
+                "labels": np.array([self.CLASS_LABELS.index(label)])}
+
+    def __len__(self):
+        return len(self.files)
+
+
+class Co3DDataset(Co3DDatasetBase):
+    pass
+
+
+class Co3D10pDataset(Co3DDatasetBase):
+    pass

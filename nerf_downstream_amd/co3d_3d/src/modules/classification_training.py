@@ -1,0 +1,45 @@
+"""Classification step logic (counterpart of the reference's
+co3d_3d/src/modules/classification_training.py:19-97, without PyTorch-Lightning):
+forward = model.process_input(batch) -> model(...), loss = F.cross_entropy(logits, labels),
+top-1 / top-5 in percent, NaN guard on the logged loss."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@torch.no_grad()
+def accuracy(output, target, topk=(1,)):
+    """Percent of samples whose label is among the k highest logits (reference :83-97)."""
+    maxk = min(max(topk), output.shape[1])
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.view(1, -1))
+    return [float(correct[: min(k, maxk)].any(0).float().sum() * (100.0 / target.numel())) for k in topk]
+
+
+class ClassificationTraining:
+    def __init__(self, model):
+        self.model = model
+
+    def forward(self, batch_or_field):
+        x = batch_or_field if hasattr(batch_or_field, "sparse") else self.model.process_input(batch_or_field)
+        return self.model(x)
+
+    def training_step(self, batch, field=None):
+        out = self.forward(field if field is not None else batch)
+        labels = batch["labels"].long()
+        return F.cross_entropy(out, labels), out
+
+    @staticmethod
+    def check_finite(loss_float):
+        if not np.isfinite(loss_float):
+            raise ValueError(f"Invalid loss: {loss_float}")
+
+    @torch.no_grad()
+    def validation_step(self, batch):
+        logits = self.forward(batch)
+        labels = batch["labels"].long()
+        loss = F.cross_entropy(logits, labels)
+        top = logits.topk(min(5, logits.shape[1]), 1).indices
+        c1 = (top[:, 0] == labels).sum()
+        c5 = (top == labels[:, None]).any(1).sum()
+        return loss.detach(), c1, c5, labels.numel()

@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Trainer of the plenoxel voxel-grid classifier: same command line, gin names and training
+recipe as the reference's co3d_3d/train.py (argparse :198-238, `train()` parameters :50-97),
+driven by the same config files, e.g.
+
+    python -m nerf_downstream_amd.co3d_3d.train --ginc nerf_downstream_amd/co3d_3d/configs/co3d_cls.gin \
+        --ginc nerf_downstream_amd/co3d_3d/configs/resnet14.gin --gpus 8
+
+The reference builds a PyTorch-Lightning Trainer with DDP (:174-187); this is a plain loop with
+the same semantics -- per-rank batches of `train.batch_size`, per-rank BatchNorm statistics,
+mean of the gradients over the ranks each step (bucketed RCCL all-reduce overlapped with
+backward, nerf_downstream_amd/parallel.py), SGD / cosine schedule stepped per iteration,
+validation top-1/top-5, `last.ckpt` / best checkpoint with `model.`-prefixed keys.
+One process per GPU: with --gpus N > 1 and no torchrun environment it re-launches itself under
+`python -m torch.distributed.run` (as a child process, before touching the GPU).
+"""
+import argparse
+import csv
+import json
+import logging
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from nerf_downstream_amd import gin_lite as gin
+from nerf_downstream_amd.co3d_3d.src.data.data_module import DataModule
+from nerf_downstream_amd.co3d_3d.src.models import get_model
+from nerf_downstream_amd.co3d_3d.src.modules.classification_training import ClassificationTraining, accuracy
+from nerf_downstream_amd.co3d_3d.src.modules.optim import get_optimizer, get_scheduler
+from nerf_downstream_amd.parallel import BucketedGradAllReduce
+
+logger = logging.getLogger(__name__)
+
+
+class CSVLogger:
+    def __init__(self, save_path, run_name):
+        self.dir = os.path.join(save_path, run_name)
+        os.makedirs(self.dir, exist_ok=True)
+        self.path = os.path.join(self.dir, "metrics.csv")
+        self.rows = []
+
+    def log_dict(self, metrics, step):
+        row = {"global_step": step, **{k: (float(v) if hasattr(v, "__float__") else v) for k, v in metrics.items()}}
+        self.rows.append(row)
+        keys = sorted({k for r in self.rows for k in r})
+        with open(self.path, "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=keys)
+            w.writeheader()
+            w.writerows(self.rows)
+
+
+def _to_device(batch, device):
+    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def _dist_env():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def save_checkpoint(path, model, optimizer, scheduler, step, epoch, best):
+    torch.save(
+        {
+            "state_dict": {"model." + k: v for k, v in model.state_dict().items()},  # Lightning key layout
+            "optimizer_states": [optimizer.state_dict()],
+            "lr_schedulers": [scheduler.state_dict()] if scheduler is not None else [],
+            "global_step": step,
+            "epoch": epoch,
+            "best": best,
+        },
+        path,
+    )
+
+
+def load_checkpoint(path, model, optimizer=None, scheduler=None, weights_only=False):
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in ckpt["state_dict"].items()}
+    model.load_state_dict(sd)
+    if not weights_only:
+        if optimizer is not None and ckpt.get("optimizer_states"):
+            optimizer.load_state_dict(ckpt["optimizer_states"][0])
+        if scheduler is not None and ckpt.get("lr_schedulers"):
+            scheduler.load_state_dict(ckpt["lr_schedulers"][0])
+    return ckpt
+
+
+@torch.no_grad()
+def validate(module, loader, device, world):
+    model = module.model
+    was_training = model.training
+    model.eval()
+    tot = torch.zeros(4, dtype=torch.float64, device=device)  # loss*n, correct1, correct5, n
+    for batch in loader:
+        batch = _to_device(batch, device)
+        loss, c1, c5, n = module.validation_step(batch)
+        tot += torch.stack([loss.double() * n, c1.double(), c5.double(), torch.tensor(float(n), device=device, dtype=torch.float64)])
+    if world > 1:
+        dist.all_reduce(tot)
+    model.train(was_training)
+    n = max(tot[3].item(), 1.0)
+    return {"val/loss": tot[0].item() / n, "val/acc1": 100.0 * tot[1].item() / n, "val/acc5": 100.0 * tot[2].item() / n}
+
+
+@gin.configurable
+def train(
+    save_path: str,
+    gpus: int,
+    run_name: str,
+    run_name_postfix: str,
+    project_name: str,
+    max_steps: int,
+    max_epochs: int,
+    warmup_steps: int = -1,
+    model=None,
+    training_module: str = "SegmentationTraining",
+    optimizer_name: str = "SGD",
+    scheduler_name: str = "PolyLR",
+    scheduler_interval: str = "step",
+    lr: float = 1e-3,
+    weight_decay: float = 1e-4,
+    batch_size: int = 8,
+    val_batch_size: int = 6,
+    prune_batch_size: int = 8,
+    train_num_workers: int = 4,
+    val_num_workers: int = 2,
+    collate_func_name: str = "collate_mink",
+    val_every_n_steps: int = 1000,
+    log_every_n_steps: int = 10,
+    reset_profiler_every_n_steps: int = 1000,
+    progressbar_refresh_rate: int = 1,
+    loggers: list = ["csv"],
+    resume_training: bool = False,
+    checkpoint_path: str = None,
+    load_weights: bool = False,
+    load_optimizers: bool = False,
+    transfer_self_supervised: bool = False,
+    use_sync_batchnorm: bool = False,
+    use_sync_grad: bool = False,
+    ignore_label: int = -100,
+    train_phase="train",
+    val_phase="val",
+    test_phase="test",
+    monitor_metric: str = "val/mIoU",
+    evaluate: bool = False,
+    void_weight=None,
+    debug: bool = False,
+    ME=None,
+    device=None,
+    seed: int = 777,
+):
+    """Same parameters (and gin bindings `train.*`) as the reference.  `ME` / `device` are test
+    hooks: the CPU tests inject the oracle namespace to run BASELINE config #1 on the host."""
+    if training_module != "ClassificationTraining":
+        raise NotImplementedError(f"{training_module}: only ClassificationTraining is on the MI355X hot path")
+    if scheduler_interval != "step":
+        raise NotImplementedError("the classification configs step the scheduler per iteration")
+    world, rank, local_rank = _dist_env()
+    if device is None:
+        if ME is None and not torch.cuda.is_available():
+            raise RuntimeError("co3d_3d.train needs a GPU: the HIP backend has no CPU fallback (reference: accelerator='gpu')")
+        device = torch.device("cuda", local_rank) if torch.cuda.is_available() and ME is None else torch.device("cpu")
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if device.type == "cuda" else "gloo")
+    os.makedirs(save_path, exist_ok=True)
+
+    torch.manual_seed(seed)  # identical initial weights on every rank (reference: pl.seed_everything)
+    if model is None:
+        model = get_model(ME=ME) if ME is not None else get_model()
+    if use_sync_batchnorm and world > 1:
+        from nerf_downstream_amd import minkowski
+
+        model = minkowski.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
+    model = model.to(device)
+    if run_name is None or "default" in run_name.lower() or run_name == "":
+        run_name = f"b{batch_size}x{gpus}-{model.__class__.__name__}"
+    if run_name_postfix is not None:
+        run_name += "-" + run_name_postfix
+
+    data = DataModule(train_phase, val_phase, test_phase, batch_size, val_batch_size, train_num_workers, val_num_workers,
+                      collate_func_name, world_size=world, rank=rank, seed=seed)
+    module = ClassificationTraining(model)
+    optimizer = get_optimizer(optimizer_name, model.parameters(), lr=lr, weight_decay=weight_decay)
+    scheduler = get_scheduler(scheduler_name, optimizer, warmup_steps)
+    reducer = BucketedGradAllReduce(model) if world > 1 else None
+    csv_logger = CSVLogger(save_path, run_name) if rank == 0 and "csv" in loggers else None
+    for name in loggers:
+        if name != "csv" and rank == 0:
+            logger.warning(f"logger {name!r} is not available here; only 'csv' is written")
+
+    step, epoch, best = 0, 0, -float("inf")
+    last_ckpt = os.path.join(save_path, run_name, "last.ckpt")
+    if resume_training or load_weights:
+        path = checkpoint_path or last_ckpt
+        ck = load_checkpoint(path, model, optimizer if (resume_training or load_optimizers) else None,
+                             scheduler if resume_training else None, weights_only=not resume_training and not load_optimizers)
+        if resume_training:
+            step, epoch, best = ck["global_step"], ck["epoch"], ck.get("best", best)
+        logger.info(f"loaded {path} (step {step})")
+
+    train_loader, val_loader = data.train_dataloader(), data.val_dataloader()
+    total_steps = max_steps + (warmup_steps if warmup_steps > 0 else 0)
+    history = []
+    model.train()
+    t_iter = time.perf_counter()
+    done = step >= total_steps
+    while not done and (max_epochs <= 0 or epoch < max_epochs):
+        if hasattr(train_loader.sampler, "set_epoch"):
+            train_loader.sampler.set_epoch(epoch)
+        it = iter(train_loader)
+        batch = next(it, None)
+        if batch is not None:
+            batch = _to_device(batch, device)
+            field = model.process_input(batch)
+        while batch is not None:
+            if reducer is not None:
+                reducer.zero_grad()
+            else:
+                optimizer.zero_grad(set_to_none=True)
+            loss, out = module.training_step(batch, field)
+            loss.backward()
+            # prepare the next batch (coordinate / kernel maps on the side stream) under backward
+            cur_batch = batch
+            batch = next(it, None)
+            if batch is not None:
+                batch = _to_device(batch, device)
+                field = model.process_input(batch)
+            if reducer is not None:
+                reducer.finish()
+            optimizer.step()
+            if scheduler is not None:
+                scheduler.step()
+            step += 1
+            if step % log_every_n_steps == 0:
+                loss_float = float(loss.detach().cpu())
+                ClassificationTraining.check_finite(loss_float)
+                acc1, acc5 = accuracy(out.detach(), cur_batch["labels"].long(), topk=(1, 5))
+                now = time.perf_counter()
+                m = {"train/loss": loss_float, "train/acc1": acc1, "train/acc5": acc5,
+                     "train/iter_time": (now - t_iter) / log_every_n_steps, "lr": optimizer.param_groups[0]["lr"]}
+                t_iter = now
+                history.append({"global_step": step, **m})
+                if csv_logger:
+                    csv_logger.log_dict(m, step)
+                if rank == 0:
+                    logger.info(f"step {step}: " + " ".join(f"{k}={v:.4g}" for k, v in m.items()))
+            if step % val_every_n_steps == 0 or step >= total_steps:
+                vm = validate(module, val_loader, device, world)
+                history.append({"global_step": step, **vm})
+                if csv_logger:
+                    csv_logger.log_dict(vm, step)
+                if rank == 0:
+                    logger.info(f"step {step}: " + " ".join(f"{k}={v:.4g}" for k, v in vm.items()))
+                    os.makedirs(os.path.dirname(last_ckpt), exist_ok=True)
+                    save_checkpoint(last_ckpt, model, optimizer, scheduler, step, epoch, best)
+                    score = vm.get(monitor_metric, vm["val/acc1"])
+                    if score > best:
+                        best = score
+                        save_checkpoint(os.path.join(save_path, run_name, "best.ckpt"), model, optimizer, scheduler, step, epoch, best)
+            if step >= total_steps:
+                done = True
+                break
+        epoch += 1
+    results = {"global_step": step, "best": best, "history": history}
+    if evaluate and rank == 0:
+        with open(os.path.join(save_path, "eval_results.json"), "w") as f:
+            json.dump({k: v for k, v in results.items() if k != "history"}, f)
+    return results
+
+
+def setup_logger(exp_name, debug):
+    tag = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "0"))
+    logging.basicConfig(level=logging.DEBUG if debug else logging.INFO, format=f"{tag}:[{exp_name}] %(asctime)s %(message)s",
+                        datefmt="[%X]", handlers=[logging.StreamHandler(sys.stdout)], force=True)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--ginc", action="append", help="gin config file")
+    p.add_argument("--ginb", action="append", help="gin bindings")
+    p.add_argument("--save_path", type=str, default="experiments", help="path for logging")
+    p.add_argument("--resume", action="store_true", help="resume training")
+    p.add_argument("--run_name", type=str, default=None)
+    p.add_argument("--run_name_postfix", type=str, default=None)
+    p.add_argument("--gpus", type=int, default=1, help="num_gpus")
+    p.add_argument("--seed", type=int, default=777)
+    p.add_argument("--debug", action="store_true")
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU; start the workers as a child job and return its exit code
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"),
+               "-m", "nerf_downstream_amd.co3d_3d.train"] + (argv if argv is not None else sys.argv[1:])
+        return subprocess.call(cmd)
+    run_name = args.run_name if args.run_name is not None else "default"
+    if args.run_name_postfix is not None:
+        run_name = f"{run_name}-{args.run_name_postfix}"
+    setup_logger(f"{run_name}_{args.seed}", args.debug)
+    ginbs = [f"train.gpus={args.gpus}"] + (args.ginb or [])
+    logging.info(f"Gin configuration files: {args.ginc}")
+    logging.info(f"Gin bindings: {ginbs}")
+    np.random.seed(args.seed)
+    gin.parse_config_files_and_bindings(args.ginc, ginbs)
+    train(save_path=args.save_path, resume_training=args.resume, run_name=args.run_name,
+          run_name_postfix=args.run_name_postfix, seed=args.seed)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

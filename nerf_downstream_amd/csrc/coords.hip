@@ -81,18 +81,25 @@ __global__ __launch_bounds__(kBlock) void flag_kernel(const int *__restrict__ tv
   if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-// single-workgroup exclusive scan of int32 (n up to a few 1e5); total -> *total_out
+// single-workgroup exclusive scan of int32 (n up to a few 1e5); total -> *total_out.
+// 1024 threads x 8 consecutive items per trip: wave-level shuffles scan the per-thread sums.
 __global__ __launch_bounds__(1024) void scan_kernel(const int *__restrict__ in, int *__restrict__ out, int64_t n,
                                                     int *total_out) {
+  constexpr int IT = 8;
   __shared__ int s_wave[16];
   __shared__ int s_carry;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t base = 0; base < n; base += 1024) {
-    const int64_t i = base + threadIdx.x;
-    const int v = i < n ? in[i] : 0;
-    int incl = v;
+  for (int64_t base = 0; base < n; base += 1024 * IT) {
+    const int64_t i0 = base + (int64_t)threadIdx.x * IT;
+    int v[IT], tsum = 0;
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      v[j] = (i0 + j < n) ? in[i0 + j] : 0;
+      tsum += v[j];
+    }
+    int incl = tsum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int t = __shfl_up(incl, d);
@@ -100,12 +107,23 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int *__restrict__ in, 
     }
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += s_wave[w];
-    const int carry = s_carry;
-    if (i < n) out[i] = carry + woff + incl - v;
+    int wv = lane < 16 ? s_wave[lane] : 0;  // every wave scans the 16 wave totals
+    int wincl = wv;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const int t = __shfl_up(wincl, d);
+      if (lane >= d) wincl += t;
+    }
+    const int woff = __shfl(wincl - wv, wave);
+    const int total = __shfl(wincl, 15);
+    int run = s_carry + woff + incl - tsum;
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      if (i0 + j < n) out[i0 + j] = run;
+      run += v[j];
+    }
     __syncthreads();
-    if (threadIdx.x == 1023) s_carry = carry + woff + incl;
+    if (threadIdx.x == 0) s_carry += total;
     __syncthreads();
   }
   if (threadIdx.x == 0 && total_out) *total_out = s_carry;

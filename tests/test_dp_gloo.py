@@ -1,0 +1,99 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient all-reduce used for data parallelism
+(one process per GPU; RCCL on the MI355X node, gloo here) averages the per-rank gradients,
+keeps BatchNorm statistics per rank (reference default, train.py:83) and leaves every rank with
+identical parameters after the optimizer step."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _batch(rank):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import batch_scenes
+
+    coords, feats = batch_scenes([100 + 2 * rank, 101 + 2 * rank], grid=24, cin=8)
+    return {"coordinates": coords, "features": feats, "labels": torch.tensor([rank, 1 - rank])}
+
+
+def _model():
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from oracle import me_cpu as OME
+
+    torch.manual_seed(5)
+    return get_model("ResNet14", 8, 3, ME=OME)
+
+
+def _local_grads(rank):
+    m = _model()
+    b = _batch(rank)
+    F.cross_entropy(m(m.process_input(b)), b["labels"]).backward()
+    return m, torch.cat([p.grad.flatten() for p in m.parameters()])
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerf_downstream_amd.parallel import BucketedGradAllReduce
+
+    torch.set_num_threads(2)
+    m = _model()
+    red = BucketedGradAllReduce(m, bucket_bytes=4 << 20)  # several buckets for the 14 M parameters
+    assert len(red.buckets) > 3
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
+    b = _batch(rank)
+    red.zero_grad()
+    F.cross_entropy(m(m.process_input(b)), b["labels"]).backward()
+    assert all(red._launched)  # every bucket's all-reduce was started from the backward hooks
+    red.finish()
+    g = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    opt.step()
+    w = torch.cat([p.detach().flatten() for p in m.parameters()])
+    rm = m.bn1.bn.running_mean.clone()
+    torch.save({"g": g, "w": w, "rm": rm}, f"{out}/r{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bucketed_allreduce_world2(tmp_path, oracle_maps):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["w"], r1["w"])  # ranks stay in lock-step
+    assert not torch.equal(r0["rm"], r1["rm"])  # BatchNorm statistics are per rank
+    torch.set_num_threads(2)  # same reduction order as the workers
+    g0, g1 = _local_grads(0)[1], _local_grads(1)[1]
+    ref = 0.5 * (g0 + g1)
+    assert torch.allclose(r0["g"], ref, atol=1e-4 * float(ref.abs().max()), rtol=1e-3)
+
+
+def test_flat_buffer_layout_single_process():
+    sys.path.insert(0, ROOT)
+    from nerf_downstream_amd.parallel import BucketedGradAllReduce
+
+    m = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Linear(8, 2))
+    red = BucketedGradAllReduce(m, bucket_bytes=64)
+    params = list(m.parameters())
+    assert red.flat.numel() == sum(p.numel() for p in params)
+    # reverse registration order: the last layer's gradients (ready first in backward) come first
+    assert params[-1].grad.data_ptr() == red.flat.data_ptr()
+    m(torch.randn(3, 4)).sum().backward()
+    red.finish()  # world 1: no-op
+    assert torch.equal(params[0].grad.flatten(), red.flat[-params[0].numel():])
+    red.zero_grad()
+    assert float(red.flat.abs().sum()) == 0.0

@@ -1,0 +1,138 @@
+"""CPU: the train.py surface (argparse flags, gin files, dataset schema, collate, checkpoints)
+end to end.  BASELINE config #0 ("2-class synthetic plenoxel voxels, batch=2 on the CPU path")
+runs the SAME training loop with the oracle's mini-ME injected -- the product itself has no CPU
+path and must refuse to run without a GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nerf_downstream_amd import gin_lite as gin
+
+CFG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nerf_downstream_amd", "co3d_3d", "configs")
+
+
+@pytest.fixture(autouse=True)
+def _clean_gin():
+    gin.clear_config()
+    yield
+    gin.clear_config()
+
+
+def test_gin_subset_parses_reference_style_files(tmp_path):
+    gin.parse_config_files_and_bindings([f"{CFG}/co3d_cls.gin", f"{CFG}/resnet34.gin"], ["train.gpus=8", "train.lr = 0.05"])
+    assert gin.query_parameter("get_model.name") == "ResNet34"  # later file wins
+    assert gin.query_parameter("train.lr") == 0.05  # bindings win over files
+    assert gin.query_parameter("train.loggers") == ["csv", "neptune"]
+    assert gin.query_parameter("Co3DDatasetBase.features") == ["sh"]
+    with pytest.raises(gin.GinError):
+        gin.query_parameter("train.nope")
+    ref = "/root/reference/co3d_3d/configs"
+    if os.path.isdir(ref):  # every config file of the reference parses (not available on the GPU box)
+        for f in sorted(os.listdir(ref)):
+            gin.parse_config_file(os.path.join(ref, f))
+        assert "get_model.name" in gin.query_parameter("logged.hyper_params")
+
+
+def test_cli_flags_match_reference():
+    from nerf_downstream_amd.co3d_3d.train import build_parser
+
+    a = build_parser().parse_args(["--ginc", "a.gin", "--ginc", "b.gin", "--ginb", "train.lr=1", "--gpus", "4", "--seed", "3",
+                                   "--resume", "--run_name", "r", "--run_name_postfix", "p", "--save_path", "s", "--debug"])
+    assert a.ginc == ["a.gin", "b.gin"] and a.ginb == ["train.lr=1"] and a.gpus == 4 and a.seed == 3 and a.resume and a.debug
+
+
+def test_dataset_schema_and_collate():
+    from nerf_downstream_amd.co3d_3d.src.data.synthetic import SparseVoxelDataset
+    from nerf_downstream_amd.co3d_3d.src.data.utils import collate_mink
+
+    ds = SparseVoxelDataset(phase="train", num_samples=4, num_classes=51, grid=32, features=["density", "sh"])
+    s = ds[1]
+    assert set(s) == {"coordinates", "features", "xyzs", "labels"}  # reference co3d.py:231-242
+    assert s["coordinates"].dtype == torch.float32 and s["coordinates"].shape[1] == 3
+    assert s["features"].shape == (s["coordinates"].shape[0], 28) and s["labels"].shape == (1,)
+    assert torch.equal(s["coordinates"], s["coordinates"].floor())  # integer voxel indices as floats
+    assert torch.equal(ds[1]["features"], s["features"])  # deterministic
+    b = collate_mink([ds[0], ds[1]])
+    n0 = ds[0]["coordinates"].shape[0]
+    assert b["coordinates"].dtype == torch.float32 and b["coordinates"].shape[1] == 4
+    assert torch.all(b["coordinates"][:n0, 0] == 0) and torch.all(b["coordinates"][n0:, 0] == 1)
+    assert b["labels"].dtype == torch.int64 and b["labels"].tolist() == [0, 1]
+    assert SparseVoxelDataset(features=["sh"], grid=32)[0]["features"].shape[1] == 27
+
+
+def test_co3d_npz_loader(tmp_path, monkeypatch):
+    from nerf_downstream_amd.co3d_3d.src.data.co3d import CLASSES, Co3DDataset
+
+    rng = np.random.default_rng(0)
+    links = np.sort(rng.choice(128 ** 3, 500, replace=False)).astype(np.int32)
+    scene = tmp_path / "data" / "plenoxel_co3d_sceneA"
+    scene.mkdir(parents=True)
+    sh = rng.integers(0, 255, (500, 27)).astype(np.uint8)
+    np.savez(scene / "data.npz", links=links, density=rng.random((500, 1)).astype(np.float32), sh=sh,
+             sh_min=np.float32(-2.0), sh_scale=np.float32(0.01), reso=[[128] * 3, [256] * 3])
+    (tmp_path / "filelist").mkdir()
+    (tmp_path / "filelist" / "train.txt").write_text("cup sceneA extra\n")
+    monkeypatch.chdir(tmp_path)
+    ds = Co3DDataset(phase="train", data_root=str(tmp_path / "data"), features=["density", "sh"])
+    s = ds[0]
+    c = s["coordinates"].long()
+    assert torch.equal(c[:, 0] * 128 * 128 + c[:, 1] * 128 + c[:, 2], torch.from_numpy(links).long())
+    assert s["labels"][0] == CLASSES.index("cup") and s["features"].shape == (500, 28)
+    assert torch.allclose(s["features"][:, 1:], torch.from_numpy(sh.astype(np.float32) * 0.01 - 2.0))
+
+
+def test_model_parameter_names_and_counts():
+    """State-dict layout of the reference ResNetBase and its parameter counts."""
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from oracle import me_cpu as OME
+
+    m = get_model("ResNet14", 28, 51, ME=OME)
+    keys = list(m.state_dict())
+    for k in ["conv1.kernel", "bn1.bn.weight", "bn1.bn.running_var", "bn1.bn.num_batches_tracked", "layer1.0.conv1.kernel",
+              "layer1.0.norm2.bn.bias", "layer3.0.downsample.0.kernel", "layer4.0.downsample.1.bn.running_mean",
+              "final.kernel", "final.bias"]:
+        assert k in keys, k
+    assert m.conv1.kernel.shape == (27, 28, 64) and m.layer2[0].downsample[0].kernel.shape == (1, 64, 128)
+    assert m.final.kernel.shape == (512, 51) and m.final.bias.shape == (1, 51)
+    assert sum(p.numel() for p in m.parameters()) == 14_412_339
+    m34 = get_model("ResNet34", 28, 51, ME=OME)
+    assert sum(p.numel() for p in m34.parameters()) == 63_526_451
+    assert len(m34.layer3) == 6
+
+
+def test_product_train_refuses_cpu(tmp_path):
+    from nerf_downstream_amd.co3d_3d.train import train
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    gin.parse_config_files_and_bindings([f"{CFG}/co3d_cls.gin", f"{CFG}/synthetic_2class_cpu.gin"], ["train.gpus=1", "train.max_steps=1"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        train(save_path=str(tmp_path), resume_training=False, run_name=None, run_name_postfix=None)
+
+
+def test_baseline_config0_cpu_plumbing(tmp_path):
+    """co3d_3d/train.py, Mink-ResNet14, 2-class synthetic plenoxels, batch 2, CPU oracle backend."""
+    from nerf_downstream_amd.co3d_3d.train import load_checkpoint, train
+    from oracle import me_cpu as OME
+
+    gin.parse_config_files_and_bindings(
+        [f"{CFG}/co3d_cls.gin", f"{CFG}/resnet14.gin", f"{CFG}/synthetic_2class_cpu.gin"],
+        ["train.gpus=0", "train.max_steps=4", "train.val_every_n_steps=4", "train.log_every_n_steps=1",
+         "SparseVoxelDataset.grid=24", "train.lr=0.01"],
+    )
+    res = train(save_path=str(tmp_path), resume_training=False, run_name="t", run_name_postfix=None, ME=OME)
+    assert res["global_step"] == 4
+    logged = [h for h in res["history"] if "train/loss" in h]
+    assert len(logged) == 4 and all(np.isfinite(h["train/loss"]) for h in logged)
+    val = [h for h in res["history"] if "val/acc1" in h]
+    assert len(val) == 1 and 0.0 <= val[0]["val/acc1"] <= 100.0
+    ckpt = tmp_path / "t" / "last.ckpt"
+    assert ckpt.exists() and (tmp_path / "t" / "metrics.csv").exists()
+    sd = torch.load(ckpt, weights_only=False)
+    assert all(k.startswith("model.") for k in sd["state_dict"]) and sd["global_step"] == 4
+    # resume continues from the stored step
+    gin.bind_parameter("train.max_steps", 6)
+    res2 = train(save_path=str(tmp_path), resume_training=True, run_name="t", run_name_postfix=None, ME=OME)
+    assert res2["global_step"] == 6
