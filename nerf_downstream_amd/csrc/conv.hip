@@ -50,6 +50,15 @@ __device__ __forceinline__ float4 ld4_sel(const float *base, int64_t off, bool o
   return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Same, but the zeroing is a bit mask on the loaded words: the optimiser cannot fold it back
+// into an exec-masked (branchy) load, so the load stays an unconditional, schedulable instruction.
+__device__ __forceinline__ float4 ld4_mask(const float *base, int64_t off, bool ok) {
+  const uint4 u = *reinterpret_cast<const uint4 *>(base + (ok ? off : 0));
+  const unsigned m = ok ? 0xFFFFFFFFu : 0u;
+  return make_float4(__uint_as_float(u.x & m), __uint_as_float(u.y & m), __uint_as_float(u.z & m),
+                     __uint_as_float(u.w & m));
+}
+
 // W_T = false: w[K][cin][cout];  W_T = true: w[K][cout][cin] (dgrad reads the forward kernel)
 // VEC: every operand is 16-byte aligned with channel counts that are multiples of 4.
 template <bool W_T, bool VEC>
@@ -309,59 +318,94 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
   for (int i = 0; i < 4; ++i) my_orow[i] = s_orow[a_r + 32 * i];
 
   int gk = kmask ? __builtin_ctz(kmask) : -1, gc0 = 0;  // iterator of the global-load stage
-  int idx_g[4] = {-1, -1, -1, -1};
-  auto load_idx = [&](int k) {
+  int idx_g[4] = {-1, -1, -1, -1};  // neighbour rows of the item the next gload() fetches
+  auto load_idx = [&](int k, int (&idx)[4]) {  // branch-free: k < 0 (past the end) yields -1
+    const int kq = max(k, 0);
+    const unsigned dead = k < 0 ? 0xFFFFFFFFu : 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (STAGE)
-        idx_g[i] = s_nbr[(a_r + 32 * i) * K + k];
-      else
-        idx_g[i] = my_orow[i] >= 0 ? p.nbr[(int64_t)my_orow[i] * K + k] : -1;
+      if (STAGE) {
+        idx[i] = (int)((unsigned)s_nbr[(a_r + 32 * i) * K + kq] | dead);
+      } else {
+        const unsigned v = (unsigned)p.nbr[(int64_t)max(my_orow[i], 0) * K + kq];
+        idx[i] = (int)(v | dead | (my_orow[i] < 0 ? 0xFFFFFFFFu : 0u));
+      }
     }
   };
-  float4 ga[4], gb[2];
-  auto gload = [&]() {  // item (gk, gc0) -> registers; then advance (prefetching the next indices)
-    const int kw = p.flip_k ? (K - 1 - gk) : gk;
+  // raw 16-byte words of the item in flight + validity bits; the zeroing of invalid words is
+  // deferred to sts() one iteration later, so nothing in the issuing iteration waits on vmcnt
+  uint4 ga[4] = {}, gb[2] = {};
+  unsigned g_ok = 0u;
+  auto ldraw = [&](const float *base, int64_t off, bool ok) {
+    return *reinterpret_cast<const uint4 *>(base + (ok ? off : 0));
+  };
+  auto gload = [&]() {  // fetch item (gk, gc0) into registers and step the iterator
+    // the indices of the FOLLOWING item are requested first: they have a whole iteration to
+    // arrive before the next gload() turns them into addresses
+    const int nc0 = gc0 + BK;
+    const bool wrap = nc0 >= p.cin;
+    const int gkq0 = max(gk, 0);
+    const unsigned rest = (gkq0 + 1 < 32) ? (kmask >> (gkq0 + 1)) : 0u;
+    const int nk_wrap = (gk >= 0 && rest) ? (gkq0 + 1 + __builtin_ctz(rest | 0x80000000u)) : -1;
+    const int nk = wrap ? nk_wrap : gk;
+    int idx_n[4];
+    load_idx(nk, idx_n);
+    const int gkq = max(gk, 0);
+    const int kw = p.flip_k ? (K - 1 - gkq) : gkq;
     const int c = gc0 + 4 * a_cc;
+    unsigned okb = 0u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ga[i] = ld4_sel(p.x, (int64_t)idx_g[i] * p.ldx + c, idx_g[i] >= 0 && c < p.cin);
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = idx_g[i] >= 0 && c < p.cin;
+      ga[i] = ldraw(p.x, (int64_t)idx_g[i] * p.ldx + c, ok);
+      okb |= ok ? (1u << i) : 0u;
+    }
     if (!W_T) {
       const int n = n0 + 4 * b_n4;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int kk = gc0 + b_kk + 16 * i;
-        gb[i] = ld4_sel(p.w, ((int64_t)kw * p.cin + kk) * p.cout + n, kk < p.cin && n < p.cout);
+        const bool ok = kk < p.cin && n < p.cout;
+        gb[i] = ldraw(p.w, ((int64_t)kw * p.cin + kk) * p.cout + n, ok);
+        okb |= ok ? (16u << i) : 0u;
       }
     } else {
       const int n = n0 + bt_n;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int kk = gc0 + 4 * (bt_k4 + 4 * i);
-        gb[i] = ld4_sel(p.w, ((int64_t)kw * p.cout + n) * p.cin + kk, n < p.cout && kk < p.cin);
+        const bool ok = n < p.cout && kk < p.cin;
+        gb[i] = ldraw(p.w, ((int64_t)kw * p.cout + n) * p.cin + kk, ok);
+        okb |= ok ? (16u << i) : 0u;
       }
     }
-    gc0 += BK;
-    if (gc0 >= p.cin) {
-      gc0 = 0;
-      const unsigned rest = (gk + 1 < 32) ? (kmask >> (gk + 1)) : 0u;
-      gk = rest ? (gk + 1 + __builtin_ctz(rest)) : -1;
-      if (gk >= 0) load_idx(gk);
-    }
+    g_ok = okb;
+    gc0 = wrap ? 0 : nc0;
+    gk = nk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) idx_g[i] = idx_n[i];
   };
   auto sts = [&](int buf) {
+    auto masked = [&](uint4 u, unsigned bit) {
+      const unsigned m = (g_ok & bit) ? 0xFFFFFFFFu : 0u;
+      return make_uint4(u.x & m, u.y & m, u.z & m, u.w & m);
+    };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&sA[buf][(a_r + 32 * i) * LDA + 4 * a_cc]) = ga[i];
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4 *>(&sA[buf][(a_r + 32 * i) * LDA + 4 * a_cc]) = masked(ga[i], 1u << i);
     if (!W_T) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) *reinterpret_cast<float4 *>(&sB[buf][(b_kk + 16 * i) * BN + 4 * b_n4]) = gb[i];
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<uint4 *>(&sB[buf][(b_kk + 16 * i) * BN + 4 * b_n4]) = masked(gb[i], 16u << i);
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int kk = 4 * (bt_k4 + 4 * i);
-        sB[buf][(kk + 0) * BN + bt_n] = gb[i].x;
-        sB[buf][(kk + 1) * BN + bt_n] = gb[i].y;
-        sB[buf][(kk + 2) * BN + bt_n] = gb[i].z;
-        sB[buf][(kk + 3) * BN + bt_n] = gb[i].w;
+        const uint4 u = masked(gb[i], 16u << i);
+        sB[buf][(kk + 0) * BN + bt_n] = __uint_as_float(u.x);
+        sB[buf][(kk + 1) * BN + bt_n] = __uint_as_float(u.y);
+        sB[buf][(kk + 2) * BN + bt_n] = __uint_as_float(u.z);
+        sB[buf][(kk + 3) * BN + bt_n] = __uint_as_float(u.w);
       }
     }
   };
@@ -395,10 +439,10 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
     }
   };
 
-  Ops R0, R1;
+  Ops R0 = {}, R1 = {};
   // ---- prologue: items 0,1 -> LDS, item 2 in flight, operands of item 0 in registers
   if (n_items > 0) {
-    load_idx(gk);
+    load_idx(gk, idx_g);
     gload();
     sts(0);
   }
@@ -411,20 +455,47 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
   if (n_items > 0) lds_read(0, R0);
   MINK_LDS_BARRIER();
 
-  auto body = [&](int c, const Ops &cur, Ops &nxt) {
-    if (c + 1 < n_items) lds_read((c + 1) & 1, nxt);
-    __builtin_amdgcn_sched_barrier(0);
+  // steady state (all three stages active, no branch inside): one scheduling region holding the
+  // operand reads of item c+1, the 32 MFMAs of item c, the LDS stores of item c+2 and the global
+  // loads of item c+3; the group barriers ask the scheduler to slot the memory / address
+  // instructions between the 64-cycle MFMAs instead of clustering them.
+  auto body_full = [&](int c, const Ops &cur, Ops &nxt) {
+    sts(c & 1);  // item c+2 replaces item c (every wave read it during the previous iteration)
+    gload();     // item c+3: in flight until the sts of the next iteration
+    lds_read((c + 1) & 1, nxt);
     mfma_half(cur, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + 2 < n_items) sts(c & 1);  // item c+2 replaces item c (every wave read it last iteration)
-    if (c + 3 < n_items) gload();
-    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(cur, 2);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
+      __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);  // VALU / SALU
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one VMEM read
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // one DS write
+    }
+    MINK_LDS_BARRIER();
+  };
+  auto body_tail = [&](int c, const Ops &cur, Ops &nxt) {  // last three items: stages drain
+    if (c + 1 < n_items) lds_read((c + 1) & 1, nxt);
+    mfma_half(cur, 0);
+    if (c + 2 < n_items) sts(c & 1);
     mfma_half(cur, 2);
     MINK_LDS_BARRIER();
   };
-  for (int c = 0; c < n_items; c += 2) {
-    body(c, R0, R1);
-    if (c + 1 < n_items) body(c + 1, R1, R0);
+  int c = 0;
+  for (; c + 3 < n_items; c += 2) {
+    body_full(c, R0, R1);
+    if (c + 4 < n_items) {
+      body_full(c + 1, R1, R0);
+    } else {
+      body_tail(c + 1, R1, R0);
+      c += 2;
+      break;
+    }
+  }
+  for (; c < n_items; c += 2) {
+    body_tail(c, R0, R1);
+    if (c + 1 < n_items) body_tail(c + 1, R1, R0);
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

@@ -1,0 +1,79 @@
+// Micro-benchmark: sustained v_mfma_f32_32x32x2_f32 rate (register operands vs LDS-fed operands).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int MODE>  // 0: register operands; 1: operands re-read from LDS every step (ds_read_b32)
+__global__ __launch_bounds__(256) void k(float *out, int iters) {
+  __shared__ float sA[128 * 36];
+  __shared__ float sB[32 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 128 * 36; i += 256) sA[i] = (float)(i % 7) * 0.01f;
+  for (int i = tid; i < 32 * 64; i += 256) sB[i] = (float)(i % 5) * 0.01f;
+  __syncthreads();
+  f32x16 acc0 = {0}, acc1 = {0};
+  float a = lane * 0.001f, b = 0.5f;
+  const int arow = wave * 32 + (lane & 31), h = lane >> 5, col = lane & 31;
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
+      }
+    } else {
+      float4 av[4];
+      float b0[16], b1[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) av[t] = *reinterpret_cast<const float4 *>(&sA[arow * 36 + 8 * t + 4 * h]);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int kk = 8 * (t >> 2) + 4 * h + (t & 3);
+        b0[t] = sB[kk * 64 + col];
+        b1[t] = sB[kk * 64 + 32 + col];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float a4[4] = {av[t].x, av[t].y, av[t].z, av[t].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b0[4 * t + j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b1[4 * t + j], acc1, 0, 0, 0);
+        }
+      }
+      if (MODE == 2) __syncthreads();
+    }
+  }
+  float s = 0;
+  for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int MODE>
+void run(const char *name, int blocks, int iters) {
+  float *out;
+  hipMalloc(&out, blocks * 256 * 4);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0), hipEventCreate(&e1);
+  k<MODE><<<blocks, 256>>>(out, iters);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k<MODE><<<blocks, 256>>>(out, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double flops = (double)blocks * 4 * iters * 32 * 4096.0;
+  printf("%-34s blocks=%5d iters=%d  %.3f ms  %.1f TFLOP/s\n", name, blocks, iters, ms, flops / ms / 1e9);
+  hipFree(out);
+}
+
+int main() {
+  for (int bpc : {1, 2, 3}) {
+    run<0>("register operands", 256 * bpc, 2000);
+    run<1>("LDS-fed operands", 256 * bpc, 2000);
+    run<2>("LDS-fed + barrier per 32 MFMA", 256 * bpc, 2000);
+  }
+  return 0;
+}
