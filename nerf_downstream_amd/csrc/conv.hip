@@ -264,7 +264,10 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
 // otherwise indices are read straight from the table one offset ahead.
 #define MINK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <bool W_T, bool STAGE>
+// FLAT > 0 (== cin, not a multiple of 32; forward weights only): the reduction runs over the
+// flattened (offset, channel) axis K*cin in 32-wide items that may straddle two offsets, so no
+// MFMA step is spent on channel padding (stem: 756 = 27*28 -> 24 items instead of 27).
+template <bool W_T, bool STAGE, int FLAT>
 __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float sA[2][BM * LDA];
   __shared__ __attribute__((aligned(16))) float sB[2][BK * BN];
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
     kmask &= s_kmask;
   }
   const int ncc = (p.cin + BK - 1) / BK;
-  const int n_items = __popc(kmask) * ncc;
+  const int n_items = FLAT ? (K * FLAT + BK - 1) / BK : __popc(kmask) * ncc;
 
   // per-thread staging coordinates
   const int a_cc = tid & 7, a_r = tid >> 3;     // A: rows a_r + 32 i, float4 column a_cc
@@ -339,7 +342,48 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
   auto ldraw = [&](const float *base, int64_t off, bool ok) {
     return *reinterpret_cast<const uint4 *>(base + (ok ? off : 0));
   };
+  int gj = 0;  // FLAT: item counter of the global-load stage
+  auto flat_idx = [&](int j, int (&idx)[4]) {  // neighbour rows for flat item j (per-thread offset)
+    const int off = (BK * j + 4 * a_cc) / (FLAT ? FLAT : 1);
+    const int offq = min(off, K - 1);
+    const unsigned dead = off >= K ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned v = (unsigned)p.nbr[(int64_t)max(my_orow[i], 0) * K + offq];
+      idx[i] = (int)(v | dead | (my_orow[i] < 0 ? 0xFFFFFFFFu : 0u));
+    }
+  };
+  auto gload_flat = [&]() {
+    int idx_n[4];
+    flat_idx(gj + 1, idx_n);
+    const int kf = BK * gj + 4 * a_cc;
+    const int off = kf / (FLAT ? FLAT : 1);
+    const int ch = kf - off * FLAT;
+    unsigned okb = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = idx_g[i] >= 0;
+      ga[i] = ldraw(p.x, (int64_t)idx_g[i] * p.ldx + ch, ok);
+      okb |= ok ? (1u << i) : 0u;
+    }
+    const int n = n0 + 4 * b_n4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kk = BK * gj + b_kk + 16 * i;  // row of the flattened [K*cin][cout] weight matrix
+      const bool ok = kk < K * FLAT && n < p.cout;
+      gb[i] = ldraw(p.w, (int64_t)kk * p.cout + n, ok);
+      okb |= ok ? (16u << i) : 0u;
+    }
+    g_ok = okb;
+    ++gj;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) idx_g[i] = idx_n[i];
+  };
   auto gload = [&]() {  // fetch item (gk, gc0) into registers and step the iterator
+    if (FLAT) {
+      gload_flat();
+      return;
+    }
     // the indices of the FOLLOWING item are requested first: they have a whole iteration to
     // arrive before the next gload() turns them into addresses
     const int nc0 = gc0 + BK;
@@ -442,7 +486,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
   Ops R0 = {}, R1 = {};
   // ---- prologue: items 0,1 -> LDS, item 2 in flight, operands of item 0 in registers
   if (n_items > 0) {
-    load_idx(gk, idx_g);
+    if (FLAT) flat_idx(0, idx_g);
+    else load_idx(gk, idx_g);
     gload();
     sts(0);
   }
@@ -886,6 +931,7 @@ using namespace mink;
 
 static int g_stagger = 0;
 static int g_pipeline = 1;
+static int g_flat = 1;
 static int g_use_direct = 0;  // measured slower than the LDS-staged kernel (B operand traffic)
 
 extern "C" {
@@ -901,6 +947,7 @@ int mink_conv_set_stagger(int units) {
   const int old = g_stagger;
   g_stagger = units & 255;
   g_pipeline = !(units & 256);  // bit 8: fall back to the un-pipelined kernel (A/B benchmarks)
+  g_flat = !(units & 512);      // bit 9: no flattened-K stem path
   return old;
 }
 
@@ -949,10 +996,11 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
     const bool vec = al && (w_transposed ? true : (cout & 3) == 0);
     const bool stage = row_perm != nullptr;
     if (vec && g_pipeline) {
-      if (w_transposed && stage) gather_gemm2_kernel<true, true><<<grid, 256, 0, st>>>(p);
-      else if (w_transposed) gather_gemm2_kernel<true, false><<<grid, 256, 0, st>>>(p);
-      else if (stage) gather_gemm2_kernel<false, true><<<grid, 256, 0, st>>>(p);
-      else gather_gemm2_kernel<false, false><<<grid, 256, 0, st>>>(p);
+      if (w_transposed && stage) gather_gemm2_kernel<true, true, 0><<<grid, 256, 0, st>>>(p);
+      else if (w_transposed) gather_gemm2_kernel<true, false, 0><<<grid, 256, 0, st>>>(p);
+      else if (stage) gather_gemm2_kernel<false, true, 0><<<grid, 256, 0, st>>>(p);
+      else if (cin == 28 && zs == 1 && !flip_k && g_flat) gather_gemm2_kernel<false, false, 28><<<grid, 256, 0, st>>>(p);
+      else gather_gemm2_kernel<false, false, 0><<<grid, 256, 0, st>>>(p);
     } else if (w_transposed && vec) gather_gemm_kernel<true, true><<<grid, 256, 0, st>>>(p);
     else if (w_transposed) gather_gemm_kernel<true, false><<<grid, 256, 0, st>>>(p);
     else if (vec) gather_gemm_kernel<false, true><<<grid, 256, 0, st>>>(p);
