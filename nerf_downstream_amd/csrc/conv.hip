@@ -705,7 +705,7 @@ struct WgradParams {
   const int *nbr;
   float *out;  // dw (nsplit == 1) or workspace [nsplit][K][cin][cout]
   int64_t n_out, rows_per_split;
-  int ldx, cin, ldy, cout, K, ct_tiles, ngroups;
+  int ldx, cin, ldy, cout, K, ct_tiles, ngroups, ablate;
 };
 
 // G: offsets per workgroup.  NARROW: cin <= 32 -- the x tile is 32 floats wide and the two
@@ -746,8 +746,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = (f32x16){0};
 
-  float4 rx[XNI];
+  float4 rx[XNI] = {};
   auto gather = [&](int g) {  // x rows of the compacted pairs of offset g -> registers
+    if (p.ablate & 64) return;
     const int m = s_cnt[2 * g] + s_cnt[2 * g + 1];
     const int mpad = (m + 15) & ~15;
 #pragma unroll
@@ -832,6 +833,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       const float *db = sD + 32 * wn + col;
       const int sbeg = NARROW ? wa * (nsteps >> 1) : 0;
       const int send = NARROW ? sbeg + (nsteps >> 1) : nsteps;
+      if (!(p.ablate & 128))
       for (int s = sbeg; s < send; s += 4) {  // 4 MFMAs per trip, all operands loaded up front
         const int4 ro = *reinterpret_cast<const int4 *>(lrow + s);
         const float a0 = xa[(s + 0) * XLD], a1 = xa[(s + 1) * XLD], a2 = xa[(s + 2) * XLD], a3 = xa[(s + 3) * XLD];
@@ -880,13 +882,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   }
 }
 
+// out[i] = sum_z ws[z][i]: 64 outputs x 4 slab lanes per workgroup (fixed order -> deterministic)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ ws, int64_t count, int nslab,
                                                           float *__restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
+  __shared__ float s_part[4][64];
+  const int lane = threadIdx.x >> 6, o = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 64 + o;
   float s = 0.f;
-  for (int z = 0; z < nslab; ++z) s += ws[(int64_t)z * count + i];
-  out[i] = s;
+  if (i < count)
+    for (int z = lane; z < nslab; z += 4) s += ws[(int64_t)z * count + i];
+  s_part[lane][o] = s;
+  __syncthreads();
+  if (lane == 0 && i < count) out[i] = (s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o]);
 }
 
 struct WgradPlan {
@@ -904,7 +911,7 @@ static WgradPlan wgrad_plan(int64_t n_out, int K, int cin, int cout) {
   else if (K >= 3 && tiles * cdiv(K, 3) * row_tiles >= 1024) pl.G = 3;
   pl.ngroups = (int)cdiv(K, pl.G);
   const int64_t xy = tiles * pl.ngroups;
-  int64_t z = cdiv(1024, xy);
+  int64_t z = cdiv(512, xy);  // ~2 resident workgroups per CU: fewer partial slabs to write and reduce
   if (z > row_tiles) z = row_tiles;
   if (z < 1) z = 1;
   pl.rows_per_split = align_up(cdiv(n_out, z), WROWS);
@@ -1038,6 +1045,7 @@ int mink_conv_wgrad(const float *x, int32_t ldx, int32_t cin, const float *dy, i
   p.n_out = n_out, p.rows_per_split = pl.rows_per_split, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K;
   p.ct_tiles = (int)cdiv(cout, WT);
   p.ngroups = pl.ngroups;
+  p.ablate = g_stagger;
   const dim3 grid((unsigned)(pl.ngroups * cdiv(cin, WT) * p.ct_tiles), (unsigned)pl.nsplit);
   if (pl.G == 9) launch_wgrad<9>(p, grid, st);
   else if (pl.G == 3) launch_wgrad<3>(p, grid, st);
@@ -1045,7 +1053,7 @@ int mink_conv_wgrad(const float *x, int32_t ldx, int32_t cin, const float *dy, i
   MINK_CHECK_LAUNCH();
   if (pl.nsplit > 1) {
     const int64_t count = (int64_t)K * cin * cout;
-    slab_reduce_kernel<<<dim3((unsigned)cdiv(count, 256)), 256, 0, st>>>((const float *)workspace, count, pl.nsplit, dw);
+    slab_reduce_kernel<<<dim3((unsigned)cdiv(count, 64)), 256, 0, st>>>((const float *)workspace, count, pl.nsplit, dw);
     MINK_CHECK_LAUNCH();
   }
   return MINK_OK;

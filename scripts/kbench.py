@@ -53,6 +53,16 @@ if which == "stagger":
         lib().mink_conv_set_stagger(st)
         t = timeit(lambda: Fn.gather_gemm(xin, w, nbr, 64), reps)
         print(f"stagger {st}: stem fwd {t*1e3:8.1f} us")
+if which == "wablate":
+    from nerf_downstream_amd._lib import lib
+    nbr, _ = m.kernel_table(k1, k1, 3, 1)
+    xin = x.F.contiguous()
+    gy = torch.randn(nbr.shape[0], 64, device=dev)
+    for st in (0, 0, 64, 128, 192, 0):
+        lib().mink_conv_set_stagger(st)
+        t = timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64)), reps)
+        print(f"ablate {st}: stem wgrad {t*1e3:8.1f} us")
+    lib().mink_conv_set_stagger(0)
 if which in ("stem", "all"):
     bench_layer("stem", x.F.contiguous(), k1, k1, 3, 28, 64, 1)
 if which in ("l1", "l4", "all"):
