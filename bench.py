@@ -76,6 +76,28 @@ def cpu_baseline(model_name, cin, num_classes, grid, state_dict, seconds_budget=
     }
 
 
+def pmc_traffic(tag, meta):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary
+    (profiles/*_pmc.json, produced by scripts/pmc_summary.py from separate rocprofv3 --pmc
+    passes; 2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md).  None if no matching entry."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None
+    want = "wgrad_kernel" if tag.startswith("wgrad") else "gather_gemm2_kernel"
+    best = None
+    for e in json.load(open(files[-1])):
+        if want in e["kernel"] and "hbm_traffic_bytes_per_launch" in e:
+            if tag.startswith("wgrad") and meta["cin"] <= 32 and "<9, true" not in e["kernel"]:
+                continue
+            if not tag.startswith("wgrad") and e["workgroups"] != -(-meta["n_out"] // 128):
+                continue
+            if best is None or e["hbm_traffic_bytes_per_launch"] > best:
+                best = e["hbm_traffic_bytes_per_launch"]
+    return best
+
+
 def roofline_from_timings(timings):
     """Dominant conv kernel of the timed region: achieved = algorithmic FLOPs per launch
     (2 * pairs * Cin * Cout, pairs = valid neighbour-table entries) / mean HIP-event duration."""
@@ -102,7 +124,7 @@ def roofline_from_timings(timings):
         "peak": MFMA_F32_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-        "traffic": None,
+        "traffic": pmc_traffic(tag, meta),
         "avg_ms": avg_ms,
         "launches": len(ms),
         "flops_per_launch": flops,
