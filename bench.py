@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--in-channel", type=int, default=28)
     ap.add_argument("--num-classes", type=int, default=51)
+    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16", "bf16x3"],
+                    help="matrix-core arithmetic of conv forward/dgrad (fp32 = exact, the headline; bf16 = BASELINE config #3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -165,6 +167,7 @@ def main():
     from nerf_downstream_amd.parallel import BucketedGradAllReduce
 
     _lib.lib()  # fail loudly if the HIP backend is missing
+    Fn.set_conv_math(args.math)
 
     torch.manual_seed(777)  # same initial weights on every rank (reference: pl.seed_everything)
     model = get_model(args.model, args.in_channel, args.num_classes).to(dev)
@@ -247,7 +250,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": {"fp32": "f32", "bf16": "bf16 (MFMA operands; fp32 accumulate, storage and wgrad)",
+                      "bf16x3": "f32 via split-bf16 MFMA (3 products)"}[args.math],
             "data": "synthetic",
             "config": {
                 "workload": f"Mink-{args.model} full CO3D-category classification ({args.num_classes} classes), "

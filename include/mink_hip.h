@@ -165,6 +165,11 @@ int mink_conv_set_direct(int on);
 /* Tuning knob: start-up stagger (units of 1024 clocks per phase) between workgroups that share a
  * CU in the gather-GEMM; 0 = off.  Returns the previous value. */
 int mink_conv_set_stagger(int units);
+/* Matrix-core arithmetic of mink_conv_gather_gemm (forward / input gradient):
+ *   0 = exact fp32 MFMA (default), 1 = bf16 operands with fp32 accumulation (BASELINE config
+ *   "bf16 mixed precision"), 3 = split-bf16 (hi/lo, three products; ~1e-5 relative).
+ * HBM tensors stay fp32 in every mode.  Returns the previous mode. */
+int mink_conv_set_math(int mode);
 /* Split-K factor the library recommends for a layer (1 for large row counts). */
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout);
 int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,

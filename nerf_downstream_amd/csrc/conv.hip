@@ -6,6 +6,8 @@
 // Both are implicit GEMMs over the neighbour table, accumulated in registers by
 // v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD), with no atomics: every output
 // element has exactly one owner, so results are bitwise reproducible run to run.
+#include <type_traits>
+
 #include "common.h"
 
 namespace mink {
@@ -267,10 +269,30 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
 // FLAT > 0 (== cin, not a multiple of 32; forward weights only): the reduction runs over the
 // flattened (offset, channel) axis K*cin in 32-wide items that may straddle two offsets, so no
 // MFMA step is spent on channel padding (stem: 756 = 27*28 -> 24 items instead of 27).
-template <bool W_T, bool STAGE, int FLAT>
+// MATH: 0 = exact fp32 (v_mfma_f32_32x32x2_f32); 1 = bf16 operands, fp32 accumulate
+// (v_mfma_f32_32x32x16_bf16, 16x the matrix rate; BASELINE config "bf16 mixed precision");
+// 3 = split-bf16: x = hi + lo, products hi*hi + hi*lo + lo*hi (~2^-17 relative per product).
+// The tiles are converted when they are stored to LDS; HBM tensors stay fp32.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr int LD16 = BK + 8;  // bf16 LDS row stride (80 bytes): conflict-free ds_read_b128
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) |
+         ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+__device__ __forceinline__ float bf16_residual(float a) { return a - (float)(__bf16)a; }
+
+template <bool W_T, bool STAGE, int FLAT, int MATH>
 __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) float sA[2][BM * LDA];
-  __shared__ __attribute__((aligned(16))) float sB[2][BK * BN];
+  constexpr int NP = MATH == 3 ? 2 : 1;  // bf16 planes (hi, lo)
+  constexpr int A_BYTES = MATH == 0 ? BM * LDA * 4 : NP * BM * LD16 * 2;
+  constexpr int B_BYTES = MATH == 0 ? BK * BN * 4 : NP * BN * LD16 * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char s_a_raw[2][A_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char s_b_raw[2][B_BYTES];
+  auto sA = [&](int buf) { return reinterpret_cast<float *>(s_a_raw[buf]); };
+  auto sB = [&](int buf) { return reinterpret_cast<float *>(s_b_raw[buf]); };
+  auto sA16 = [&](int buf, int pl) { return reinterpret_cast<unsigned short *>(s_a_raw[buf]) + pl * BM * LD16; };
+  auto sB16 = [&](int buf, int pl) { return reinterpret_cast<unsigned short *>(s_b_raw[buf]) + pl * BN * LD16; };
   __shared__ int s_nbr[STAGE ? BM * KMAX : 1];
   __shared__ int s_orow[BM];
   __shared__ unsigned s_kmask;
@@ -434,56 +456,123 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
       const unsigned m = (g_ok & bit) ? 0xFFFFFFFFu : 0u;
       return make_uint4(u.x & m, u.y & m, u.z & m, u.w & m);
     };
+    if (MATH == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4 *>(&sA[buf][(a_r + 32 * i) * LDA + 4 * a_cc]) = masked(ga[i], 1u << i);
-    if (!W_T) {
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<uint4 *>(&sA(buf)[(a_r + 32 * i) * LDA + 4 * a_cc]) = masked(ga[i], 1u << i);
+      if (!W_T) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        *reinterpret_cast<uint4 *>(&sB[buf][(b_kk + 16 * i) * BN + 4 * b_n4]) = masked(gb[i], 16u << i);
-    } else {
+        for (int i = 0; i < 2; ++i)
+          *reinterpret_cast<uint4 *>(&sB(buf)[(b_kk + 16 * i) * BN + 4 * b_n4]) = masked(gb[i], 16u << i);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int kk = 4 * (bt_k4 + 4 * i);
+          const uint4 u = masked(gb[i], 16u << i);
+          sB(buf)[(kk + 0) * BN + bt_n] = __uint_as_float(u.x);
+          sB(buf)[(kk + 1) * BN + bt_n] = __uint_as_float(u.y);
+          sB(buf)[(kk + 2) * BN + bt_n] = __uint_as_float(u.z);
+          sB(buf)[(kk + 3) * BN + bt_n] = __uint_as_float(u.w);
+        }
+      }
+    } else {  // convert to bf16 (and the residual plane for split-bf16) on the way into LDS
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 u = masked(ga[i], 1u << i);
+        float f[4] = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          *reinterpret_cast<uint2 *>(&sA16(buf, pl)[(a_r + 32 * i) * LD16 + 4 * a_cc]) =
+              make_uint2(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = bf16_residual(f[e]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int kk = 4 * (bt_k4 + 4 * i);
         const uint4 u = masked(gb[i], 16u << i);
-        sB[buf][(kk + 0) * BN + bt_n] = __uint_as_float(u.x);
-        sB[buf][(kk + 1) * BN + bt_n] = __uint_as_float(u.y);
-        sB[buf][(kk + 2) * BN + bt_n] = __uint_as_float(u.z);
-        sB[buf][(kk + 3) * BN + bt_n] = __uint_as_float(u.w);
+        float f[4] = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          if (!W_T) {  // 4 consecutive columns of one k row -> transposed [col][k] image
+            const int kk = b_kk + 16 * i;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              sB16(buf, pl)[(4 * b_n4 + e) * LD16 + kk] = __builtin_bit_cast(unsigned short, (__bf16)f[e]);
+          } else {  // 4 consecutive k of one column
+            *reinterpret_cast<uint2 *>(&sB16(buf, pl)[bt_n * LD16 + 4 * (bt_k4 + 4 * i)]) =
+                make_uint2(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]));
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = bf16_residual(f[e]);
+        }
       }
     }
   };
   const int arow = wave * 32 + (lane & 31), h = lane >> 5, col = lane & 31;
-  struct Ops {
+  struct Ops {  // MATH 0: fp32 fragments; else: bf16x8 fragments (as uint4) per plane and k-step
     float4 a[4];
     float b0[16], b1[16];
   };
-  auto lds_read = [&](int buf, Ops &r) {
+  struct Ops16 {
+    uint4 a[NP][2], b0[NP][2], b1[NP][2];
+  };
+  using OpsT = typename std::conditional<MATH == 0, Ops, Ops16>::type;
+  auto lds_read = [&](int buf, OpsT &rr) {
+    if constexpr (MATH == 0) {
+      Ops &r = rr;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) r.a[t] = *reinterpret_cast<const float4 *>(&sA[buf][arow * LDA + 8 * t + 4 * h]);
+      for (int t = 0; t < 4; ++t) r.a[t] = *reinterpret_cast<const float4 *>(&sA(buf)[arow * LDA + 8 * t + 4 * h]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kk = 8 * t + 4 * h + j;
-        r.b0[4 * t + j] = sB[buf][kk * BN + col];
-        r.b1[4 * t + j] = sB[buf][kk * BN + 32 + col];
-      }
+        for (int j = 0; j < 4; ++j) {
+          const int kk = 8 * t + 4 * h + j;
+          r.b0[4 * t + j] = sB(buf)[kk * BN + col];
+          r.b1[4 * t + j] = sB(buf)[kk * BN + 32 + col];
+        }
+    } else {
+      Ops16 &r = rr;
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          r.a[pl][t] = *reinterpret_cast<const uint4 *>(&sA16(buf, pl)[arow * LD16 + 16 * t + 8 * h]);
+          r.b0[pl][t] = *reinterpret_cast<const uint4 *>(&sB16(buf, pl)[col * LD16 + 16 * t + 8 * h]);
+          r.b1[pl][t] = *reinterpret_cast<const uint4 *>(&sB16(buf, pl)[(col + 32) * LD16 + 16 * t + 8 * h]);
+        }
+    }
   };
   f32x16 acc0 = {0}, acc1 = {0};
-  auto mfma_half = [&](const Ops &r, int t0) {
+  auto mfma_half = [&](const OpsT &rr, int t0) {
+    if constexpr (MATH == 0) {
+      const Ops &r = rr;
 #pragma unroll
-    for (int t = t0; t < t0 + 2; ++t) {
-      const float a4[4] = {r.a[t].x, r.a[t].y, r.a[t].z, r.a[t].w};
+      for (int t = t0; t < t0 + 2; ++t) {
+        const float a4[4] = {r.a[t].x, r.a[t].y, r.a[t].z, r.a[t].w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], r.b0[4 * t + j], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], r.b1[4 * t + j], acc1, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], r.b0[4 * t + j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], r.b1[4 * t + j], acc1, 0, 0, 0);
+        }
       }
+    } else {
+      const Ops16 &r = rr;
+      const int t = t0 >> 1;  // halves 0 / 2 -> k-steps 0 / 1 (16 channels each)
+      auto fr = [](uint4 u) { return __builtin_bit_cast(bf16x8, u); };
+      // smallest terms first (split-bf16): lo*hi + hi*lo, then hi*hi
+      if (MATH == 3) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr(r.a[NP - 1][t]), fr(r.b0[0][t]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr(r.a[NP - 1][t]), fr(r.b1[0][t]), acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr(r.a[0][t]), fr(r.b0[NP - 1][t]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr(r.a[0][t]), fr(r.b1[NP - 1][t]), acc1, 0, 0, 0);
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr(r.a[0][t]), fr(r.b0[0][t]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr(r.a[0][t]), fr(r.b1[0][t]), acc1, 0, 0, 0);
     }
   };
 
-  Ops R0 = {}, R1 = {};
+  OpsT R0 = {}, R1 = {};
   // ---- prologue: items 0,1 -> LDS, item 2 in flight, operands of item 0 in registers
   if (n_items > 0) {
     if (FLAT) flat_idx(0, idx_g);
@@ -504,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
   // operand reads of item c+1, the 32 MFMAs of item c, the LDS stores of item c+2 and the global
   // loads of item c+3; the group barriers ask the scheduler to slot the memory / address
   // instructions between the 64-cycle MFMAs instead of clustering them.
-  auto body_full = [&](int c, const Ops &cur, Ops &nxt) {
+  auto body_full = [&](int c, const OpsT &cur, OpsT &nxt) {
     sts(c & 1);  // item c+2 replaces item c (every wave read it during the previous iteration)
     gload();     // item c+3: in flight until the sts of the next iteration
     lds_read((c + 1) & 1, nxt);
@@ -520,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
     }
     MINK_LDS_BARRIER();
   };
-  auto body_tail = [&](int c, const Ops &cur, Ops &nxt) {  // last three items: stages drain
+  auto body_tail = [&](int c, const OpsT &cur, OpsT &nxt) {  // last three items: stages drain
     if (c + 1 < n_items) lds_read((c + 1) & 1, nxt);
     mfma_half(cur, 0);
     if (c + 2 < n_items) sts(c & 1);
@@ -939,6 +1028,7 @@ using namespace mink;
 static int g_stagger = 0;
 static int g_pipeline = 1;
 static int g_flat = 1;
+static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
 static int g_use_direct = 0;  // measured slower than the LDS-staged kernel (B operand traffic)
 
 extern "C" {
@@ -955,6 +1045,12 @@ int mink_conv_set_stagger(int units) {
   g_stagger = units & 255;
   g_pipeline = !(units & 256);  // bit 8: fall back to the un-pipelined kernel (A/B benchmarks)
   g_flat = !(units & 512);      // bit 9: no flattened-K stem path
+  return old;
+}
+
+int mink_conv_set_math(int mode) {
+  const int old = g_math;
+  if (mode == 0 || mode == 1 || mode == 3) g_math = mode;
   return old;
 }
 
@@ -1003,11 +1099,19 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
     const bool vec = al && (w_transposed ? true : (cout & 3) == 0);
     const bool stage = row_perm != nullptr;
     if (vec && g_pipeline) {
-      if (w_transposed && stage) gather_gemm2_kernel<true, true, 0><<<grid, 256, 0, st>>>(p);
-      else if (w_transposed) gather_gemm2_kernel<true, false, 0><<<grid, 256, 0, st>>>(p);
-      else if (stage) gather_gemm2_kernel<false, true, 0><<<grid, 256, 0, st>>>(p);
-      else if (cin == 28 && zs == 1 && !flip_k && g_flat) gather_gemm2_kernel<false, false, 28><<<grid, 256, 0, st>>>(p);
-      else gather_gemm2_kernel<false, false, 0><<<grid, 256, 0, st>>>(p);
+      const bool flat = cin == 28 && zs == 1 && !flip_k && !w_transposed && !stage && g_flat;
+#define MINK_LAUNCH_GG2(M)                                                                          \
+  do {                                                                                              \
+    if (w_transposed && stage) gather_gemm2_kernel<true, true, 0, M><<<grid, 256, 0, st>>>(p);      \
+    else if (w_transposed) gather_gemm2_kernel<true, false, 0, M><<<grid, 256, 0, st>>>(p);         \
+    else if (stage) gather_gemm2_kernel<false, true, 0, M><<<grid, 256, 0, st>>>(p);                \
+    else if (flat) gather_gemm2_kernel<false, false, 28, M><<<grid, 256, 0, st>>>(p);               \
+    else gather_gemm2_kernel<false, false, 0, M><<<grid, 256, 0, st>>>(p);                          \
+  } while (0)
+      if (g_math == 1) MINK_LAUNCH_GG2(1);
+      else if (g_math == 3) MINK_LAUNCH_GG2(3);
+      else MINK_LAUNCH_GG2(0);
+#undef MINK_LAUNCH_GG2
     } else if (w_transposed && vec) gather_gemm_kernel<true, true><<<grid, 256, 0, st>>>(p);
     else if (w_transposed) gather_gemm_kernel<true, false><<<grid, 256, 0, st>>>(p);
     else if (vec) gather_gemm_kernel<false, true><<<grid, 256, 0, st>>>(p);

@@ -12,6 +12,7 @@ from .modules import (  # noqa: F401
     MinkowskiSumPooling,
     MinkowskiSyncBatchNorm,
 )
+from .functional import set_conv_math  # noqa: F401
 from .tensor import SparseTensor, TensorField  # noqa: F401
 
 BACKEND = "hip-gfx950"

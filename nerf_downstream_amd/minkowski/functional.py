@@ -26,6 +26,21 @@ def _bytes(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# ------------------------------------------------------------------- matrix-core math
+_MATH = {"fp32": 0, "f32": 0, "bf16": 1, "bf16x3": 3}
+
+
+def set_conv_math(mode="fp32"):
+    """Arithmetic of the convolution forward / input-gradient GEMMs: "fp32" (exact, default),
+    "bf16" (bf16 MFMA operands, fp32 accumulate -- BASELINE config "bf16 mixed precision") or
+    "bf16x3" (split-bf16, three products per step).  Tensors in HBM stay fp32; the weight
+    gradient always runs in exact fp32.  Returns the previous mode name."""
+    if mode not in _MATH:
+        raise ValueError(f"conv math {mode!r}: choose from {sorted(set(_MATH))}")
+    old = lib().mink_conv_set_math(_MATH[mode])
+    return {0: "fp32", 1: "bf16", 3: "bf16x3"}[old]
+
+
 # ---------------------------------------------------------------------- kernel timing
 # bench.py measures the dominant kernel live with HIP events recorded on the launch stream.
 # HIP event records are not free on this stack (each one is a barrier packet that drains the

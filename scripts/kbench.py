@@ -9,6 +9,9 @@ from nerf_downstream_amd.minkowski import functional as Fn
 
 which = sys.argv[1] if len(sys.argv) > 1 else "stem"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+if len(sys.argv) > 3:
+    ME.set_conv_math(sys.argv[3])
+    print("conv math:", sys.argv[3])
 dev = torch.device("cuda", 0)
 b = make_batches(1, 16, 0, 51, 128, 28)[0]
 tf = ME.TensorField(coordinates=b["coordinates"].to(dev), features=b["features"].to(dev))

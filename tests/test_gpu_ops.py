@@ -156,3 +156,32 @@ def test_field_to_sparse_average(oracle_maps):
     assert x.F.shape[0] < len(rep)
     assert np.array_equal(x.C.cpu().numpy(), ox.C.numpy())
     assert torch.allclose(x.F.cpu(), ox.F, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16", 3e-2), ("bf16x3", 2e-4)])
+@pytest.mark.parametrize("cin,cout,stride,ts", [(28, 64, 1, 1), (64, 128, 2, 2), (128, 128, 1, 4)])
+def test_convolution_reduced_math(oracle_maps, mode, tol, cin, cout, stride, ts):
+    """bf16 MFMA (BASELINE config "bf16 mixed precision") and split-bf16 modes of the forward /
+    input-gradient GEMMs against the fp32 oracle; tolerance relative to the output scale."""
+    torch.manual_seed(2)
+    ME, OME, tf, otf = _pair([3, 4], 24, cin, negative=True)
+    x, ox = _to_ts(ME, tf.sparse(), ts), _to_ts(OME, otf.sparse(), ts)
+    oconv = OME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=stride, dimension=3)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=stride, dimension=3).cuda()
+    conv.load_state_dict(oconv.state_dict())
+    F_g = x.F.detach().clone().requires_grad_(True)
+    F_c = ox.F.detach().clone().requires_grad_(True)
+    old = ME.set_conv_math(mode)
+    try:
+        y = conv(ME.SparseTensor(F_g, x.coordinate_map_key, x.coordinate_manager))
+        oy = oconv(OME.SparseTensor(F_c, ox.coordinate_map_key, ox.coordinate_manager))
+        g = torch.randn_like(oy.F)
+        y.F.backward(g.cuda())
+        oy.F.backward(g)
+    finally:
+        ME.set_conv_math(old)
+    for a, b in [(y.F, oy.F), (F_g.grad, F_c.grad)]:
+        scale = float(b.detach().abs().max())
+        assert float((a.detach().cpu() - b.detach()).abs().max()) <= tol * scale, (mode, float((a.detach().cpu() - b.detach()).abs().max()), scale)
+    # the weight gradient stays in exact fp32
+    assert torch.allclose(conv.kernel.grad.cpu(), oconv.kernel.grad, atol=ATOL * max(1.0, float(oconv.kernel.grad.abs().max())), rtol=RTOL)
