@@ -113,6 +113,22 @@ int mink_kernel_map(const uint64_t *in_table_keys, const int32_t *in_table_vals,
                     const int32_t *out_coords, int64_t n_out, const int32_t *offsets_host, int32_t K,
                     int32_t *nbr, int32_t *nbr_t, void *stream);
 
+/* Every kernel map of one forward/backward pass in ONE call (one descriptor per map; same
+ * semantics as mink_kernel_map, nbr_t is cleared to -1 here).  Cuts the per-map host cost. */
+typedef struct MinkKernelMapDesc {
+  const uint64_t *in_table_keys;
+  const int32_t *in_table_vals;
+  int64_t in_cap;
+  const int32_t *out_coords;
+  int64_t n_out;
+  int64_t n_in;
+  int32_t *nbr;
+  int32_t *nbr_t; /* may be NULL */
+  int32_t K;
+  int32_t offsets[81]; /* [K][3], scaled by dilation * input tensor stride */
+} MinkKernelMapDesc;
+int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *descs, void *stream);
+
 /* ME-format rulebook from a neighbour table: per offset k the (in,out) pairs ordered
  * by output row, built with wave64 ballot + prefix sums.
  *   counts[K+1]      : exclusive scan of pairs per offset (device, int32)

@@ -13,6 +13,14 @@ CSRC = os.path.join(_HERE, "csrc")
 
 _i32, _i64, _f32, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
+
+class KernelMapDesc(ctypes.Structure):
+    """MinkKernelMapDesc of include/mink_hip.h"""
+
+    _fields_ = [("in_table_keys", _p), ("in_table_vals", _p), ("in_cap", _i64), ("out_coords", _p), ("n_out", _i64),
+                ("n_in", _i64), ("nbr", _p), ("nbr_t", _p), ("K", _i32), ("offsets", _i32 * 81)]
+
+
 # name -> (restype, argtypes); mirrors include/mink_hip.h one to one
 SIGNATURES = {
     "mink_last_error": (ctypes.c_char_p, []),
@@ -24,6 +32,7 @@ SIGNATURES = {
     "mink_levels_workspace_bytes": (_i64, [_i64]),
     "mink_coords_build_levels": (ctypes.c_int, [_p, ctypes.c_int, _i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "mink_kernel_map": (ctypes.c_int, [_p, _p, _i64, _p, _i64, _p, _i32, _p, _p, _p]),
+    "mink_kernel_map_batch": (ctypes.c_int, [_i32, _p, _p]),
     "mink_rulebook_workspace_bytes": (_i64, [_i64, _i32]),
     "mink_rulebook": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
     "mink_class_partition_rows": (_i64, [_i64, _i32]),

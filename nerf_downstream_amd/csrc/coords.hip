@@ -443,6 +443,19 @@ int mink_kernel_map(const uint64_t *in_table_keys, const int32_t *in_table_vals,
   return MINK_OK;
 }
 
+int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
+  MINK_REQUIRE(n >= 0 && (n == 0 || d), "kernel_map_batch: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n; ++i) {
+    if (d[i].nbr_t && d[i].n_in > 0)
+      MINK_HIP(hipMemsetAsync(d[i].nbr_t, 0xFF, sizeof(int32_t) * d[i].n_in * d[i].K, st));
+    int rc = mink_kernel_map(d[i].in_table_keys, d[i].in_table_vals, d[i].in_cap, d[i].out_coords, d[i].n_out,
+                             d[i].offsets, d[i].K, d[i].nbr, d[i].nbr_t, stream);
+    if (rc) return rc;
+  }
+  return MINK_OK;
+}
+
 int64_t mink_rulebook_workspace_bytes(int64_t n_out, int32_t K) {
   const int64_t nchunk = cdiv(n_out > 0 ? n_out : 1, kBlock);
   return 2 * align_up(4 * nchunk * K, 256) + 256;

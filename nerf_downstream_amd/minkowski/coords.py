@@ -23,7 +23,7 @@ _STATUS_RANGE, _STATUS_UNSORTED = 1, 2
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _as_int(v):
@@ -33,8 +33,18 @@ def _as_int(v):
     return int(v)
 
 
+_OFFSET_CACHE = {}
+
+
 def kernel_offsets(kernel_size, in_ts, dilation=1):
     """Kernel region (A4): x fastest, z slowest; odd sizes centred, even sizes {0..k-1}."""
+    key = (int(kernel_size), int(in_ts), int(dilation))
+    if key not in _OFFSET_CACHE:
+        _OFFSET_CACHE[key] = _kernel_offsets(*key)
+    return _OFFSET_CACHE[key]
+
+
+def _kernel_offsets(kernel_size, in_ts, dilation):
     k = int(kernel_size)
     r = np.arange(k) - (k - 1) // 2 if k % 2 == 1 else np.arange(k)
     dz, dy, dx = np.meshgrid(r, r, r, indexing="ij")
@@ -110,6 +120,7 @@ class CoordinateManager:
     def replay(self, plan):
         """Build every map of `plan` now (on the current stream) so the forward/backward pass that
         follows finds them cached."""
+        self._build_tables_batched([op for op in plan if op[0] == "ktable"])
         for op in plan:
             if op[0] == "stride":
                 self.stride(CoordinateMapKey(op[1]), op[2])
@@ -119,6 +130,41 @@ class CoordinateManager:
                 self.class_perm(CoordinateMapKey(op[1]), op[2])
             elif op[0] == "boff":
                 self.batch_offsets(CoordinateMapKey(op[1]))
+
+    def _build_tables_batched(self, ops):
+        """All neighbour tables of a plan with one allocation and one native call."""
+        import ctypes
+
+        from .._lib import KernelMapDesc
+
+        todo = []
+        for _, ts_in, ts_out, ks, dil, transposed in ops:
+            ent = self.tables.get((ts_in, ts_out, ks, dil))
+            if ts_in in self.levels and ts_out in self.levels and (ent is None or (transposed and ent[1] is None)):
+                todo.append((ts_in, ts_out, ks, dil, transposed))
+        if not todo:
+            return
+        sizes = []
+        for ts_in, ts_out, ks, dil, transposed in todo:
+            K = ks ** 3
+            sizes.append((self.levels[ts_out].n * K, self.levels[ts_in].n * K if transposed else 0))
+        pool = torch.empty(sum(a + b for a, b in sizes) + 4, dtype=torch.int32, device=self.device)
+        descs = (KernelMapDesc * len(todo))()
+        off = 0
+        for d, (ts_in, ts_out, ks, dil, transposed), (na, nb) in zip(descs, todo, sizes):
+            lin, lout = self.levels[ts_in], self.levels[ts_out]
+            K = ks ** 3
+            nbr = pool[off : off + na].view(lout.n, K)
+            off += na
+            nbr_t = pool[off : off + nb].view(lin.n, K) if transposed else None
+            off += nb
+            d.in_table_keys, d.in_table_vals, d.in_cap = lin.tkeys.data_ptr(), lin.tvals.data_ptr(), lin.cap
+            d.out_coords, d.n_out, d.n_in = lout.coords.data_ptr(), lout.n, lin.n
+            d.nbr, d.nbr_t, d.K = nbr.data_ptr(), (nbr_t.data_ptr() if transposed else None), K
+            o = kernel_offsets(ks, ts_in, dil).ravel()
+            d.offsets[: o.size] = o.tolist()
+            self.tables[(ts_in, ts_out, ks, dil)] = (nbr, nbr_t)
+        check(lib().mink_kernel_map_batch(len(todo), ctypes.cast(descs, ctypes.c_void_p), _stream()))
 
     def tensors(self):
         out = [self.field_inverse, self.field_unique_index]

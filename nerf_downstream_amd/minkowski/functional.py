@@ -10,7 +10,7 @@ from .._lib import check, lib
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _f32c(t):
@@ -24,6 +24,22 @@ def _ptr(t):
 
 def _bytes(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# Scratch buffers of the main (compute) stream are recycled: kernels on one stream run in
+# order, so the next user may overwrite a workspace as soon as it is enqueued behind the last.
+_SCRATCH = {}
+
+
+def _scratch(nbytes, device, slot):
+    stream = _stream()
+    key = (device.index, stream, slot)
+    buf = _SCRATCH.get(key)
+    nbytes = max(int(nbytes), 256)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
 
 
 # ------------------------------------------------------------------- matrix-core math
@@ -85,7 +101,7 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, ro
     cin = x.shape[1]
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
     ksplit = int(L.mink_conv_plan_ksplit(n_out, K, cout))
-    ws = torch.empty(ksplit * n_out * cout, dtype=torch.float32, device=x.device) if ksplit > 1 else None
+    ws = _scratch(4 * ksplit * n_out * cout, x.device, "splitk") if ksplit > 1 else None
     tag = f"{'dgrad' if w_transposed else 'fwd'}[{n_out}x{K}:{cin}->{cout}]"
     with _timed(tag, kind="gather_gemm", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr, ksplit=ksplit):
         check(
@@ -103,7 +119,7 @@ def conv_wgrad(x, dy, nbr, kernel_shape):
     n_out, K = nbr.shape
     cin, cout = x.shape[1], dy.shape[1]
     dw = torch.empty(kernel_shape, dtype=torch.float32, device=x.device)
-    ws = _bytes(L.mink_conv_wgrad_workspace_bytes(n_out, K, cin, cout), x.device)
+    ws = _scratch(L.mink_conv_wgrad_workspace_bytes(n_out, K, cin, cout), x.device, "wgrad")
     with _timed(f"wgrad[{n_out}x{K}:{cin}->{cout}]", kind="wgrad", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr):
         check(
             L.mink_conv_wgrad(
@@ -165,7 +181,7 @@ class BatchNormFunction(torch.autograd.Function):
         if training:
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
-            ws = _bytes(L.mink_bn_workspace_bytes(n, C), dev)
+            ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
             check(
                 L.mink_bn_stats(
                     x.data_ptr(), n, C, eps, momentum if running_mean is not None else 0.0, mean.data_ptr(),
@@ -202,7 +218,7 @@ class BatchNormFunction(torch.autograd.Function):
         gres = torch.empty_like(x) if ctx.has_res else None
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-        ws = _bytes(L.mink_bn_workspace_bytes(n, C), dev)
+        ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
         check(
             L.mink_bn_bwd(
                 gy.data_ptr(), x.data_ptr(), _ptr(y), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
