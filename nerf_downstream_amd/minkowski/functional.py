@@ -130,6 +130,23 @@ def conv_wgrad(x, dy, nbr, kernel_shape):
     return dw
 
 
+_OVERLAP_WGRAD = False  # measured: the event traffic costs more host time than the overlap wins
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device.index)
+    if s is None:
+        s = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
+def set_wgrad_overlap(on=True):
+    global _OVERLAP_WGRAD
+    old, _OVERLAP_WGRAD = _OVERLAP_WGRAD, bool(on)
+    return old
+
+
 class ConvolutionFunction(torch.autograd.Function):
     """MinkowskiConvolution forward/backward (reference modules/common.py:116-125; A6).
 
@@ -150,18 +167,31 @@ class ConvolutionFunction(torch.autograd.Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = _f32c(gy)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            # dgrad = the same gather-GEMM over the transposed map with W[k]^T; transposing the
-            # (small) kernel once lets it run on the LDS-free direct path like the forward
-            direct = w.shape[-1] % 32 == 0
-            wd = w.transpose(1, 2).contiguous() if direct else w
+        gx = gw = None
+        want_gx, want_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        # dgrad and wgrad only share their inputs: run wgrad on a second HIP stream so the two
+        # (latency-bound for the deep, small layers) overlap; the compute stream re-joins before
+        # anything can consume the weight gradient.
+        side = _side_stream(gy.device) if (want_gx and want_gw and _OVERLAP_WGRAD) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)  # gy / x are ready on the side stream
+        if want_gx:
+            # dgrad = the same gather-GEMM over the transposed map with W[k]^T (read in place)
             if ctx.same_map:  # stride 1: nbr_t[i][k] == nbr[i][K-1-k]
-                gx = gather_gemm(gy, wd, ctx.nbr, w.shape[-2], w_transposed=not direct, flip_k=True)
+                gx = gather_gemm(gy, w, ctx.nbr, w.shape[-2], w_transposed=True, flip_k=True)
             else:
                 _, nbr_t, perm = ctx.table_fn(True)
-                gx = gather_gemm(gy, wd, nbr_t, w.shape[-2], w_transposed=not direct, row_perm=perm)
-        gw = conv_wgrad(x, gy, ctx.nbr, w.shape) if ctx.needs_input_grad[1] else None
+                gx = gather_gemm(gy, w, nbr_t, w.shape[-2], w_transposed=True, row_perm=perm)
+        if want_gw:
+            if side is not None:
+                with torch.cuda.stream(side):
+                    gw = conv_wgrad(x, gy, ctx.nbr, w.shape)
+                for t in (x, gy, gw):
+                    t.record_stream(side if t is not gw else main)
+                main.wait_stream(side)
+            else:
+                gw = conv_wgrad(x, gy, ctx.nbr, w.shape)
         return gx, gw, None, None
 
 
