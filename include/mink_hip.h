@@ -246,6 +246,18 @@ int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int3
                 const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual,
                 float *dgamma, float *dbeta, void *workspace, void *stream);
 
+/* Fused tail of the stem: y_pool = SumPool(relu(BN(x))) without materialising the normalised
+ * [n,C] tensor (bn1 -> relu -> pool, resnet.py:58-64).  `nbr[n_out][K]` is the 2^3 children
+ * table, `in2out[n]` the stride map.  Statistics come from mink_bn_stats; the ReLU mask of the
+ * backward pass is recomputed from x. */
+int mink_bn_relu_pool_fwd(const float *x, int32_t C, const float *mean, const float *invstd,
+                          const float *gamma, const float *beta, const int32_t *nbr, int64_t n_out,
+                          int32_t K, float *y, void *stream);
+int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32_t C, const float *mean,
+                          const float *invstd, const float *gamma, const float *beta,
+                          const int32_t *in2out, float *dx, float *dgamma, float *dbeta,
+                          void *workspace, void *stream);
+
 /* Elementwise: mode 0: y = max(x,0); mode 1: dx = (y>0) ? dy : 0 (a=dy,b=y);
  * mode 2: y = a + b. */
 int mink_eltwise(const float *a, const float *b, int64_t count, int32_t mode, float *y, void *stream);

@@ -77,8 +77,10 @@ class ResNetBase(MinkowskiBaseModel):
         if self.training and self._norms:
             torch._foreach_add_([m.bn.num_batches_tracked for m in self._norms], 1)
         out = self.conv1(x.sparse())
-        out = self.bn1(out, relu=True) if self._fused else self.relu(self.bn1(out))
-        out = self.pool(out)
+        if self._fused:  # bn1 -> relu -> pool in one pass over the finest-level activation
+            out = self.pool(out, norm=self.bn1)
+        else:
+            out = self.pool(self.relu(self.bn1(out)))
         out = self.layer4(self.layer3(self.layer2(self.layer1(out))))
         return self.final(self.glob_avg(out)).F
 

@@ -17,11 +17,15 @@ __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<floa
 // Generic two-quantity column reduction over rows: each thread owns 4 channels (one float4
 // column) and strides over rows; partial[blk][2][C] in double.
 // MODE 0: (sum x, sum x^2)      MODE 1: (sum g, sum g*xhat) with g = dy * (relu ? y>0 : 1)
+// MODE 2: as MODE 1 for the fused bn+relu+sum-pool: g = dy_pool[in2out[row]] * (gamma*xhat+beta > 0)
 template <int MODE>
 __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                        const float *__restrict__ yrelu, int64_t n, int C,
                                                        const float *__restrict__ mean,
-                                                       const float *__restrict__ invstd, double *__restrict__ partial) {
+                                                       const float *__restrict__ invstd, double *__restrict__ partial,
+                                                       const int *__restrict__ in2out = nullptr,
+                                                       const float *__restrict__ gamma = nullptr,
+                                                       const float *__restrict__ beta = nullptr) {
   extern __shared__ double s_red[];  // [rows_in_block][2][C] reduced over the row lanes
   const int tpr = C >> 2;            // threads per row
   const int rlanes = EB / tpr;       // rows handled concurrently
@@ -29,7 +33,9 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
   float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
   float4 mu = make_float4(0, 0, 0, 0), is = make_float4(1, 1, 1, 1);
   const bool active = rl < rlanes;
-  if (MODE == 1 && active) mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
+  float4 ga = make_float4(1, 1, 1, 1), be = make_float4(0, 0, 0, 0);
+  if (MODE >= 1 && active) mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
+  if (MODE == 2 && active) ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
   if (active) {
     for (int64_t row = (int64_t)blockIdx.x * rlanes + rl; row < n; row += (int64_t)gridDim.x * rlanes) {
       const int64_t off = row * C + 4 * c4;
@@ -37,6 +43,14 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
         const float4 v = ld4(a + off);
         s0.x += v.x, s0.y += v.y, s0.z += v.z, s0.w += v.w;
         s1.x += v.x * v.x, s1.y += v.y * v.y, s1.z += v.z * v.z, s1.w += v.w * v.w;
+      } else if (MODE == 2) {
+        const float4 x = ld4(b + off);
+        float4 g = ld4(a + (int64_t)in2out[row] * C + 4 * c4);
+        const float4 xh = make_float4((x.x - mu.x) * is.x, (x.y - mu.y) * is.y, (x.z - mu.z) * is.z, (x.w - mu.w) * is.w);
+        g.x = xh.x * ga.x + be.x > 0.f ? g.x : 0.f, g.y = xh.y * ga.y + be.y > 0.f ? g.y : 0.f;
+        g.z = xh.z * ga.z + be.z > 0.f ? g.z : 0.f, g.w = xh.w * ga.w + be.w > 0.f ? g.w : 0.f;
+        s0.x += g.x, s0.y += g.y, s0.z += g.z, s0.w += g.w;
+        s1.x += g.x * xh.x, s1.y += g.y * xh.y, s1.z += g.z * xh.z, s1.w += g.w * xh.w;
       } else {
         float4 g = ld4(a + off);
         const float4 x = ld4(b + off);
@@ -180,6 +194,65 @@ __global__ __launch_bounds__(EB) void eltwise_kernel(const float *__restrict__ a
   if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
     const int64_t i = (n4 << 2) + threadIdx.x;
     y[i] = mode == 0 ? fmaxf(a[i], 0.f) : (mode == 1 ? (b[i] > 0.f ? a[i] : 0.f) : a[i] + b[i]);
+  }
+}
+
+// ------------------------------------------------ fused bn + relu + sum-pool (stem tail)
+// y[o] = sum_{i child of o} relu((x[i]-mean)*invstd*gamma+beta): the normalised [N,C] tensor of
+// the finest level (the largest activation of the network) is never written to HBM.
+__global__ __launch_bounds__(EB) void bn_relu_pool_fwd_kernel(const float *__restrict__ x, int C4,
+                                                              const float *__restrict__ mean,
+                                                              const float *__restrict__ invstd,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta,
+                                                              const int *__restrict__ nbr, int64_t n_out, int K,
+                                                              float *__restrict__ y) {
+  const int64_t idx = (int64_t)blockIdx.x * EB + threadIdx.x;
+  if (idx >= n_out * C4) return;
+  const int64_t o = idx / C4;
+  const int c = (int)(idx - o * C4) * 4;
+  const float4 mu = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+  const float4 sc = make_float4(is.x * g.x, is.y * g.y, is.z * g.z, is.w * g.w);
+  const float4 sh = make_float4(b.x - mu.x * sc.x, b.y - mu.y * sc.y, b.z - mu.z * sc.z, b.w - mu.w * sc.w);
+  float4 s = make_float4(0, 0, 0, 0);
+  for (int k = 0; k < K; ++k) {
+    const int i = nbr[o * K + k];
+    if (i >= 0) {
+      const float4 v = ld4(x + (int64_t)i * (4 * C4) + c);
+      s.x += fmaxf((v.x - mu.x) * is.x * g.x + b.x, 0.f), s.y += fmaxf((v.y - mu.y) * is.y * g.y + b.y, 0.f);
+      s.z += fmaxf((v.z - mu.z) * is.z * g.z + b.z, 0.f), s.w += fmaxf((v.w - mu.w) * is.w * g.w + b.w, 0.f);
+    }
+  }
+  (void)sh;
+  st4(y + o * (int64_t)(4 * C4) + c, s);
+}
+
+// dx[i] = gamma*invstd*(g - dbeta/n - xhat*dgamma/n), g = dy_pool[in2out[i]] * (gamma*xhat+beta > 0)
+__global__ __launch_bounds__(EB) void bn_relu_pool_bwd_kernel(const float *__restrict__ dyp,
+                                                              const float *__restrict__ x,
+                                                              const int *__restrict__ in2out, int64_t n, int C4,
+                                                              float inv_n, const float *__restrict__ mean,
+                                                              const float *__restrict__ invstd,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta,
+                                                              const float *__restrict__ dgamma,
+                                                              const float *__restrict__ dbeta,
+                                                              float *__restrict__ dx) {
+  for (int64_t i4 = (int64_t)blockIdx.x * EB + threadIdx.x; i4 < n * C4; i4 += (int64_t)gridDim.x * EB) {
+    const int64_t row = i4 / C4;
+    const int c = (int)(i4 - row * C4) * 4;
+    const float4 v = ld4(x + 4 * i4), mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), be = ld4(beta + c),
+                 dg = ld4(dgamma + c), db = ld4(dbeta + c);
+    float4 g = ld4(dyp + (int64_t)in2out[row] * (4 * C4) + c);
+    const float4 xh = make_float4((v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w);
+    g.x = xh.x * ga.x + be.x > 0.f ? g.x : 0.f, g.y = xh.y * ga.y + be.y > 0.f ? g.y : 0.f;
+    g.z = xh.z * ga.z + be.z > 0.f ? g.z : 0.f, g.w = xh.w * ga.w + be.w > 0.f ? g.w : 0.f;
+    float4 o;
+    o.x = ga.x * is.x * (g.x - db.x * inv_n - xh.x * dg.x * inv_n);
+    o.y = ga.y * is.y * (g.y - db.y * inv_n - xh.y * dg.y * inv_n);
+    o.z = ga.z * is.z * (g.z - db.z * inv_n - xh.z * dg.z * inv_n);
+    o.w = ga.w * is.w * (g.w - db.w * inv_n - xh.w * dg.w * inv_n);
+    st4(dx + 4 * i4, o);
   }
 }
 
@@ -357,6 +430,49 @@ int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int3
   const int64_t n4 = n * (C >> 2);
   bn_bwd_apply_kernel<<<dim3(ew_grid(n4)), EB, 0, st>>>(dy, x, yr, n4, C >> 2, 1.f / (float)n, mean, invstd, gamma,
                                                        dgamma, dbeta, dx, dresidual);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_bn_relu_pool_fwd(const float *x, int32_t C, const float *mean, const float *invstd, const float *gamma,
+                          const float *beta, const int32_t *nbr, int64_t n_out, int32_t K, float *y, void *stream) {
+  REQ_C4(C, "bn_relu_pool_fwd");
+  MINK_REQUIRE(n_out >= 0 && K >= 1, "bn_relu_pool_fwd: bad shape");
+  if (n_out == 0) return MINK_OK;
+  MINK_REQUIRE(x && mean && invstd && gamma && beta && nbr && y, "bn_relu_pool_fwd: NULL pointer");
+  REQ_A16(x, "bn_relu_pool_fwd");
+  REQ_A16(y, "bn_relu_pool_fwd");
+  bn_relu_pool_fwd_kernel<<<dim3((unsigned)cdiv(n_out * (C >> 2), EB)), EB, 0, (hipStream_t)stream>>>(
+      x, C >> 2, mean, invstd, gamma, beta, nbr, n_out, K, y);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32_t C, const float *mean,
+                          const float *invstd, const float *gamma, const float *beta, const int32_t *in2out, float *dx,
+                          float *dgamma, float *dbeta, void *workspace, void *stream) {
+  REQ_C4(C, "bn_relu_pool_bwd");
+  MINK_REQUIRE(n >= 1 && dy_pool && x && mean && invstd && gamma && beta && in2out && dx && dgamma && dbeta && workspace,
+               "bn_relu_pool_bwd: bad arguments");
+  REQ_A16(dy_pool, "bn_relu_pool_bwd");
+  REQ_A16(x, "bn_relu_pool_bwd");
+  REQ_A16(dx, "bn_relu_pool_bwd");
+  hipStream_t st = (hipStream_t)stream;
+  const int tpr = C >> 2;
+  MINK_REQUIRE(tpr <= EB, "bn_relu_pool_bwd: too many channels");
+  const int rlanes = EB / tpr;
+  int64_t nblk = cdiv(n, (int64_t)rlanes * 8);
+  if (nblk > kRedBlocks) nblk = kRedBlocks;
+  const size_t shm = (size_t)rlanes * 2 * C * sizeof(double);
+  colreduce_kernel<2><<<dim3((unsigned)nblk), EB, shm, st>>>(dy_pool, x, nullptr, n, C, mean, invstd, (double *)workspace,
+                                                            in2out, gamma, beta);
+  MINK_CHECK_LAUNCH();
+  bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, 16)), 256, 0, st>>>((const double *)workspace, (int)nblk, C, gamma,
+                                                                     dgamma, dbeta);
+  MINK_CHECK_LAUNCH();
+  const int64_t n4 = n * (C >> 2);
+  bn_relu_pool_bwd_kernel<<<dim3(ew_grid(n4)), EB, 0, st>>>(dy_pool, x, in2out, n, C >> 2, 1.f / (float)n, mean, invstd,
+                                                           gamma, beta, dgamma, dbeta, dx);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

@@ -258,6 +258,63 @@ class BatchNormFunction(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None, None, None, None, gres, None
 
 
+class BNReLUSumPoolFunction(torch.autograd.Function):
+    """relu(BN(x)) summed over the 2^3 children of every coarse voxel, in one pass over x
+    (reference resnet.py:58-64: bn1 -> relu -> pool).  The normalised fine-level tensor -- the
+    largest activation of the network -- is never written; backward recomputes the ReLU mask."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, nbr, in2out):
+        L = lib()
+        x = _f32c(x)
+        n, C = x.shape
+        dev = x.device
+        if training:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
+            check(
+                L.mink_bn_stats(
+                    x.data_ptr(), n, C, eps, momentum if running_mean is not None else 0.0, mean.data_ptr(),
+                    invstd.data_ptr(), _ptr(running_mean), _ptr(running_var), ws.data_ptr(), _stream(),
+                )
+            )
+        else:
+            mean = running_mean.float()
+            invstd = torch.rsqrt(running_var.float() + eps)
+        n_out, K = nbr.shape
+        y = torch.empty(n_out, C, dtype=torch.float32, device=dev)
+        check(
+            L.mink_bn_relu_pool_fwd(
+                x.data_ptr(), C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), nbr.data_ptr(),
+                n_out, K, y.data_ptr(), _stream(),
+            )
+        )
+        ctx.save_for_backward(x, mean, invstd, gamma, beta)
+        ctx.in2out, ctx.training = in2out, training
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.training:
+            raise NotImplementedError("fused bn+relu+pool backward needs batch statistics (training mode)")
+        L = lib()
+        x, mean, invstd, gamma, beta = ctx.saved_tensors
+        gy = _f32c(gy)
+        n, C = x.shape
+        gx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _scratch(L.mink_bn_workspace_bytes(n, C), x.device, "bn")
+        check(
+            L.mink_bn_relu_pool_bwd(
+                gy.data_ptr(), x.data_ptr(), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                ctx.in2out.data_ptr(), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(),
+            )
+        )
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
 # ----------------------------------------------------------------------------- eltwise
 def _eltwise(a, b, mode):
     y = torch.empty_like(a)

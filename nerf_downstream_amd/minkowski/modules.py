@@ -132,11 +132,24 @@ class MinkowskiSumPooling(nn.Module):
         assert self.kernel_size == self.stride and self.kernel_size ** 3 <= 27, \
             "only non-overlapping pooling (kernel_size == stride) is implemented"
 
-    def forward(self, input):
+    def forward(self, input, norm=None):
+        """`norm` (extension): a MinkowskiBatchNorm to apply, followed by ReLU, to `input` on the
+        fly -- pool(relu(norm(input))) in one pass without materialising the normalised tensor."""
         m, in_key = input.coordinate_manager, input.coordinate_map_key
         out_key = m.stride(in_key, self.stride)
         nbr, _ = m.kernel_table(in_key, out_key, self.kernel_size, 1)
-        out = Fn.SumPoolFunction.apply(input.F, nbr, m.stride_map(in_key, out_key))
+        i2o = m.stride_map(in_key, out_key)
+        if norm is not None and norm.bn.affine and (norm.bn.training or not torch.is_grad_enabled()):
+            bn = norm.bn
+            training = bn.training or not bn.track_running_stats
+            if training and bn.track_running_stats and not norm.counted_by_parent:
+                bn.num_batches_tracked += 1
+            out = Fn.BNReLUSumPoolFunction.apply(input.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
+                                                 bn.momentum if bn.momentum is not None else 0.1, bn.eps, nbr, i2o)
+        else:
+            if norm is not None:
+                input = norm(input, relu=True)
+            out = Fn.SumPoolFunction.apply(input.F, nbr, i2o)
         return SparseTensor(out, out_key, m)
 
 

@@ -185,3 +185,29 @@ def test_convolution_reduced_math(oracle_maps, mode, tol, cin, cout, stride, ts)
         assert float((a.detach().cpu() - b.detach()).abs().max()) <= tol * scale, (mode, float((a.detach().cpu() - b.detach()).abs().max()), scale)
     # the weight gradient stays in exact fp32
     assert torch.allclose(conv.kernel.grad.cpu(), oconv.kernel.grad, atol=ATOL * max(1.0, float(oconv.kernel.grad.abs().max())), rtol=RTOL)
+
+
+def test_fused_bn_relu_sumpool(oracle_maps):
+    """pool(relu(bn(x))) fused (extension kwarg of MinkowskiSumPooling) == the three modules."""
+    from nerf_downstream_amd import minkowski as ME
+
+    torch.manual_seed(4)
+    _, _, tf, _ = _pair([6, 7], 24, 16, negative=True)
+    x = tf.sparse()
+    m, key = x.coordinate_manager, x.coordinate_map_key
+    bn_a, bn_b = ME.MinkowskiBatchNorm(16).cuda(), ME.MinkowskiBatchNorm(16).cuda()
+    with torch.no_grad():
+        bn_a.bn.weight.uniform_(0.5, 1.5), bn_a.bn.bias.uniform_(-0.5, 0.5)
+    bn_b.load_state_dict(bn_a.state_dict())
+    pool = ME.MinkowskiSumPooling(kernel_size=2, stride=2, dimension=3)
+    Fa = x.F.detach().clone().requires_grad_(True)
+    Fb = x.F.detach().clone().requires_grad_(True)
+    ya = pool(ME.SparseTensor(Fa, key, m), norm=bn_a).F
+    yb = pool(ME.MinkowskiReLU()(bn_b(ME.SparseTensor(Fb, key, m)))).F
+    assert torch.allclose(ya, yb, atol=1e-5, rtol=1e-5)
+    g = torch.randn_like(ya)
+    ya.backward(g), yb.backward(g)
+    assert torch.allclose(Fa.grad, Fb.grad, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(bn_a.bn.weight.grad, bn_b.bn.weight.grad, atol=1e-3, rtol=1e-4)
+    assert torch.allclose(bn_a.bn.bias.grad, bn_b.bn.bias.grad, atol=1e-3, rtol=1e-4)
+    assert torch.allclose(bn_a.bn.running_var, bn_b.bn.running_var) and int(bn_a.bn.num_batches_tracked) == 1
