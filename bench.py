@@ -149,17 +149,28 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
+    if os.environ.get("BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit if stuck
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal hooks (single-GPU box): BENCH_DEVICE pins every rank to one card and
+    # BENCH_DIST_BACKEND=gloo replaces RCCL, so the N>1 code path can be exercised without a node
+    dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from nerf_downstream_amd import _lib
     from nerf_downstream_amd.co3d_3d.src.models import get_model
@@ -174,7 +185,7 @@ def main():
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=200000)
-    reducer = BucketedGradAllReduce(model) if world > 1 else None  # N=1: autograd hands gradients over without a copy
+    reducer = BucketedGradAllReduce(model, bucket_bytes=int(os.environ.get("BENCH_BUCKET_BYTES", 32 << 20))) if world > 1 else None  # N=1: autograd hands gradients over without a copy
 
     batches = make_batches(2, args.batch, rank, args.num_classes, args.grid, args.in_channel)
     batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]

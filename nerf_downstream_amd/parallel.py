@@ -22,6 +22,9 @@ class BucketedGradAllReduce:
     def __init__(self, module, bucket_bytes=32 << 20, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if self.world > 1 and dist.get_backend(process_group) == "gloo":
+            # gloo (CPU rehearsals / tests) stalls on 32 MiB device tensors; RCCL wants them large
+            bucket_bytes = min(bucket_bytes, 8 << 20)
         params = [p for p in module.parameters() if p.requires_grad][::-1]
         total = sum(p.numel() for p in params)
         dev = params[0].device
