@@ -175,11 +175,9 @@ int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *bat
  *   ksplit             : >1 splits the K offsets over `ksplit` workgroups per tile and
  *                        reduces through `workspace` (ksplit*n_out*cout floats)
  */
-/* Kernel selection knob (tests / A-B benchmarks): 1 = LDS-free direct gather-GEMM where it
- * applies (default), 0 = always the LDS-staged kernel.  Returns the previous setting. */
-int mink_conv_set_direct(int on);
-/* Tuning knob: start-up stagger (units of 1024 clocks per phase) between workgroups that share a
- * CU in the gather-GEMM; 0 = off.  Returns the previous value. */
+/* Tuning / A-B knob (benchmarks only): bits 0-5 start-up stagger of the un-pipelined kernel,
+ * bit 8 = use the un-pipelined kernel, bit 9 = disable the flattened-K stem path.  Returns the
+ * previous stagger value. */
 int mink_conv_set_stagger(int units);
 /* Matrix-core arithmetic of mink_conv_gather_gemm (forward / input gradient):
  *   0 = exact fp32 MFMA (default), 1 = bf16 operands with fp32 accumulation (BASELINE config

@@ -649,117 +649,6 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
   }
 }
 
-// --------------------------------------------------------------------------- direct
-// Barrier-free variant of the gather-GEMM for w[K][cin][cout] weights: every wave owns 32
-// output rows x 64 columns and feeds the MFMA straight from global memory / L1 -- the A
-// fragment of v_mfma_f32_32x32x2_f32 is (row = lane&31, k = lane>>5), so lane (r,h) loads the
-// h-th half of ITS neighbour row's channel chunk with 8/16-byte loads (a row gather needs no
-// LDS transpose), and the B fragment (k = lane>>5, col = lane&31) is a coalesced 128-byte read
-// of one weight row served by L1/L2.  No LDS, no __syncthreads: waves of a SIMD overlap each
-// other's load latency, and the next chunk's A fragment is prefetched under the MFMAs.
-// KH = input channels per lane half and chunk (cin is processed in chunks of 2*KH).
-template <int KH>
-__global__ __launch_bounds__(256) void conv_direct_kernel(GemmParams p) {
-  constexpr int VW = (KH % 4 == 0) ? 4 : 2;  // floats per A load
-  constexpr int NV = KH / VW;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lr = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.y * BN;
-  const int K = p.K;
-  const int kbeg = blockIdx.z * p.kper;
-  const int kend = min(K, kbeg + p.kper);
-  const int64_t v = (int64_t)blockIdx.x * BM + wave * 32 + lr;
-  int orow = -1;
-  if (v < p.n_virtual) orow = p.row_perm ? p.row_perm[v] : (int)v;
-  const int *nb = p.nbr + (int64_t)(orow >= 0 ? orow : 0) * K;
-  const int nchunk = (p.cin + 2 * KH - 1) / (2 * KH);
-
-  f32x16 acc0 = {0}, acc1 = {0};
-  const int ca = n0 + lr, cb = n0 + 32 + lr;
-  const bool va = ca < p.cout, vb = cb < p.cout;
-
-  float a_cur[KH], a_nxt[KH];
-  auto load_a = [&](int idx, int c0, float (&a)[KH]) {
-    const int cbase = c0 + h * KH;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int c = cbase + j * VW;
-      if (idx >= 0 && c + VW <= p.cin) {
-        const float *src = p.x + (int64_t)idx * p.ldx + c;
-        if (VW == 4) {
-          const float4 t = *reinterpret_cast<const float4 *>(src);
-          a[4 * j] = t.x, a[4 * j + 1] = t.y, a[4 * j + 2] = t.z, a[4 * j + 3] = t.w;
-        } else {
-          const float2 t = *reinterpret_cast<const float2 *>(src);
-          a[2 * j] = t.x, a[2 * j + 1] = t.y;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < VW; ++e) a[VW * j + e] = (idx >= 0 && c + e < p.cin) ? p.x[(int64_t)idx * p.ldx + c + e] : 0.f;
-      }
-    }
-  };
-
-  // work items = (offset k with at least one neighbour in this wave, channel chunk)
-  int k = kbeg, idx = -1;
-  auto next_k = [&](int from) {  // first offset >= from with a neighbour (wave-uniform), or kend
-    int kk = from;
-    for (; kk < kend; ++kk) {
-      const int t = orow >= 0 ? nb[kk] : -1;
-      if (__ballot(t >= 0)) {
-        idx = t;
-        break;
-      }
-    }
-    return kk;
-  };
-  k = next_k(kbeg);
-  int ch = 0;
-  if (k < kend) load_a(idx, 0, a_cur);
-  while (k < kend) {
-    // prefetch the A fragment of the next work item
-    int nk = k, nch = ch + 1, nidx = idx;
-    if (nch == nchunk) {
-      nch = 0;
-      const int save = idx;
-      nk = next_k(k + 1);
-      nidx = idx;
-      idx = save;
-    }
-    if (nk < kend) load_a(nidx, nch * 2 * KH, a_nxt);
-    const int kw = p.flip_k ? (K - 1 - k) : k;
-    const float *wrow = p.w + ((int64_t)kw * p.cin + ch * 2 * KH + h * KH) * p.cout;
-    const int krem = p.cin - (ch * 2 * KH + h * KH);  // valid channels in this lane half
-#pragma unroll
-    for (int s = 0; s < KH; ++s) {
-      const bool kv = s < krem;
-      const float b0 = (kv && va) ? wrow[(int64_t)s * p.cout + ca] : 0.f;
-      const float b1 = (kv && vb) ? wrow[(int64_t)s * p.cout + cb] : 0.f;
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], b1, acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < KH; ++s) a_cur[s] = a_nxt[s];
-    k = nk, ch = nch, idx = nidx;
-  }
-
-  // ---- epilogue (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-  const bool direct = gridDim.z == 1;
-  float *dst = direct ? p.y : p.ws + (int64_t)blockIdx.z * p.n_out * p.cout;
-  const int ldd = direct ? p.ldy : p.cout;
-  const float bias_a = (direct && p.bias && va) ? p.bias[ca] : 0.f;
-  const float bias_b = (direct && p.bias && vb) ? p.bias[cb] : 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int src_lane = (r & 3) + 8 * (r >> 2) + 4 * h;  // tile row held by this accumulator register
-    const int64_t row = __shfl(orow, src_lane);           // lanes 0..31 hold the tile's output rows
-    if (row >= 0) {
-      if (va) dst[row * ldd + ca] = acc0[r] + bias_a;
-      if (vb) dst[row * ldd + cb] = acc1[r] + bias_b;
-    }
-  }
-}
-
 // y[row][c] = sum_z ws[z][row][c] + bias[c]
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int64_t n_out, int cout,
                                                             int ksplit, const float *__restrict__ bias,
@@ -1029,16 +918,8 @@ static int g_stagger = 0;
 static int g_pipeline = 1;
 static int g_flat = 1;
 static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
-static int g_use_direct = 0;  // measured slower than the LDS-staged kernel (B operand traffic)
 
 extern "C" {
-
-/* 0 = always use the LDS-staged kernel, 1 = use the LDS-free direct kernel where it applies */
-int mink_conv_set_direct(int on) {
-  const int old = g_use_direct;
-  g_use_direct = on;
-  return old;
-}
 
 int mink_conv_set_stagger(int units) {
   const int old = g_stagger;
@@ -1086,15 +967,7 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
   const int zs = (int)cdiv(K, p.kper);
   const dim3 grid((unsigned)cdiv(n_virtual, BM), (unsigned)cdiv(cout, BN), (unsigned)zs);
   hipStream_t st = (hipStream_t)stream;
-  // direct (LDS-free) path: natural weight layout, 8-byte aligned channel halves
-  const bool a8 = ((ldx & 1) == 0) && (((uintptr_t)x & 15) == 0);
-  if (!w_transposed && g_use_direct && a8 && cin == 28)
-    conv_direct_kernel<14><<<grid, 256, 0, st>>>(p);
-  else if (!w_transposed && g_use_direct && a8 && (ldx & 3) == 0 && (cin % 64) == 0)
-    conv_direct_kernel<32><<<grid, 256, 0, st>>>(p);
-  else if (!w_transposed && g_use_direct && a8 && (ldx & 3) == 0 && (cin % 32) == 0)
-    conv_direct_kernel<16><<<grid, 256, 0, st>>>(p);
-  else {
+  {
     const bool al = (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && (ldx & 3) == 0 && (cin & 3) == 0;
     const bool vec = al && (w_transposed ? true : (cout & 3) == 0);
     const bool stage = row_perm != nullptr;

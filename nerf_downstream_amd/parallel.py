@@ -7,8 +7,9 @@ per-rank BatchNorm statistics, mean of gradients across ranks once per step.  He
 * all parameter gradients live in ONE flat fp32 buffer (`.grad` tensors are views), laid out
   in REVERSE registration order so the buffer fills front-to-back as backward proceeds
   (layer4 -- 74 % of the bytes -- first);
-* the buffer is cut into buckets (default 32 MiB: large messages, because ring/tree
-  collectives over point-to-point xGMI links are per-link bandwidth bound);
+* the buffer is cut into buckets of >= 8 MiB (one parameter tensor is never split: layer4's two
+  3^3 kernels are 28 MB and 14 MB messages on their own, ready first; the LAST bucket, which
+  cannot overlap with anything, ends up ~4 MB);
 * a post-accumulate-grad hook counts ready parameters per bucket and launches the bucket's
   `all_reduce(async_op=True)` as soon as it is complete -- RCCL runs it on its own HIP stream,
   overlapped with the remaining backward kernels;
@@ -19,7 +20,7 @@ import torch.distributed as dist
 
 
 class BucketedGradAllReduce:
-    def __init__(self, module, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, module, bucket_bytes=8 << 20, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if self.world > 1 and dist.get_backend(process_group) == "gloo":

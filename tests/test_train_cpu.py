@@ -136,3 +136,39 @@ def test_baseline_config0_cpu_plumbing(tmp_path):
     gin.bind_parameter("train.max_steps", 6)
     res2 = train(save_path=str(tmp_path), resume_training=True, run_name="t", run_name_postfix=None, ME=OME)
     assert res2["global_step"] == 6
+
+
+def test_gin_configurable_injection_rules():
+    @gin.configurable
+    def f(a, b=2, c=3):
+        return a, b, c
+
+    @gin.configurable
+    class K:
+        def __init__(self, x=1, y=2):
+            self.x, self.y = x, y
+
+    gin.parse_config("f.b = 20\nf.c = [1,\n  2]\nK.y = 'z'")
+    assert f(1) == (1, 20, [1, 2])       # bound parameters fill what the caller leaves out
+    assert f(1, 5, c=7) == (1, 5, 7)     # explicit arguments always win
+    assert (K().x, K().y, K(y=9).y) == (1, "z", 9)
+    gin.bind_parameter("f.nope", 1)
+    with pytest.raises(gin.GinError):
+        f(1)                             # binding a parameter the configurable does not have
+    with pytest.raises(gin.GinError):
+        gin.parse_config("f.b = undefined_name")
+
+
+def test_coordinate_plan_compilation():
+    """Pure host logic of the prepare-ahead pipeline: request trace -> de-duplicated plan."""
+    from nerf_downstream_amd.minkowski.coords import CoordinateManager
+
+    trace = [("ktable", 1, 1, 3, 1, False), ("stride", 1, 2), ("ktable", 1, 2, 2, 1, False), ("stride", 2, 2),
+             ("ktable", 2, 4, 3, 1, False), ("ktable", 4, 4, 3, 1, False), ("boff", 4),
+             ("ktable", 4, 4, 3, 1, False), ("ktable", 2, 4, 3, 1, True), ("perm", 2, 128), ("stride", 2, 2)]
+    plan = CoordinateManager.compile_plan(trace)
+    assert plan.count(("stride", 2, 2)) == 1 and len(plan) == 8
+    assert ("ktable", 2, 4, 3, 1, True) in plan and ("ktable", 2, 4, 3, 1, False) not in plan  # built transposed once
+    assert plan.index(("stride", 1, 2)) < plan.index(("ktable", 1, 2, 2, 1, False))            # first-use order kept
+    assert CoordinateManager.plan_stride_chain(plan) == (2, 2)
+    assert CoordinateManager.plan_stride_chain(None) == ()
