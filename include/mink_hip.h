@@ -244,6 +244,20 @@ int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int3
                 const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual,
                 float *dgamma, float *dbeta, void *workspace, void *stream);
 
+/* Split form for MinkowskiSyncBatchNorm (train.py:106-107): per-channel sums stay on the device
+ * as doubles so the host can all-reduce them (RCCL) between the passes.
+ *   mink_bn_reduce mode 0: sums = [sum x | sum x^2];  mode 1: [sum g | sum g*xhat] (g masked by y>0
+ *   when y != NULL).  n_total: device double (rows over all ranks). */
+int mink_bn_reduce(int32_t mode, const float *a, const float *b, const float *y, int64_t n, int32_t C,
+                   const float *mean, const float *invstd, double *sums, void *workspace, void *stream);
+int mink_bn_stats_from_sums(const double *sums, const double *n_total, int32_t C, float eps, float momentum,
+                            float *mean, float *invstd, float *running_mean, float *running_var,
+                            void *stream);
+int mink_bn_bwd_from_sums(const float *dy, const float *x, const float *y, int64_t n, int32_t C,
+                          const double *sums, const double *n_total, const float *mean,
+                          const float *invstd, const float *gamma, int32_t relu, float *dx,
+                          float *dresidual, float *scratch2c, void *stream);
+
 /* Fused tail of the stem: y_pool = SumPool(relu(BN(x))) without materialising the normalised
  * [n,C] tensor (bn1 -> relu -> pool, resnet.py:58-64).  `nbr[n_out][K]` is the 2^3 children
  * table, `in2out[n]` the stride map.  Statistics come from mink_bn_stats; the ReLU mask of the

@@ -123,6 +123,43 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double *__re
   dgamma[c] = (float)ss;
 }
 
+// ---- split form used by SyncBatchNorm: partials -> sums[2][C] (double), all-reduced by the host
+__global__ __launch_bounds__(256) void bn_sum_partials_kernel(const double *__restrict__ partial, int nblk, int C,
+                                                              double *__restrict__ sums) {
+  int c;
+  double s, ss;
+  if (!finalize_sums(partial, nblk, C, c, s, ss)) return;
+  sums[c] = s;
+  sums[C + c] = ss;
+}
+
+__global__ void bn_stats_from_sums_kernel(const double *__restrict__ sums, const double *__restrict__ n_total, int C,
+                                          float eps, float momentum, float *__restrict__ mean,
+                                          float *__restrict__ invstd, float *running_mean, float *running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = *n_total;
+  const double m = sums[c] / n;
+  double var = sums[C + c] / n - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// sums (double, possibly all-reduced) -> float dbeta / dgamma scaled for the apply pass
+__global__ void bn_bwd_sums_to_float_kernel(const double *__restrict__ sums, const double *__restrict__ n_total, int C,
+                                            float *__restrict__ dbeta_mean, float *__restrict__ dgamma_mean) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta_mean[c] = (float)(sums[c] / *n_total);
+  dgamma_mean[c] = (float)(sums[C + c] / *n_total);
+}
+
 // y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] )
 __global__ __launch_bounds__(EB) void bn_apply_kernel(const float *__restrict__ x, int64_t n4, int C4,
                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -430,6 +467,48 @@ int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int3
   const int64_t n4 = n * (C >> 2);
   bn_bwd_apply_kernel<<<dim3(ew_grid(n4)), EB, 0, st>>>(dy, x, yr, n4, C >> 2, 1.f / (float)n, mean, invstd, gamma,
                                                        dgamma, dbeta, dx, dresidual);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_bn_reduce(int32_t mode, const float *a, const float *b, const float *y, int64_t n, int32_t C, const float *mean,
+                   const float *invstd, double *sums, void *workspace, void *stream) {
+  REQ_C4(C, "bn_reduce");
+  MINK_REQUIRE((mode == 0 || mode == 1) && n >= 1 && a && sums && workspace, "bn_reduce: bad arguments");
+  MINK_REQUIRE(mode == 0 || (b && mean && invstd), "bn_reduce: mode 1 needs x, mean and invstd");
+  REQ_A16(a, "bn_reduce");
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = 0;
+  int rc = launch_colreduce(mode, a, b, y, n, C, mean, invstd, (double *)workspace, st, &nblk);
+  if (rc) return rc;
+  bn_sum_partials_kernel<<<dim3((unsigned)cdiv(C, 16)), 256, 0, st>>>((const double *)workspace, nblk, C, sums);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_bn_stats_from_sums(const double *sums, const double *n_total, int32_t C, float eps, float momentum, float *mean,
+                            float *invstd, float *running_mean, float *running_var, void *stream) {
+  MINK_REQUIRE(C >= 1 && sums && n_total && mean && invstd, "bn_stats_from_sums: bad arguments");
+  bn_stats_from_sums_kernel<<<dim3((unsigned)cdiv(C, 64)), 64, 0, (hipStream_t)stream>>>(sums, n_total, C, eps, momentum, mean,
+                                                                                       invstd, running_mean, running_var);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_bn_bwd_from_sums(const float *dy, const float *x, const float *y, int64_t n, int32_t C, const double *sums,
+                          const double *n_total, const float *mean, const float *invstd, const float *gamma,
+                          int32_t relu, float *dx, float *dresidual, float *scratch2c, void *stream) {
+  REQ_C4(C, "bn_bwd_from_sums");
+  MINK_REQUIRE(n >= 1 && dy && x && sums && n_total && mean && invstd && gamma && dx && scratch2c,
+               "bn_bwd_from_sums: bad arguments");
+  MINK_REQUIRE(!relu || y, "bn_bwd_from_sums: fused ReLU needs the forward output");
+  hipStream_t st = (hipStream_t)stream;
+  // dbeta/n and dgamma/n as floats; the apply kernel is then called with inv_n = 1
+  bn_bwd_sums_to_float_kernel<<<dim3((unsigned)cdiv(C, 64)), 64, 0, st>>>(sums, n_total, C, scratch2c, scratch2c + C);
+  MINK_CHECK_LAUNCH();
+  const int64_t n4 = n * (C >> 2);
+  bn_bwd_apply_kernel<<<dim3(ew_grid(n4)), EB, 0, st>>>(dy, x, relu ? y : nullptr, n4, C >> 2, 1.f, mean, invstd, gamma,
+                                                       scratch2c + C, scratch2c, dx, dresidual);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

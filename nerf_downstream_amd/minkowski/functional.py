@@ -258,6 +258,75 @@ class BatchNormFunction(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None, None, None, None, gres, None
 
 
+class SyncBatchNormFunction(torch.autograd.Function):
+    """BatchNorm with statistics over all ranks (ME.MinkowskiSyncBatchNorm, reference
+    train.py:106-107): per-channel (sum x, sum x^2, rows) are all-reduced between the reduction and
+    the apply pass; backward all-reduces (sum g, sum g*xhat).  Parameter gradients stay local
+    sums -- the data-parallel gradient all-reduce averages them like every other gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, group):
+        import torch.distributed as dist
+
+        L = lib()
+        x = _f32c(x)
+        n, C = x.shape
+        dev = x.device
+        if residual is not None:
+            residual = _f32c(residual)
+        buf = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        buf[2 * C] = float(n)
+        ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
+        check(L.mink_bn_reduce(0, x.data_ptr(), None, None, n, C, None, None, buf.data_ptr(), ws.data_ptr(), _stream()))
+        dist.all_reduce(buf, group=group)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        check(
+            L.mink_bn_stats_from_sums(
+                buf.data_ptr(), buf[2 * C :].data_ptr(), C, eps, momentum if running_mean is not None else 0.0,
+                mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var), _stream(),
+            )
+        )
+        y = torch.empty_like(x)
+        check(
+            L.mink_bn_apply(
+                x.data_ptr(), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                _ptr(residual), int(relu), y.data_ptr(), _stream(),
+            )
+        )
+        ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma, buf[2 * C :].clone())
+        ctx.relu, ctx.has_res, ctx.group = relu, residual is not None, group
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.distributed as dist
+
+        L = lib()
+        x, y, mean, invstd, gamma, n_total = ctx.saved_tensors
+        gy = _f32c(gy)
+        n, C = x.shape
+        dev = x.device
+        sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
+        check(
+            L.mink_bn_reduce(1, gy.data_ptr(), x.data_ptr(), _ptr(y), n, C, mean.data_ptr(), invstd.data_ptr(),
+                             sums.data_ptr(), ws.data_ptr(), _stream())
+        )
+        dbeta, dgamma = sums[:C].float(), sums[C:].float()  # local sums: averaged later with the other grads
+        dist.all_reduce(sums, group=ctx.group)
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if ctx.has_res else None
+        tmp = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        check(
+            L.mink_bn_bwd_from_sums(
+                gy.data_ptr(), x.data_ptr(), _ptr(y), n, C, sums.data_ptr(), n_total.data_ptr(), mean.data_ptr(),
+                invstd.data_ptr(), gamma.data_ptr(), int(ctx.relu), gx.data_ptr(), _ptr(gres), tmp.data_ptr(), _stream(),
+            )
+        )
+        return gx, dgamma, dbeta, None, None, None, None, gres, None, None
+
+
 class BNReLUSumPoolFunction(torch.autograd.Function):
     """relu(BN(x)) summed over the 2^3 children of every coarse voxel, in one pass over x
     (reference resnet.py:58-64: bn1 -> relu -> pool).  The normalised fine-level tensor -- the

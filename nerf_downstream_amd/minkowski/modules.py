@@ -105,12 +105,46 @@ class MinkowskiBatchNorm(nn.Module):
 
 
 class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
-    """Placeholder for ME.MinkowskiSyncBatchNorm (reference train.py:106-107, off by default:
-    `use_sync_batchnorm=False`, train.py:83).  Statistics stay per rank."""
+    """ME.MinkowskiSyncBatchNorm (reference train.py:106-107; off by default, train.py:83): batch
+    statistics over the voxels of ALL ranks.  Falls back to local statistics when no process
+    group is initialised or in eval mode."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
+        super().__init__(num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats)
+        self.process_group = process_group
+
+    def forward(self, input, relu=False, residual=None):
+        import torch.distributed as dist
+
+        bn = self.bn
+        training = bn.training or not bn.track_running_stats
+        if not (training and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1):
+            return super().forward(input, relu=relu, residual=residual)
+        if bn.track_running_stats and not self.counted_by_parent:
+            bn.num_batches_tracked += 1
+        if residual is not None:
+            input._check(residual)
+        out = Fn.SyncBatchNormFunction.apply(
+            input.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
+            bn.eps, residual.F if residual is not None else None, bool(relu), self.process_group)
+        return SparseTensor(out, input.coordinate_map_key, input.coordinate_manager)
 
     @classmethod
     def convert_sync_batchnorm(cls, module, process_group=None):
-        raise NotImplementedError("SyncBatchNorm is optional in the reference (default off) and not built yet")
+        """Recursively replace every MinkowskiBatchNorm by a MinkowskiSyncBatchNorm sharing its
+        parameters and buffers (same contract as ME / torch.nn.SyncBatchNorm)."""
+        if isinstance(module, MinkowskiBatchNorm) and not isinstance(module, MinkowskiSyncBatchNorm):
+            bn = module.bn
+            new = cls(bn.num_features, bn.eps, bn.momentum, bn.affine, bn.track_running_stats, process_group)
+            new.bn = bn
+            new.counted_by_parent = module.counted_by_parent
+            new.train(module.training)
+            return new
+        for name, child in list(module.named_children()):
+            setattr(module, name, cls.convert_sync_batchnorm(child, process_group))
+        if hasattr(module, "_norms"):  # networks that keep a list of their norm layers
+            module._norms = [m for m in module.modules() if isinstance(m, MinkowskiBatchNorm)]
+        return module
 
 
 class MinkowskiReLU(nn.Module):
@@ -139,7 +173,8 @@ class MinkowskiSumPooling(nn.Module):
         out_key = m.stride(in_key, self.stride)
         nbr, _ = m.kernel_table(in_key, out_key, self.kernel_size, 1)
         i2o = m.stride_map(in_key, out_key)
-        if norm is not None and norm.bn.affine and (norm.bn.training or not torch.is_grad_enabled()):
+        fusable = norm is not None and norm.bn.affine and type(norm) is MinkowskiBatchNorm
+        if fusable and (norm.bn.training or not torch.is_grad_enabled()):
             bn = norm.bn
             training = bn.training or not bn.track_running_stats
             if training and bn.track_running_stats and not norm.counted_by_parent:

@@ -97,3 +97,53 @@ def test_data_parallel_two_ranks_on_card(tmp_path):
     assert torch.equal(r0["g"], r1["g"])
     ref = 0.5 * (torch.load(tmp_path / "local0.pt") + torch.load(tmp_path / "local1.pt"))
     assert torch.allclose(r0["g"], ref, atol=1e-5 * float(ref.abs().max()), rtol=1e-4)
+
+
+def _syncbn_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nerf_downstream_amd import minkowski as ME
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    n, C = 1500, 64
+    x_all = torch.randn(2 * n + 77, C, generator=g) * 1.5 + 0.3
+    w_all = torch.randn(2 * n + 77, C, generator=g)
+    sl = slice(0, n) if rank == 0 else slice(n, 2 * n + 77)  # uneven shards
+    x = x_all[sl].to(dev).requires_grad_(True)
+    coords = torch.zeros(x.shape[0], 4)
+    coords[:, 1] = torch.arange(x.shape[0])
+    m = ME.TensorField(coordinates=coords.to(dev), features=x.detach()).coordinate_manager
+    model = torch.nn.Sequential(ME.MinkowskiBatchNorm(C)).to(dev)
+    with torch.no_grad():
+        model[0].bn.weight.copy_(torch.linspace(0.5, 1.5, C)), model[0].bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+    model = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
+    assert isinstance(model[0], ME.MinkowskiSyncBatchNorm)
+    y = model[0](ME.SparseTensor(x, ME.CoordinateMapKey(1), m), relu=True).F
+    (y * w_all[sl].to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    torch.save({"y": y.detach().cpu(), "dx": x.grad.cpu(), "dw": model[0].bn.weight.grad.cpu(), "db": model[0].bn.bias.grad.cpu(),
+                "rm": model[0].bn.running_mean.cpu(), "rv": model[0].bn.running_var.cpu()}, f"{out}/s{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batch_norm_two_ranks(tmp_path):
+    """MinkowskiSyncBatchNorm over 2 ranks == BatchNorm1d over the concatenated rows."""
+    mp.spawn(_syncbn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    g = torch.Generator().manual_seed(0)
+    n, C = 1500, 64
+    x = (torch.randn(2 * n + 77, C, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    w = torch.randn(2 * n + 77, C, generator=g)
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, C)), bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+    y = torch.relu(bn(x))
+    (y * w).sum().backward()
+    assert torch.allclose(torch.cat([r0["y"], r1["y"]]), y, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(torch.cat([r0["dx"], r1["dx"]]), x.grad, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(r0["dw"] + r1["dw"], bn.weight.grad, atol=2e-3, rtol=1e-4)  # local sums add up
+    assert torch.allclose(r0["db"] + r1["db"], bn.bias.grad, atol=2e-3, rtol=1e-4)
+    assert torch.allclose(r0["rm"], bn.running_mean, atol=1e-6) and torch.allclose(r1["rv"], bn.running_var, atol=1e-5)
