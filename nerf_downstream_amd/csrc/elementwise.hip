@@ -44,13 +44,36 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
         s0.x += v.x, s0.y += v.y, s0.z += v.z, s0.w += v.w;
         s1.x += v.x * v.x, s1.y += v.y * v.y, s1.z += v.z * v.z, s1.w += v.w * v.w;
       } else if (MODE == 2) {
-        const float4 x = ld4(b + off);
-        float4 g = ld4(a + (int64_t)in2out[row] * C + 4 * c4);
-        const float4 xh = make_float4((x.x - mu.x) * is.x, (x.y - mu.y) * is.y, (x.z - mu.z) * is.z, (x.w - mu.w) * is.w);
-        g.x = xh.x * ga.x + be.x > 0.f ? g.x : 0.f, g.y = xh.y * ga.y + be.y > 0.f ? g.y : 0.f;
-        g.z = xh.z * ga.z + be.z > 0.f ? g.z : 0.f, g.w = xh.w * ga.w + be.w > 0.f ? g.w : 0.f;
-        s0.x += g.x, s0.y += g.y, s0.z += g.z, s0.w += g.w;
-        s1.x += g.x * xh.x, s1.y += g.y * xh.y, s1.z += g.z * xh.z, s1.w += g.w * xh.w;
+        // four rows per trip: the dependent (index -> pooled gradient) loads of all four are in
+        // flight together, otherwise this pass is latency-bound
+        const int64_t stride = (int64_t)gridDim.x * rlanes;
+        int64_t rows[4];
+        int par[4];
+        float4 xs[4], gs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          rows[u] = row + u * stride;
+          par[u] = in2out[rows[u] < n ? rows[u] : row];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t r = rows[u] < n ? rows[u] : row;
+          xs[u] = ld4(b + r * C + 4 * c4);
+          gs[u] = ld4(a + (int64_t)par[u] * C + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (rows[u] < n) {
+            const float4 x = xs[u];
+            float4 g = gs[u];
+            const float4 xh = make_float4((x.x - mu.x) * is.x, (x.y - mu.y) * is.y, (x.z - mu.z) * is.z, (x.w - mu.w) * is.w);
+            g.x = xh.x * ga.x + be.x > 0.f ? g.x : 0.f, g.y = xh.y * ga.y + be.y > 0.f ? g.y : 0.f;
+            g.z = xh.z * ga.z + be.z > 0.f ? g.z : 0.f, g.w = xh.w * ga.w + be.w > 0.f ? g.w : 0.f;
+            s0.x += g.x, s0.y += g.y, s0.z += g.z, s0.w += g.w;
+            s1.x += g.x * xh.x, s1.y += g.y * xh.y, s1.z += g.z * xh.z, s1.w += g.w * xh.w;
+          }
+        }
+        row += 3 * stride;  // the loop header adds the fourth stride
       } else {
         float4 g = ld4(a + off);
         const float4 x = ld4(b + off);
