@@ -147,3 +147,19 @@ def test_sync_batch_norm_two_ranks(tmp_path):
     assert torch.allclose(r0["dw"] + r1["dw"], bn.weight.grad, atol=2e-3, rtol=1e-4)  # local sums add up
     assert torch.allclose(r0["db"] + r1["db"], bn.bias.grad, atol=2e-3, rtol=1e-4)
     assert torch.allclose(r0["rm"], bn.running_mean, atol=1e-6) and torch.allclose(r1["rv"], bn.running_var, atol=1e-5)
+
+
+def test_train_cli_with_dataloader_workers(tmp_path):
+    """The CLI entry point end to end on the GPU: gin files, DataLoader worker processes running
+    collate_mink (CPU-only, forked after HIP is initialised in the parent), checkpoints."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "nerf_downstream_amd.co3d_3d.train", "--ginc", f"{CFG}/co3d_cls.gin", "--ginc", f"{CFG}/resnet14.gin",
+           "--ginc", f"{CFG}/synthetic_cls.gin", "--save_path", str(tmp_path), "--run_name", "cli", "--gpus", "1", "--seed", "5",
+           "--ginb", "train.max_steps=6", "--ginb", "train.val_every_n_steps=6", "--ginb", "train.log_every_n_steps=2",
+           "--ginb", "SparseVoxelDataset.grid=32", "--ginb", "SparseVoxelDataset.num_samples=32", "--ginb", "train.batch_size=4",
+           "--ginb", "train.val_batch_size=4", "--ginb", "train.train_num_workers=2", "--ginb", "train.val_num_workers=2", "--ginb", "train.lr=0.01"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "val/acc1" in r.stdout
+    assert (tmp_path / "cli" / "last.ckpt").exists() and (tmp_path / "cli" / "metrics.csv").exists()
