@@ -251,7 +251,7 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "voxels/sec fwd+bwd Mink-ResNet14 on CO3D plenoxels",
+            "metric": f"voxels/sec fwd+bwd Mink-{args.model} on CO3D plenoxels",
             "value": vox.item() / tmax.item(),
             "unit": "voxels/s",
             "n_gpus": world,

@@ -158,6 +158,14 @@ class ConvolutionFunction(torch.autograd.Function):
     def forward(ctx, x, kernel, table_fn, same_map):
         x = _f32c(x)
         w = _f32c(kernel)
+        cin = x.shape[1]
+        ctx.cin = cin
+        if cin % 4 and not ctx.needs_input_grad[0]:
+            # e.g. the reference default features=["sh"] (27 channels): one zero column puts the
+            # rows on 16-byte boundaries so the vectorised / flattened-K kernels apply
+            pad = 4 - cin % 4
+            x = torch.nn.functional.pad(x, (0, pad))
+            w = torch.nn.functional.pad(w, (0, 0, 0, pad))
         nbr = table_fn(False)[0]
         ctx.save_for_backward(x, w)
         ctx.table_fn, ctx.same_map, ctx.nbr = table_fn, same_map, nbr
@@ -192,6 +200,8 @@ class ConvolutionFunction(torch.autograd.Function):
                 main.wait_stream(side)
             else:
                 gw = conv_wgrad(x, gy, ctx.nbr, w.shape)
+            if gw.shape[1] != ctx.cin:  # drop the gradient of the zero-padded input channels
+                gw = gw[:, : ctx.cin].contiguous()
         return gx, gw, None, None
 
 
