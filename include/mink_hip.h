@@ -193,10 +193,11 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
                           void *stream);
 
 /* Weight gradient dW[k] = X[nbr[.][k]]^T @ dY, split over row blocks and reduced
- * deterministically (no atomics).  workspace >= mink_conv_wgrad_workspace_bytes(). */
+ * deterministically (no atomics).  x has n_in rows (every nbr entry is -1 or in [0, n_in)).
+ * workspace >= mink_conv_wgrad_workspace_bytes(). */
 int64_t mink_conv_wgrad_workspace_bytes(int64_t n_out, int32_t K, int32_t cin, int32_t cout);
-int mink_conv_wgrad(const float *x, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
-                    const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace,
+int mink_conv_wgrad(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *dy, int32_t ldy,
+                    int32_t cout, const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace,
                     void *stream);
 
 /* ------------------------------------------------------------------ pooling / reductions

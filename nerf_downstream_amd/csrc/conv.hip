@@ -684,6 +684,7 @@ struct WgradParams {
   float *out;  // dw (nsplit == 1) or workspace [nsplit][K][cin][cout]
   int64_t n_out, rows_per_split;
   int ldx, cin, ldy, cout, K, ct_tiles, ngroups, ablate;
+  unsigned x_bytes, dy_bytes, nbr_bytes;  // streaming kernel only (buffer descriptors)
 };
 
 // G: offsets per workgroup.  NARROW: cin <= 32 -- the x tile is 32 floats wide and the two
@@ -860,6 +861,147 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   }
 }
 
+// ----------------------------------------------------------------- streaming wgrad (cin <= 32)
+// The stem's weight gradient (28 -> 64 over ~8e5 rows, the largest kernel of a training step)
+// as a plain streamed GEMM  dW[k] (32 x 32 per wave) += X[nbr[.][k]]^T (32 x 2) * dY (2 x 32):
+// the MFMA operands are loaded straight from global memory in the 32x32x2 register layout
+// (a half-wave reads one 128-byte row segment), so there is no LDS tile, no pair list and no
+// barrier in the loop.  Missing neighbours and rows past the end become out-of-range buffer
+// offsets, which a buffer load returns as 0:  offset = (nb & 0xFFFFFF) * 4 ldx + column is
+// >= the size of x for nb = -1 as long as n_in < 2^24 and ldx < 64 (checked by the launcher).
+// D row pairs of operands and D pairs of neighbour rows are in flight per wave.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *ptr, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ptr), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
+  static_assert(D % 2 == 0, "the neighbour staging ring has two slots");
+  constexpr int G = 9;                   // K == 27: three groups of nine offsets
+  constexpr unsigned OOB = 0x80000000u;  // beyond any descriptor this kernel is launched with
+  __shared__ float sR[2 * 16 * 64];
+  // wave-private staging of the neighbour entries of one row pair: one lane per entry loads
+  // them, every lane of the half reads them back (LDS broadcast) -- a same-address vector load
+  // would cost as much L1 return bandwidth as the x rows themselves
+  __shared__ __attribute__((aligned(16))) unsigned sN[4][2][2][32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wa = wave >> 1, h = lane >> 5, col = lane & 31;
+  const int grp = blockIdx.x % p.ngroups;
+  const int co0 = (blockIdx.x / p.ngroups) * WT;
+  const int k0 = grp * G;
+  constexpr int ng = G;
+  const int64_t rbeg = (int64_t)blockIdx.y * p.rows_per_split;
+  const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rd = make_rsrc(p.dy, p.dy_bytes),
+                               rn = make_rsrc(p.nbr, p.nbr_bytes);
+  const unsigned ldx4 = 4u * p.ldx, ldy4 = 4u * p.ldy, K4 = 4u * p.K;
+  // lanes beyond cin / cout only feed rows / columns of the product that are never stored
+  const unsigned xcol = 4u * min(col, p.cin - 1);
+  const unsigned dcol = 4u * min(co0 + 32 * wn + col, p.cout - 1);
+  const unsigned ncol = col < G ? 4u * (k0 + col) : OOB;
+
+  f32x16 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = (f32x16){0};
+  float xa[D][G], db[D];
+  unsigned nraw[D];  // lane (h, col < 9): nbr[R0 + h][k0 + col] of a pair still to be staged
+
+  // this wave's q-th pair covers rows R0, R0 + 1 (lane half h takes R0 + h); the two wave
+  // rows interleave their pairs
+  const int64_t npairs = (rend - rbeg + 1) >> 1;
+  const int nq = (int)((npairs + 1 - wa) >> 1);
+  auto row_of = [&](int q) { return rbeg + 2 * (2 * (int64_t)q + wa) + h; };
+  auto load_raw = [&](int s, int q) {  // rows past the end read as entry 0; their x offset is forced out of range below
+    const int64_t R = row_of(q);
+    nraw[s] = __builtin_amdgcn_raw_buffer_load_b32(rn, (int)(R < rend ? (unsigned)R * K4 + ncol : OOB), 0, 0);
+  };
+  auto stash = [&](int s, int slot) {
+    sN[wave][slot][h][col] = nraw[s];  // lanes col >= 9 store padding: no exec-mask branch in the loop
+  };
+  auto load_dy = [&](int s, int q) {
+    const int64_t R = row_of(q);
+    db[s] = buf_load(rd, R < rend ? (unsigned)R * ldy4 + dcol : OOB);
+  };
+  auto load_xs = [&](int s, int slot, int q, auto &&between) {  // the nine x values of pair q
+    const uint4 n0 = *reinterpret_cast<const uint4 *>(&sN[wave][slot][h][0]);
+    const uint4 n1 = *reinterpret_cast<const uint4 *>(&sN[wave][slot][h][4]);
+    const unsigned n2 = sN[wave][slot][h][8];
+    const unsigned nbv[G] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2};
+    const unsigned xbase = row_of(q) < rend ? xcol : OOB;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      between(g);
+      xa[s][g] = buf_load(rx, __umul24(nbv[g], ldx4) + xbase);
+    }
+  };
+
+  if (rbeg < rend) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) load_raw(s, s);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < D; ++s) {  // same load order as the loop body: the vmcnt waits there are FIFO distances
+      stash(s, s & 1);
+      load_xs(s, s & 1, s, [](int) {});
+      load_dy(s, s);
+      load_raw(s, s + D);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    stash(0, 0);  // pair D
+    for (int q0 = 0; q0 < nq; q0 += D) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {  // pair q0 + s from slot s; pairs past nq were loaded as zeros
+        const float b = db[s];
+        float a[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) a[g] = xa[s][g];
+        load_xs(s, s & 1, q0 + s + D, [&](int g) {
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g], b, acc[g], 0, 0, 0);
+        });
+        load_dy(s, q0 + s + D);
+        stash((s + 1) % D, (s + 1) & 1);  // pair q0 + s + D + 1, loaded D - 1 pairs ago
+        load_raw(s, q0 + s + 2 * D);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // VALU (offset)
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the slots (and with them the load FIFO) in program order
+      }
+    }
+  }
+
+  // ---- epilogue: add the two wave rows through LDS, store the partial slab
+  float *dst = p.out + (int64_t)blockIdx.y * p.K * p.cin * p.cout;
+  const int co = co0 + 32 * wn + col;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (g < ng) {
+      const int k = k0 + g;
+      __syncthreads();
+      if (wa == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sR[(wn * 16 + r) * 64 + lane] = acc[g][r];
+      }
+      __syncthreads();
+      if (wa == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = acc[g][r] + sR[(wn * 16 + r) * 64 + lane];
+          if (ci < p.cin && co < p.cout) dst[((int64_t)k * p.cin + ci) * p.cout + co] = v;
+        }
+      }
+    }
+  }
+}
+
 // out[i] = sum_z ws[z][i]: 64 outputs x 4 slab lanes per workgroup (fixed order -> deterministic)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ ws, int64_t count, int nslab,
                                                           float *__restrict__ out) {
@@ -873,6 +1015,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
   __syncthreads();
   if (lane == 0 && i < count) out[i] = (s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o]);
 }
+
+static int g_wgrad_stream = 1;
 
 struct WgradPlan {
   int G, ngroups, nsplit;
@@ -926,6 +1070,7 @@ int mink_conv_set_stagger(int units) {
   g_stagger = units & 255;
   g_pipeline = !(units & 256);  // bit 8: fall back to the un-pipelined kernel (A/B benchmarks)
   g_flat = !(units & 512);      // bit 9: no flattened-K stem path
+  g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
   return old;
 }
 
@@ -1004,9 +1149,9 @@ int64_t mink_conv_wgrad_workspace_bytes(int64_t n_out, int32_t K, int32_t cin, i
   return pl.nsplit > 1 ? (int64_t)pl.nsplit * K * cin * cout * 4 : 0;
 }
 
-int mink_conv_wgrad(const float *x, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
+int mink_conv_wgrad(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
                     const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace, void *stream) {
-  MINK_REQUIRE(K >= 1 && K <= KMAX && cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0,
+  MINK_REQUIRE(K >= 1 && K <= KMAX && cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0 && n_in >= 0,
                "wgrad: bad shape");
   MINK_REQUIRE(dw, "wgrad: NULL dw");
   hipStream_t st = (hipStream_t)stream;
@@ -1024,7 +1169,12 @@ int mink_conv_wgrad(const float *x, int32_t ldx, int32_t cin, const float *dy, i
   p.ngroups = pl.ngroups;
   p.ablate = g_stagger;
   const dim3 grid((unsigned)(pl.ngroups * cdiv(cin, WT) * p.ct_tiles), (unsigned)pl.nsplit);
-  if (pl.G == 9) launch_wgrad<9>(p, grid, st);
+  const int64_t xb = 4 * n_in * ldx, db = 4 * n_out * ldy, nb = 4 * n_out * K;
+  p.x_bytes = (unsigned)xb, p.dy_bytes = (unsigned)db, p.nbr_bytes = (unsigned)nb;
+  const bool stream_ok = K == 27 && cin <= 32 && ldx < 64 && n_in < (1 << 24) && xb < (1ll << 31) && db < (1ll << 31) &&
+                         nb < (1ll << 31);  // what the buffer-offset arithmetic of the streaming kernel assumes
+  if (pl.G == 9 && stream_ok && g_wgrad_stream) wgrad_stream_kernel<4><<<grid, 256, 0, st>>>(p);
+  else if (pl.G == 9) launch_wgrad<9>(p, grid, st);
   else if (pl.G == 3) launch_wgrad<3>(p, grid, st);
   else launch_wgrad<1>(p, grid, st);
   MINK_CHECK_LAUNCH();

@@ -123,7 +123,7 @@ def conv_wgrad(x, dy, nbr, kernel_shape):
     with _timed(f"wgrad[{n_out}x{K}:{cin}->{cout}]", kind="wgrad", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr):
         check(
             L.mink_conv_wgrad(
-                x.data_ptr(), x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K,
+                x.data_ptr(), x.shape[0], x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K,
                 dw.data_ptr(), ws.data_ptr(), _stream(),
             )
         )

@@ -61,11 +61,47 @@ if which == "wablate":
     nbr, _ = m.kernel_table(k1, k1, 3, 1)
     xin = x.F.contiguous()
     gy = torch.randn(nbr.shape[0], 64, device=dev)
-    for st in (0, 0, 64, 128, 192, 0):
+    for st in (0, 1024, 0, 1024):
         lib().mink_conv_set_stagger(st)
         t = timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64)), reps)
         print(f"ablate {st}: stem wgrad {t*1e3:8.1f} us")
     lib().mink_conv_set_stagger(0)
+    a = Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64))
+    lib().mink_conv_set_stagger(1024)
+    b = Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64))
+    lib().mink_conv_set_stagger(0)
+    print("stream vs tiled wgrad: max |diff|", float((a - b).abs().max()), "max |ref|", float(b.abs().max()))
+if which == "sparsity":
+    nbr, _ = m.kernel_table(k1, k1, 3, 1)
+    v = nbr >= 0
+    n = v.shape[0] // 2 * 2
+    print("rows", v.shape[0], "density", float(v.float().mean()))
+    for grp in (2, 4, 8, 16, 32):
+        nn = v.shape[0] // grp * grp
+        anyv = v[:nn].view(-1, grp, 27).any(dim=1)
+        print(f"group of {grp} consecutive rows: fraction of (group, offset) with any neighbour {float(anyv.float().mean()):.3f}")
+    c = m.levels[1].coords if hasattr(m.levels[1], "coords") else None
+    if c is not None:
+        print("first coords", c[:12].tolist())
+if which == "pad":
+    from nerf_downstream_amd._lib import lib
+    nbr, _ = m.kernel_table(k1, k1, 3, 1)
+    gy = torch.randn(nbr.shape[0], 64, device=dev)
+    w = torch.randn(27, 28, 64, device=dev) * 0.05
+    xc = x.F.contiguous()
+    xp = torch.zeros(xc.shape[0], 32, device=dev)
+    xp[:, :28] = xc
+    xp = xp[:, :28]
+    for name, xin in (("ldx=28", xc), ("ldx=32", xp)):
+        for st in (1024, 0, 2048):
+            lib().mink_conv_set_stagger(st)
+            t = timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64)), reps)
+            print(f"{name} mode {st}: stem wgrad {t*1e3:8.1f} us")
+        lib().mink_conv_set_stagger(0)
+        t = timeit(lambda: Fn.gather_gemm(xin, w, nbr, 64), reps)
+        print(f"{name}: stem fwd {t*1e3:8.1f} us")
+    ya = Fn.gather_gemm(xc, w, nbr, 64); yb = Fn.gather_gemm(xp, w, nbr, 64)
+    print("fwd diff", float((ya - yb).abs().max()))
 if which in ("stem", "all"):
     bench_layer("stem", x.F.contiguous(), k1, k1, 3, 28, 64, 1)
 if which in ("l1", "l4", "all"):

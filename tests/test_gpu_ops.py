@@ -211,3 +211,40 @@ def test_fused_bn_relu_sumpool(oracle_maps):
     assert torch.allclose(bn_a.bn.weight.grad, bn_b.bn.weight.grad, atol=1e-3, rtol=1e-4)
     assert torch.allclose(bn_a.bn.bias.grad, bn_b.bn.bias.grad, atol=1e-3, rtol=1e-4)
     assert torch.allclose(bn_a.bn.running_var, bn_b.bn.running_var) and int(bn_a.bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("cin,ldx,drop", [(28, 28, 0), (28, 32, 1), (20, 20, 3), (32, 32, 0)])
+def test_stem_wgrad_streaming(cin, ldx, drop):
+    """The streaming weight-gradient kernel (K = 27, cin <= 32, >= ~44k rows; conv.hip
+    wgrad_stream_kernel) against the tiled LDS kernel and an fp64 torch restatement of
+    dW[k] = X[nbr[:, k]]^T dY on the same neighbour table.  `drop` trims rows so the row count is
+    odd / not a tile multiple; ldx > cin exercises a padded feature matrix."""
+    from nerf_downstream_amd import minkowski as ME
+    from nerf_downstream_amd._lib import lib
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    coords, feats = batch_scenes([11, 12, 13], grid=80, cin=4)
+    x = ME.TensorField(coordinates=coords.cuda(), features=feats.cuda()).sparse()
+    m, key = x.coordinate_manager, x.coordinate_map_key
+    nbr, _ = m.kernel_table(key, key, 3, 1)
+    n = nbr.shape[0] - drop
+    assert n >= 44000, n
+    nbr = nbr[:n].contiguous()
+    torch.manual_seed(cin)
+    xin = torch.randn(x.F.shape[0], ldx, device="cuda")[:, :cin]
+    dy = torch.randn(n, 64, device="cuda")
+    got = Fn.conv_wgrad(xin, dy, nbr, (27, cin, 64))
+    old = lib().mink_conv_set_stagger(1024)
+    try:
+        tiled = Fn.conv_wgrad(xin, dy, nbr, (27, cin, 64))
+    finally:
+        lib().mink_conv_set_stagger(old)
+    ref = torch.zeros(27, cin, 64, dtype=torch.float64, device="cuda")
+    for k in range(27):
+        idx = nbr[:, k].long()
+        ok = idx >= 0
+        ref[k] = xin[idx[ok]].double().t() @ dy[ok].double()
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * scale   # fp32 sums of ~1e4 O(1) products
+    assert float((tiled.double() - ref).abs().max()) <= 2e-5 * scale
+    assert torch.equal(got, Fn.conv_wgrad(xin, dy, nbr, (27, cin, 64)))  # deterministic
