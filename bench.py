@@ -183,7 +183,7 @@ def main():
     torch.manual_seed(777)  # same initial weights on every rank (reference: pl.seed_everything)
     model = get_model(args.model, args.in_channel, args.num_classes).to(dev)
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=dev.type == "cuda")
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=200000)
     reducer = BucketedGradAllReduce(model, bucket_bytes=int(os.environ.get("BENCH_BUCKET_BYTES", 8 << 20))) if world > 1 else None  # N=1: autograd hands gradients over without a copy
 

@@ -28,7 +28,11 @@ OPTIMIZERS = {c.__name__: c for c in (SGD, Adam, AdamW)}
 def get_optimizer(optimizer_name, parameters, lr, weight_decay):
     if optimizer_name not in OPTIMIZERS:
         raise ValueError(f"optimizer {optimizer_name} not recognized in {sorted(OPTIMIZERS)}.")
-    return OPTIMIZERS[optimizer_name](parameters, lr=lr, weight_decay=weight_decay)
+    parameters = list(parameters)
+    kw = {}
+    if optimizer_name == "SGD" and parameters and all(p.is_cuda for p in parameters):
+        kw["fused"] = True  # same update rule, one multi-tensor kernel instead of four foreach passes
+    return OPTIMIZERS[optimizer_name](parameters, lr=lr, weight_decay=weight_decay, **kw)
 
 
 @gin.configurable

@@ -1017,6 +1017,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
 }
 
 static int g_wgrad_stream = 1;
+static int g_wgrad_force = 0;  // bits 0-3: G code, bits 4..: row splits (scripts/kbench.py wsweep)
 
 struct WgradPlan {
   int G, ngroups, nsplit;
@@ -1031,9 +1032,14 @@ static WgradPlan wgrad_plan(int64_t n_out, int K, int cin, int cout) {
   pl.G = 1;
   if (K >= 9 && tiles * cdiv(K, 9) * row_tiles >= 1024) pl.G = 9;
   else if (K >= 3 && tiles * cdiv(K, 3) * row_tiles >= 1024) pl.G = 3;
+  const bool tiny = row_tiles <= 4 && tiles * K >= 512;  // few rows, many weight tiles: one workgroup per (tile, offset), no slabs
+  if (tiny) pl.G = 1;
+  if (g_wgrad_force & 0xF) pl.G = (g_wgrad_force & 0xF) == 1 ? 1 : (g_wgrad_force & 0xF) == 2 ? 3 : 9;  // tuning hook
   pl.ngroups = (int)cdiv(K, pl.G);
   const int64_t xy = tiles * pl.ngroups;
   int64_t z = cdiv(512, xy);  // ~2 resident workgroups per CU: fewer partial slabs to write and reduce
+  if (tiny) z = 1;
+  if (g_wgrad_force >> 4) z = g_wgrad_force >> 4;
   if (z > row_tiles) z = row_tiles;
   if (z < 1) z = 1;
   pl.rows_per_split = align_up(cdiv(n_out, z), WROWS);
@@ -1071,6 +1077,7 @@ int mink_conv_set_stagger(int units) {
   g_pipeline = !(units & 256);  // bit 8: fall back to the un-pipelined kernel (A/B benchmarks)
   g_flat = !(units & 512);      // bit 9: no flattened-K stem path
   g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
+  g_wgrad_force = (units >> 12) & 0xFFFF;  // bits 12-15: force G (1, 3, 9), bits 16-27: force the row split count
   return old;
 }
 
@@ -1080,14 +1087,34 @@ int mink_conv_set_math(int mode) {
   return old;
 }
 
-int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout) {
+int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_classes) {
   if (n_out <= 0 || K <= 1) return 1;
   const int64_t tiles = cdiv(n_out, BM) * cdiv(cout, BN);
-  int64_t want = cdiv(768, tiles);
-  if (want < 1) want = 1;
-  if (want > K) want = K;
-  const int64_t kper = cdiv(K, want);
-  return (int)cdiv(K, kper);
+  if (tiles >= 768) return 1;
+  // Small row counts: split the offsets over gridDim.z.  Measured on the ResNet layers (kbench
+  // ksweep): the best split puts just under one resident round (2 workgroups x 256 CUs) of
+  // workgroups on the chip; with more than 256 tiles it is the split that best fills whole
+  // rounds, at ~1% per extra slab for the partial-sum write + reduce (the slabs stay in MALL).
+  // A class-permuted dgrad (row_classes) has ~K/8 live offsets per tile and wants no split there.
+  const int64_t slab_cap = (128ll << 20) / (4 * n_out * cout);  // keep the slabs cache resident
+  int best = 1;
+  double best_score = -1.0;
+  for (int kper = K; kper >= 1; --kper) {
+    const int zs = (int)cdiv(K, kper);
+    if (kper > 1 && cdiv(K, kper - 1) == zs) continue;  // a smaller kper gives the same split with less work
+    if (zs > 1 && zs > slab_cap) break;
+    const int64_t blocks = tiles * zs;
+    double score;
+    if (tiles <= 256) {  // the largest split within one round
+      score = blocks <= 512 ? (double)blocks : 0.0;
+      if (row_classes && zs == 3) score = 0.0;  // thirds (one dz plane each) cut the parity classes badly,
+      if (row_classes && zs == 4 && blocks <= 640) score = (double)blocks;  // quarters slightly over a round are fine
+    }
+    else if (row_classes) score = zs == 1;
+    else score = zs > 7 ? 0.0 : (double)blocks / (512.0 * cdiv(blocks, 512)) - 0.01 * zs;
+    if (score > best_score) best_score = score, best = zs;
+  }
+  return best;
 }
 
 int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,

@@ -94,13 +94,17 @@ class _timed:
 
 
 # ------------------------------------------------------------------------- convolution
+_FORCE_KSPLIT = 0  # benchmarking hook (scripts/kbench.py ksweep)
+
+
 def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, row_perm=None):
     """y[o] = sum_k x[nbr[o,k]] @ W[k] (+bias) on the fp32 matrix cores."""
     L = lib()
     n_out, K = nbr.shape
     cin = x.shape[1]
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
-    ksplit = int(L.mink_conv_plan_ksplit(n_out, K, cout))
+    n_rows = n_out if row_perm is None else row_perm.numel()
+    ksplit = _FORCE_KSPLIT or int(L.mink_conv_plan_ksplit(n_rows, K, cout, int(row_perm is not None)))
     ws = _scratch(4 * ksplit * n_out * cout, x.device, "splitk") if ksplit > 1 else None
     tag = f"{'dgrad' if w_transposed else 'fwd'}[{n_out}x{K}:{cin}->{cout}]"
     with _timed(tag, kind="gather_gemm", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr, ksplit=ksplit):

@@ -71,6 +71,62 @@ if which == "wablate":
     b = Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64))
     lib().mink_conv_set_stagger(0)
     print("stream vs tiled wgrad: max |diff|", float((a - b).abs().max()), "max |ref|", float(b.abs().max()))
+if which == "ksweep":
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    for ts in (2, 4, 8, 16):
+        cin, cout = chans[ts], chans[ts * 2]
+        for name, ik, ok, ci, stride in ((f"l@{ts}.c1", keys[ts], keys[ts * 2], cin, 2), (f"l@{ts*2}.c2", keys[ts * 2], keys[ts * 2], cout, 1)):
+            nbr, nbr_t = m.kernel_table(ik, ok, 3, 1, transposed=(stride != 1))
+            xin = torch.randn(m.levels[ts if stride == 2 else ts * 2].n, ci, device=dev)
+            w = torch.randn(27, ci, cout, device=dev) * 0.05
+            res = []
+            for zs in sorted({-(-27 // kper) for kper in range(1, 28)}):
+                Fn._FORCE_KSPLIT = zs
+                t = timeit(lambda: Fn.gather_gemm(xin, w, nbr, cout), reps)
+                res.append((zs, t * 1e3))
+            Fn._FORCE_KSPLIT = 0
+            t0 = timeit(lambda: Fn.gather_gemm(xin, w, nbr, cout), reps) * 1e3
+            print(f"{name} fwd n_out={nbr.shape[0]} {ci}->{cout} planner={t0:.1f}us | " + " ".join(f"{z}:{t:.0f}" for z, t in res))
+            if stride == 2:
+                gy = torch.randn(nbr.shape[0], cout, device=dev)
+                wt = w.transpose(1, 2).contiguous()
+                perm = m.class_perm(ik)
+                res = []
+                for zs in sorted({-(-27 // kper) for kper in range(1, 28)}):
+                    Fn._FORCE_KSPLIT = zs
+                    t = timeit(lambda: Fn.gather_gemm(gy, wt, nbr_t, ci, row_perm=perm), reps)
+                    res.append((zs, t * 1e3))
+                Fn._FORCE_KSPLIT = 0
+                t0 = timeit(lambda: Fn.gather_gemm(gy, wt, nbr_t, ci, row_perm=perm), reps) * 1e3
+                print(f"{name} dgrad n_in={xin.shape[0]} {cout}->{ci} planner={t0:.1f}us | " + " ".join(f"{z}:{t:.0f}" for z, t in res))
+if which == "wsweep":
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    for ts in (2, 4, 8, 16):
+        cin, cout = chans[ts], chans[ts * 2]
+        for name, ik, ok, ci, stride in ((f"l@{ts}.c1", keys[ts], keys[ts * 2], cin, 2), (f"l@{ts*2}.c2", keys[ts * 2], keys[ts * 2], cout, 1)):
+            nbr, _ = m.kernel_table(ik, ok, 3, 1)
+            xin = torch.randn(m.levels[ts if stride == 2 else ts * 2].n, ci, device=dev)
+            gy = torch.randn(nbr.shape[0], cout, device=dev)
+            lib().mink_conv_set_stagger(0)
+            t0 = timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, ci, cout)), reps) * 1e3
+            out = []
+            for gcode, G in ((1, 1), (2, 3), (3, 9)):
+                for z in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96):
+                    if z > -(-nbr.shape[0] // 128):
+                        continue
+                    lib().mink_conv_set_stagger((gcode << 12) | (z << 16))
+                    t = timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, ci, cout)), reps) * 1e3
+                    out.append((t, G, z))
+            lib().mink_conv_set_stagger(0)
+            out.sort()
+            print(f"{name} wgrad n_out={nbr.shape[0]} {ci}->{cout} planner={t0:.1f}us best: " + " ".join(f"G{G}z{z}:{t:.0f}" for t, G, z in out[:6]))
 if which == "sparsity":
     nbr, _ = m.kernel_table(k1, k1, 3, 1)
     v = nbr >= 0

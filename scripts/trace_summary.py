@@ -6,7 +6,7 @@ import glob
 import sys
 
 d, steps = sys.argv[1], int(sys.argv[2])
-f = glob.glob(f"{d}/*/*kernel_trace.csv")[0]
+f = (glob.glob(f"{d}/*/*kernel_trace.csv") + glob.glob(f"{d}/*kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 agg = collections.defaultdict(list)
 for r in rows:

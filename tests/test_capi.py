@@ -26,8 +26,8 @@ def test_header_symbols_exported_and_bound():
     assert handle.mink_abi_version() == 1
     # pure host helpers can run without a GPU
     assert handle.mink_table_capacity(1000) == 2048
-    assert handle.mink_conv_plan_ksplit(1_000_000, 27, 64) == 1
-    assert handle.mink_conv_plan_ksplit(512, 27, 512) > 1
+    assert handle.mink_conv_plan_ksplit(1_000_000, 27, 64, 0) == 1
+    assert handle.mink_conv_plan_ksplit(512, 27, 512, 0) > 1
     assert handle.mink_unique_workspace_bytes(1000) > 5000
 
 

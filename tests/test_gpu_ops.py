@@ -248,3 +248,45 @@ def test_stem_wgrad_streaming(cin, ldx, drop):
     assert float((got.double() - ref).abs().max()) <= 2e-5 * scale   # fp32 sums of ~1e4 O(1) products
     assert float((tiled.double() - ref).abs().max()) <= 2e-5 * scale
     assert torch.equal(got, Fn.conv_wgrad(xin, dy, nbr, (27, cin, 64)))  # deterministic
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_split_k_every_split_matches_unsplit(stride):
+    """Every offset split the planner can return (gridDim.z = 1..27, including splits whose last
+    slice is short) gives the un-split result for forward, same-map dgrad (flipped offsets) and
+    the class-permuted stride-2 dgrad."""
+    from nerf_downstream_amd import minkowski as ME
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    coords, feats = batch_scenes([21, 22], grid=28, cin=64)
+    x = ME.TensorField(coordinates=coords.cuda(), features=feats.cuda()).sparse()
+    m, k_in = x.coordinate_manager, x.coordinate_map_key
+    k_out = m.stride(k_in, stride)
+    nbr, nbr_t = m.kernel_table(k_in, k_out, 3, 1, transposed=(stride != 1))
+    torch.manual_seed(stride)
+    w = torch.randn(27, 64, 128, device="cuda") * 0.05
+    wt = w.transpose(1, 2).contiguous()
+    gy = torch.randn(nbr.shape[0], 128, device="cuda")
+    perm = m.class_perm(k_in) if stride == 2 else None
+
+    def run():
+        y = Fn.gather_gemm(x.F, w, nbr, 128)
+        if stride == 1:  # the two forms of the data gradient: explicit W^T, and W read transposed in place
+            dx = Fn.gather_gemm(gy, wt, nbr, 64, flip_k=True)
+            dx_t = Fn.gather_gemm(gy, w, nbr, 64, w_transposed=True, flip_k=True)
+        else:
+            dx = Fn.gather_gemm(gy, wt, nbr_t, 64, row_perm=perm)
+            dx_t = Fn.gather_gemm(gy, w, nbr_t, 64, w_transposed=True, row_perm=perm)
+        assert torch.allclose(dx, dx_t, atol=1e-4, rtol=1e-4)
+        return y, dx_t
+
+    try:
+        Fn._FORCE_KSPLIT = 1
+        y1, dx1 = run()
+        for zs in sorted({-(-27 // kper) for kper in range(1, 28)}):
+            Fn._FORCE_KSPLIT = zs
+            y, dx = run()
+            assert torch.allclose(y, y1, atol=1e-4, rtol=1e-4), (zs, float((y - y1).abs().max()))
+            assert torch.allclose(dx, dx1, atol=1e-4, rtol=1e-4), (zs, float((dx - dx1).abs().max()))
+    finally:
+        Fn._FORCE_KSPLIT = 0
