@@ -191,6 +191,8 @@ def main():
     batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
     vox_per_step = [int(b["coordinates"].shape[0]) for b in batches]
 
+    if "BENCH_WGRAD_OVERLAP" in os.environ:
+        Fn.set_wgrad_overlap(os.environ["BENCH_WGRAD_OVERLAP"] != "0")
     state = {"tf": model.process_input(batches[0])}
 
     def step(i):

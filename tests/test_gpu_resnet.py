@@ -100,3 +100,33 @@ def test_prepare_ahead_is_bitwise_identical(oracle_maps):
         hip.prepare_ahead = False
         e2 = hip(hip.process_input(batch))
     assert torch.equal(e1, e2)
+
+
+def test_wgrad_side_stream_is_bitwise_identical(oracle_maps):
+    """Weight gradients computed on the side stream (join deferred to the end of backward) ==
+    the single-stream result, bit for bit, both when autograd installs .grad (deferred join) and
+    when it accumulates into an existing .grad (immediate join)."""
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    hip, _ = _models("ResNet14", 28, 51)
+    coords, feats = batch_scenes([31, 32, 33], grid=32, cin=28)
+    batch = {"coordinates": coords.cuda(), "features": feats.cuda()}
+    labels = torch.tensor([1, 2, 3]).cuda()
+
+    def grads(overlap, passes):
+        old = Fn.set_wgrad_overlap(overlap)
+        try:
+            hip.zero_grad(set_to_none=True)
+            for _ in range(passes):
+                F.cross_entropy(hip(hip.process_input(batch)), labels).backward()
+            # consumed right away on the compute stream, as an optimizer would
+            return {k: (p.grad * 1.0) for k, p in hip.named_parameters()}
+        finally:
+            Fn.set_wgrad_overlap(old)
+
+    hip.train()
+    for passes in (1, 2):
+        # running statistics move between calls; gradients do not depend on them in train mode
+        a, b = grads(False, passes), grads(True, passes)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (passes, k)
