@@ -197,8 +197,11 @@ def main():
 
     def step(i):
         # software pipeline: the TensorField (+ coordinate/kernel maps, built on a side stream) of
-        # batch i+1 is prepared while batch i is in backward; every step builds exactly one set.
+        # batch i+1 is prepared while batch i computes; every step builds exactly one set.  The
+        # coordinate pyramid is launched first, its row counts are read back (and the kernel maps
+        # launched) after forward+backward have been queued, so the host never waits for them.
         tf = state["tf"]
+        nxt = model.process_input(batches[(i + 1) % len(batches)], defer=True)
         if reducer is not None:
             reducer.zero_grad()
         else:
@@ -206,7 +209,7 @@ def main():
         out = model(tf)
         loss = F.cross_entropy(out, batches[i % len(batches)]["labels"].long())
         loss.backward()
-        state["tf"] = model.process_input(batches[(i + 1) % len(batches)])
+        state["tf"] = model.finish_input(nxt)
         if reducer is not None:
             reducer.finish()
         opt.step()

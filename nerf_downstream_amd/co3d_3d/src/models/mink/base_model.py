@@ -22,24 +22,36 @@ class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
         _HIP_ME.MinkowskiNetwork.__init__(self, dimension)
         self._ME = ME or _HIP_ME
         self._coord_plan = None
-        self._last_manager = None
+        self._recent_traces = []  # map-request traces of the last few fields (filled by their forward pass)
         self._side = None
         self.prepare_ahead = True
 
-    def process_input(self, batch):
+    def process_input(self, batch, defer=False):
+        """`defer=True` (extension, HIP backend): only launch the coordinate pyramid of this batch
+        on the side stream and return at once; `finish_input(field)` -- call it after the current
+        batch's forward/backward have been queued -- reads the row counts back (already there by
+        then, so the host never blocks) and builds the kernel maps."""
         ME = self._ME
         coords, feats = batch["coordinates"], batch["features"]
         if not (self.prepare_ahead and getattr(ME, "SUPPORTS_PREPARE_AHEAD", False) and coords.is_cuda):
             return ME.TensorField(coordinates=coords, features=feats)
         import torch
 
-        if self._last_manager is not None and self._last_manager.trace:
-            plan = ME.CoordinateManager.compile_plan(self._last_manager.trace)
-            if self._coord_plan is None or len(plan) > len(self._coord_plan):
-                self._coord_plan = plan
+        for trace in self._recent_traces:  # the newest field may not have been through forward yet
+            if trace:
+                plan = ME.CoordinateManager.compile_plan(trace)
+                if self._coord_plan is None or len(plan) > len(self._coord_plan):
+                    self._coord_plan = plan
         if self._side is None:
             self._side = torch.cuda.Stream(device=coords.device)
         with torch.cuda.stream(self._side):
-            tf = ME.TensorField(coordinates=coords, features=feats, plan=self._coord_plan or [])
-        self._last_manager = tf.coordinate_manager
+            tf = ME.TensorField(coordinates=coords, features=feats, plan=self._coord_plan or [], defer=defer)
+        self._recent_traces = [tf.coordinate_manager.trace] + self._recent_traces[:2]
         return tf
+
+    @staticmethod
+    def finish_input(field):
+        finish = getattr(field, "finish", None)
+        if finish is not None:
+            finish()
+        return field

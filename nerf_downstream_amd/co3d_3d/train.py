@@ -219,18 +219,23 @@ def train(
             batch = _to_device(batch, device)
             field = model.process_input(batch)
         while batch is not None:
+            # prepare the next batch on the side stream under this one's compute: its coordinate
+            # pyramid is launched now, the row counts are read back and the kernel maps launched
+            # once forward+backward are queued, so the host never waits for the device here
+            nxt_batch = next(it, None)
+            if nxt_batch is not None:
+                nxt_batch = _to_device(nxt_batch, device)
+                nxt_field = model.process_input(nxt_batch, defer=True)
             if reducer is not None:
                 reducer.zero_grad()
             else:
                 optimizer.zero_grad(set_to_none=True)
             loss, out = module.training_step(batch, field)
             loss.backward()
-            # prepare the next batch (coordinate / kernel maps on the side stream) under backward
             cur_batch = batch
-            batch = next(it, None)
+            batch = nxt_batch
             if batch is not None:
-                batch = _to_device(batch, device)
-                field = model.process_input(batch)
+                field = model.finish_input(nxt_field)
             if reducer is not None:
                 reducer.finish()
             optimizer.step()

@@ -91,6 +91,7 @@ class CoordinateManager:
         self._batch_size = None
         self._batch_checked = False
         self.trace = []  # every map request, in order: lets the next batch be prepared ahead of use
+        self._pending_field = None  # pyramid launched, row counts not read back yet (insert_field(defer=True))
 
     # ------------------------------------------------------------------ plan record / replay
     @staticmethod
@@ -213,10 +214,12 @@ class CoordinateManager:
         return lev, uidx[:nu], inv[:n]
 
     # ------------------------------------------------------------------ construction
-    def insert_field(self, fcoords, ahead_strides=()):
+    def insert_field(self, fcoords, ahead_strides=(), defer=False):
         """A1+A2: floor-quantise the float field and insert it (tensor stride 1); optionally also
         build the chain of stride maps `ahead_strides` (e.g. (2,2,2,2,2) -> ts 2..32) in the same
-        native call.  Row counts stay on the device until ONE read-back at the end."""
+        native call.  Row counts stay on the device until ONE read-back at the end; with
+        `defer=True` that read-back (and everything that needs the counts) is left to
+        `finish_field()`, so the caller can queue other work in between and never blocks."""
         assert fcoords.is_cuda and fcoords.dim() == 2 and fcoords.shape[1] == 4
         import ctypes
 
@@ -249,7 +252,23 @@ class CoordinateManager:
                 arr([index_b[l].data_ptr() for l in range(nlev)]), meta.data_ptr(), ws.data_ptr(), _stream(),
             )
         )
-        m = meta.tolist()  # the one host synchronisation of the whole pyramid
+        meta_host = torch.empty(nlev + 2, dtype=torch.int32, pin_memory=True)
+        meta_host.copy_(meta, non_blocking=True)
+        done = torch.cuda.current_stream(dev).record_event()
+        self._pending_field = (n, ts_list, cap, tkeys, tvals, coords, index_a, index_b, meta_host, done, fc, ws)
+        if not defer:
+            self.finish_field()
+        return CoordinateMapKey(1)
+
+    def finish_field(self):
+        """The one host synchronisation of the whole pyramid: read the row counts back and
+        publish the levels.  No-op when nothing is pending."""
+        if self._pending_field is None:
+            return
+        n, ts_list, cap, tkeys, tvals, coords, index_a, index_b, meta_host, done, _, _ = self._pending_field
+        self._pending_field = None
+        done.synchronize()
+        m, nlev = meta_host.tolist(), len(ts_list)
         if m[nlev] & _STATUS_RANGE:
             raise ValueError(
                 "coordinate outside the supported range (batch < 65535, |x|,|y|,|z| < 32768 after quantisation)"
@@ -266,7 +285,6 @@ class CoordinateManager:
             else:
                 self.in2out[(ts_list[l - 1], ts)] = index_b[l, :n_prev]
             n_prev = m[l]
-        return CoordinateMapKey(1)
 
     def stride(self, key, stride):
         s = _as_int(stride)

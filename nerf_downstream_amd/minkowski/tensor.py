@@ -80,19 +80,35 @@ class TensorField:
     Owns a fresh coordinate manager; `.sparse()` floors the coordinates, inserts them into the
     hash map and averages the features of rows that collapse onto one voxel (A1, A2)."""
 
-    def __init__(self, features=None, coordinates=None, plan=None, **kwargs):
+    def __init__(self, features=None, coordinates=None, plan=None, defer=False, **kwargs):
         """`plan` (extension): a compiled CoordinateManager request plan; all its maps are built
-        right here, on the current (side) stream, and `.sparse()` makes the consumer stream wait."""
+        right here, on the current (side) stream, and `.sparse()` makes the consumer stream wait.
+        `defer=True` only launches the coordinate pyramid (no host synchronisation); `finish()`
+        -- called explicitly once other work has been queued, or implicitly by `.sparse()` --
+        reads the row counts back and builds the rest of the plan on the same stream."""
         assert features is not None and coordinates is not None
         if not coordinates.is_cuda:
             raise RuntimeError("nerf_downstream_amd.minkowski runs on the GPU only: move the batch to cuda first")
         self._F, self._C = features, coordinates
         m = self._manager = CoordinateManager(D=coordinates.shape[1] - 1, device=coordinates.device)
-        self.coordinate_field_map_key = m.insert_field(coordinates, CoordinateManager.plan_stride_chain(plan))
-        self._ready = None
-        if plan is not None:
+        self._plan, self._ready = plan, None
+        self._build_stream = torch.cuda.current_stream(coordinates.device)
+        defer = bool(defer) and plan is not None
+        self.coordinate_field_map_key = m.insert_field(coordinates, CoordinateManager.plan_stride_chain(plan), defer=defer)
+        if not defer:
+            self.finish()
+
+    def finish(self):
+        """Second half of a deferred construction (no-op otherwise)."""
+        m = self._manager
+        if self._plan is None:
+            m.finish_field()
+            return
+        plan, self._plan = self._plan, None
+        with torch.cuda.stream(self._build_stream):
+            m.finish_field()
             m.replay(plan)
-            self._ready = torch.cuda.current_stream().record_event()
+            self._ready = self._build_stream.record_event()
 
     @property
     def F(self):
@@ -108,6 +124,7 @@ class TensorField:
 
     def sparse(self):
         m = self._manager
+        self.finish()
         if self._ready is not None:  # maps were built ahead of time on another stream
             cur = torch.cuda.current_stream()
             cur.wait_event(self._ready)

@@ -8,7 +8,7 @@ from nerf_downstream_amd.co3d_3d.src.models import get_model
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = get_model("ResNet14", 28, 51).to(dev)
-opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=True)
 batches = make_batches(2, 16, 0, 51, 128, 28)
 batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
 tf = model.process_input(batches[0])

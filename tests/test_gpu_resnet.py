@@ -93,6 +93,18 @@ def test_prepare_ahead_is_bitwise_identical(oracle_maps):
     b.sum().backward()
     torch.cuda.synchronize()
     assert torch.equal(hip.layer1[0].conv1.kernel.grad, ga)
+    # two-phase form used by the training loops: pyramid launched, then (after other work has been
+    # queued) counts read back + kernel maps; also when the caller forgets finish_input()
+    hip.zero_grad()
+    tf2 = hip.process_input(batch, defer=True)
+    assert tf2.coordinate_manager._pending_field is not None and not tf2.coordinate_manager.levels
+    hip.finish_input(tf2)
+    assert len(tf2.coordinate_manager.tables) == n_tables
+    hip(tf2).sum().backward()
+    assert torch.equal(hip.layer1[0].conv1.kernel.grad, ga)
+    hip.zero_grad()
+    hip(hip.process_input(batch, defer=True)).sum().backward()  # .sparse() finishes it
+    assert torch.equal(hip.layer1[0].conv1.kernel.grad, ga)
     # BN running stats differ between calls (momentum), logits of the same weights must not
     hip.eval()
     with torch.no_grad():
