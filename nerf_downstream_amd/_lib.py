@@ -56,6 +56,7 @@ SIGNATURES = {
     "mink_bn_workspace_bytes": (_i64, [_i64, _i32]),
     "mink_bn_stats": (ctypes.c_int, [_p, _i64, _i32, _f32, _f32, _p, _p, _p, _p, _p, _p]),
     "mink_bn_apply": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p]),
+    "mink_bn_fwd": (ctypes.c_int, [_p, _i64, _i32, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "mink_bn_bwd": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
     "mink_bn_reduce": (ctypes.c_int, [_i32, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
     "mink_bn_stats_from_sums": (ctypes.c_int, [_p, _p, _i32, _f32, _f32, _p, _p, _p, _p, _p]),

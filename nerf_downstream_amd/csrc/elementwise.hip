@@ -469,6 +469,19 @@ int mink_bn_apply(const float *x, int64_t n, int32_t C, const float *mean, const
   return MINK_OK;
 }
 
+int mink_bn_fwd(const float *x, int64_t n, int32_t C, float eps, float momentum, const float *gamma, const float *beta,
+                const float *residual, int32_t relu, float *y, float *mean, float *invstd, float *running_mean,
+                float *running_var, void *workspace, void *stream) {
+  REQ_C4(C, "bn_fwd");
+  MINK_REQUIRE(n >= 1 && x && gamma && beta && y && mean && invstd, "bn_fwd: bad arguments (n=%lld)", (long long)n);
+  MINK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_fwd: running stats must come in pairs");
+  REQ_A16(x, "bn_fwd");
+  REQ_A16(y, "bn_fwd");
+  int rc = mink_bn_stats(x, n, C, eps, momentum, mean, invstd, running_mean, running_var, workspace, stream);
+  if (rc) return rc;
+  return mink_bn_apply(x, n, C, mean, invstd, gamma, beta, residual, relu, y, stream);
+}
+
 int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int32_t C, const float *mean,
                 const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual, float *dgamma,
                 float *dbeta, void *workspace, void *stream) {

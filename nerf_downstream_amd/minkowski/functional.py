@@ -247,26 +247,27 @@ class BatchNormFunction(torch.autograd.Function):
         dev = x.device
         if residual is not None:
             residual = _f32c(residual)
+        y = torch.empty_like(x)
         if training:
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
             ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
             check(
-                L.mink_bn_stats(
-                    x.data_ptr(), n, C, eps, momentum if running_mean is not None else 0.0, mean.data_ptr(),
-                    invstd.data_ptr(), _ptr(running_mean), _ptr(running_var), ws.data_ptr(), _stream(),
+                L.mink_bn_fwd(
+                    x.data_ptr(), n, C, eps, momentum if running_mean is not None else 0.0, gamma.data_ptr(), beta.data_ptr(),
+                    _ptr(residual), int(relu), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
+                    _ptr(running_var), ws.data_ptr(), _stream(),
                 )
             )
         else:
             mean = running_mean.float()
             invstd = torch.rsqrt(running_var.float() + eps)
-        y = torch.empty_like(x)
-        check(
-            L.mink_bn_apply(
-                x.data_ptr(), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                _ptr(residual), int(relu), y.data_ptr(), _stream(),
+            check(
+                L.mink_bn_apply(
+                    x.data_ptr(), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                    _ptr(residual), int(relu), y.data_ptr(), _stream(),
+                )
             )
-        )
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
         ctx.training, ctx.relu, ctx.has_res = training, relu, residual is not None
         return y
