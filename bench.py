@@ -152,6 +152,7 @@ def main():
     if os.environ.get("BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit if stuck
         import faulthandler
 
+        faulthandler.enable()  # also on a GPU fault (SIGABRT): which launch was the host at
         faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

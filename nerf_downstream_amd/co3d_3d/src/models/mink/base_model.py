@@ -44,6 +44,9 @@ class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
                     self._coord_plan = plan
         if self._side is None:
             self._side = torch.cuda.Stream(device=coords.device)
+        skew = getattr(getattr(ME, "functional", None), "skew", None)
+        if skew is not None:
+            skew(self._side)
         with torch.cuda.stream(self._side):
             tf = ME.TensorField(coordinates=coords, features=feats, plan=self._coord_plan or [], defer=defer)
         self._recent_traces = [tf.coordinate_manager.trace] + self._recent_traces[:2]

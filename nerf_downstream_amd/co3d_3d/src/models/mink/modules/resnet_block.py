@@ -6,6 +6,8 @@ norm2/downsample are kept for state-dict compatibility).
 
 With a backend that advertises SUPPORTS_FUSED_NORM the three elementwise tails
 (norm1+relu, downsample norm, norm2+add+relu) each run as ONE fused HIP pass."""
+import os
+
 import torch.nn as nn
 
 from .common import conv, default_me, get_nonlinearity, get_norm
@@ -26,8 +28,44 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.nonlinearity = get_nonlinearity(nonlinearity_type, ME)()
         self._fused = bool(getattr(ME, "SUPPORTS_FUSED_NORM", False))
+        self._fork = bool(getattr(ME, "SUPPORTS_FUSED_NORM", False)) and os.environ.get("MINK_FORK_SHORTCUT", "1") != "0"
+        self._fork_unprepared = False  # tests: fork even when maps are still built on demand (exercises the manager's stream fence)
+
+    def _forked_shortcut(self, x):
+        """HIP backend, maps prepared ahead: run the shortcut branch (1x1 strided conv + norm) on a
+        second stream beside conv1/norm1/conv2 -- none of these kernels fills the chip alone.
+        Returns (shortcut, join) where join() makes the current stream wait for the branch."""
+        import torch
+
+        from nerf_downstream_amd.minkowski import functional as Fn
+
+        cur = torch.cuda.current_stream(x.F.device)
+        br = Fn.branch_stream(x.F.device, home=cur)
+        br.wait_stream(cur)
+        Fn.skew(br)
+        with torch.cuda.stream(br):
+            shortcut = self.downsample(x)
+        x.F.record_stream(br)
+
+        def join():
+            cur.wait_stream(br)
+            shortcut.F.record_stream(cur)
+
+        return shortcut, join
+
+    def _may_fork(self, x):
+        if not (self._fused and self._fork and self.downsample is not None and x.F.is_cuda):
+            return False
+        from nerf_downstream_amd.minkowski import functional as Fn
+
+        return Fn.branch_fork_enabled() and (getattr(x.coordinate_manager, "prepared", False) or self._fork_unprepared)
 
     def forward(self, x):
+        if self._may_fork(x):
+            shortcut, join = self._forked_shortcut(x)
+            h = self.conv2(self.norm1(self.conv1(x), relu=True))
+            join()
+            return self.norm2(h, relu=True, residual=shortcut)
         shortcut = x if self.downsample is None else self.downsample(x)
         if self._fused:
             h = self.norm1(self.conv1(x), relu=True)

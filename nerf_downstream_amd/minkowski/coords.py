@@ -92,6 +92,10 @@ class CoordinateManager:
         self._batch_checked = False
         self.trace = []  # every map request, in order: lets the next batch be prepared ahead of use
         self._pending_field = None  # pyramid launched, row counts not read back yet (insert_field(defer=True))
+        self.prepared = False
+        self._lazy_marks = []  # (stream, event, tensors) of every map built on demand (outside replay)
+        self._lazy_seen = {}   # stream -> number of marks that stream is already ordered after
+        self._replaying = False
 
     # ------------------------------------------------------------------ plan record / replay
     @staticmethod
@@ -121,6 +125,14 @@ class CoordinateManager:
     def replay(self, plan):
         """Build every map of `plan` now (on the current stream) so the forward/backward pass that
         follows finds them cached."""
+        self.prepared = bool(plan)  # the maps of the previous forward+backward exist before forward starts
+        self._replaying = True  # built on the prepare stream; TensorField.sparse() hands them over as a whole
+        try:
+            self._replay_ops(plan)
+        finally:
+            self._replaying = False
+
+    def _replay_ops(self, plan):
         self._build_tables_batched([op for op in plan if op[0] == "ktable"])
         for op in plan:
             if op[0] == "stride":
@@ -286,21 +298,47 @@ class CoordinateManager:
                 self.in2out[(ts_list[l - 1], ts)] = index_b[l, :n_prev]
             n_prev = m[l]
 
+    # ------------------------------------------------------------------ maps built on demand
+    # A map requested for the first time is built on whatever stream asks for it.  With several
+    # compute streams (shortcut branch, weight-gradient stream) another stream may hit the cached
+    # entry next: it has to wait for the build and keep the memory alive for its own kernels.
+    def _note_lazy(self, *tensors):
+        if self._replaying or not torch.cuda.is_available():
+            return
+        cur = torch.cuda.current_stream(self.device)
+        self._lazy_marks.append((cur, cur.record_event(), [t for t in tensors if t is not None]))
+        self._lazy_seen[cur] = len(self._lazy_marks)
+
+    def _sync_lazy(self):
+        if not self._lazy_marks:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        seen = self._lazy_seen.get(cur, 0)
+        for st, ev, tensors in self._lazy_marks[seen:]:
+            if st != cur:
+                cur.wait_event(ev)
+                for t in tensors:
+                    t.record_stream(cur)
+        self._lazy_seen[cur] = len(self._lazy_marks)
+
     def stride(self, key, stride):
         s = _as_int(stride)
         if s == 1:
             return key
         self.trace.append(("stride", key.ts, s))
         ts_out = key.ts * s
+        self._sync_lazy()
         if ts_out not in self.levels:
             src = self.levels[key.ts]
             lev, _, inv = self._unique(src.coords, 1, src.n, ts_out)
             self.levels[ts_out] = lev
             self.in2out[(key.ts, ts_out)] = inv
+            self._note_lazy(lev.coords, lev.tkeys, lev.tvals, inv)
         return CoordinateMapKey(ts_out)
 
     def stride_map(self, in_key, out_key):
         k = (in_key.ts, out_key.ts)
+        self._sync_lazy()
         if k not in self.in2out:
             raise KeyError(f"no stride map {k}: create the output map with stride() first")
         return self.in2out[k]
@@ -310,6 +348,7 @@ class CoordinateManager:
         ks, dil = _as_int(kernel_size), _as_int(dilation)
         kk = (in_key.ts, out_key.ts, ks, dil)
         self.trace.append(("ktable",) + kk + (bool(transposed),))
+        self._sync_lazy()
         ent = self.tables.get(kk)
         if ent is None or (transposed and ent[1] is None):
             lin, lout = self.levels[in_key.ts], self.levels[out_key.ts]
@@ -327,6 +366,7 @@ class CoordinateManager:
             )
             ent = (nbr, nbr_t)
             self.tables[kk] = ent
+            self._note_lazy(nbr, nbr_t)
         return ent
 
     def kernel_map(self, in_key, out_key, stride=1, kernel_size=3, dilation=1, is_transpose=False, is_pool=False):
@@ -349,12 +389,14 @@ class CoordinateManager:
         """Parity-class row permutation of the map `key` (for dgrad of stride-2 convolutions)."""
         ck = ("perm", key.ts, pad)
         self.trace.append(ck)
+        self._sync_lazy()
         if ck not in self.tables:
             L, lev = lib(), self.levels[key.ts]
             perm = torch.empty(int(L.mink_class_partition_rows(lev.n, pad)), dtype=torch.int32, device=self.device)
             ws = torch.empty(int(L.mink_class_partition_workspace_bytes(lev.n)), dtype=torch.uint8, device=self.device)
             check(L.mink_class_partition(lev.coords.data_ptr(), lev.n, key.ts, pad, perm.data_ptr(), ws.data_ptr(), _stream()))
             self.tables[ck] = perm
+            self._note_lazy(perm)
         return self.tables[ck]
 
     # ------------------------------------------------------------------ queries
@@ -370,6 +412,7 @@ class CoordinateManager:
     def batch_offsets(self, key):
         """int32[B+1] row ranges per batch index (rows of one batch are contiguous)."""
         self.trace.append(("boff", key.ts))
+        self._sync_lazy()
         if key.ts not in self._boff:
             B = self._batch_size
             lev = self.levels[key.ts]
@@ -379,6 +422,7 @@ class CoordinateManager:
             if key.ts == 1 and int(status.item()) & _STATUS_UNSORTED:
                 raise ValueError("batch indices must be non-decreasing (use ME.utils.sparse_collate)")
             self._boff[key.ts] = boff
+            self._note_lazy(boff)
         return self._boff[key.ts]
 
     def get_coordinates(self, key):

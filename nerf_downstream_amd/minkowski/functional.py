@@ -4,6 +4,8 @@
 Semantics follow SURVEY.md Appendix A (A6 convolution, A8 batch norm, A9 sum pooling,
 A10 global average pooling); the reference call sites are cited on the modules.
 """
+import os
+
 import torch
 
 from .._lib import check, lib
@@ -152,6 +154,51 @@ def set_wgrad_overlap(on=True):
 
 
 _DEFERRED = {"pending": False, "callback": False}
+_HOME_STREAMS = {}  # device index -> the stream the network itself runs on (noted where a branch forks off)
+_BRANCH_STREAMS = {}
+
+
+_SKEW = int(os.environ.get("MINK_STREAM_SKEW", "0"))  # race hunting: delay every auxiliary stream by this many GPU cycles
+
+
+def skew(stream):
+    """Test hook: stall `stream` for MINK_STREAM_SKEW cycles before its next piece of work, so a
+    missing cross-stream dependency shows up as a wrong result instead of passing by luck."""
+    if _SKEW:
+        with torch.cuda.stream(stream):
+            torch.cuda._sleep(_SKEW)
+
+
+def compute_streams(device):
+    """The auxiliary compute streams this module has created on `device` (weight-gradient stream,
+    shortcut-branch stream): whoever consumes gradients from another stream joins these."""
+    return [d[device.index] for d in (_SIDE_STREAMS, _BRANCH_STREAMS) if device.index in d]
+
+
+_BRANCH_FORK = True
+
+
+def set_branch_fork(on=True):
+    """Allow / forbid residual blocks to run their shortcut branch on the second compute stream."""
+    global _BRANCH_FORK
+    old, _BRANCH_FORK = _BRANCH_FORK, bool(on)
+    return old
+
+
+def branch_fork_enabled():
+    return _BRANCH_FORK
+
+
+def branch_stream(device, home=None):
+    """A second compute stream for an independent branch of the network (the shortcut
+    convolution of a residual block runs beside the main branch: both are small kernels that do
+    not fill the chip on their own).  `home`: the stream the caller forks from."""
+    s = _BRANCH_STREAMS.get(device.index)
+    if s is None:
+        s = _BRANCH_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    if home is not None:
+        _HOME_STREAMS[device.index] = home
+    return s
 
 
 def _join_side_streams():
@@ -201,6 +248,7 @@ class ConvolutionFunction(torch.autograd.Function):
         if side is not None:
             main = torch.cuda.current_stream()
             side.wait_stream(main)  # gy / x are ready on the side stream
+            skew(side)
         if want_gx:
             # dgrad = the same gather-GEMM over the transposed map with W[k]^T (read in place)
             if ctx.same_map:  # stride 1: nbr_t[i][k] == nbr[i][K-1-k]
@@ -212,15 +260,21 @@ class ConvolutionFunction(torch.autograd.Function):
             if side is not None:
                 with torch.cuda.stream(side):
                     gw = conv_wgrad(x, gy, ctx.nbr, w.shape)
-                for t in (x, gy, gw):
+                for t in (x, gy, ctx.nbr, gw):  # every buffer the side stream reads, and its output
                     t.record_stream(side if t is not gw else main)
                 # Nothing reads gw before backward ends when autograd merely installs it as
                 # w.grad: then the join is deferred to the end-of-backward callback and the
                 # wgrad kernels overlap the rest of the backward chain.  An existing .grad
                 # (accumulation, DP flat buffers), a gradient hook or the channel-padding slice
                 # below consume it right away: join now.
+                # (No reference to gw may be kept here: AccumulateGrad only installs the tensor
+                # itself when nobody else holds it -- otherwise it CLONES it, at once, on the
+                # compute stream.  Double backward clones as well.)
+                home = _HOME_STREAMS.get(gw.device.index)
+                if home is not None and home != main:
+                    gw.record_stream(home)  # a branch's gradient is consumed by the network's own stream later
                 if w.grad is None and not getattr(w, "_post_accumulate_grad_hooks", None) and \
-                        not w._backward_hooks and gw.shape[1] == ctx.cin:
+                        not w._backward_hooks and gw.shape[1] == ctx.cin and not torch.is_grad_enabled():
                     _DEFERRED["pending"] = True
                     if not _DEFERRED["callback"]:
                         _DEFERRED["callback"] = True

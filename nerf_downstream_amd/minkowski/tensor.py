@@ -105,6 +105,7 @@ class TensorField:
             m.finish_field()
             return
         plan, self._plan = self._plan, None
+        Fn.skew(self._build_stream)
         with torch.cuda.stream(self._build_stream):
             m.finish_field()
             m.replay(plan)

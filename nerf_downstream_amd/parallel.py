@@ -15,6 +15,8 @@ per-rank BatchNorm statistics, mean of gradients across ranks once per step.  He
   overlapped with the remaining backward kernels;
 * `finish()` waits for all buckets and scales by 1/world (mean), before the optimizer step.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -47,13 +49,34 @@ class BucketedGradAllReduce:
         self._launched = [False] * len(self.buckets)
         self._work = []
         self._hooks = []
+        self._home = None  # the stream the step runs on (captured in zero_grad)
         if self.world > 1:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            if dev.type == "cuda" and os.environ.get("MINK_DP_MULTISTREAM", "0") == "0":
+                # Gradients land in the flat buffer as they are produced, so the weight-gradient
+                # stream would have to re-join at every layer (no gain), and one process already
+                # drives compute + prepare + RCCL queues: keep data-parallel ranks on those.
+                # (MINK_DP_MULTISTREAM=1 keeps the single-process schedule; the reducer joins the
+                # auxiliary streams before each collective either way.)
+                from .minkowski import functional as Fn
+
+                Fn.set_wgrad_overlap(False)
+                Fn.set_branch_fork(False)
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        if self.flat.is_cuda:
+            # The gradients of one bucket may have been accumulated from several HIP streams (the
+            # step's own stream, the shortcut-branch stream, the weight-gradient stream); the
+            # collective orders itself after the CURRENT stream only, so join the others first.
+            from .minkowski import functional as Fn
+
+            cur = torch.cuda.current_stream(self.flat.device)
+            for st in [self._home] + Fn.compute_streams(self.flat.device):
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
         self._work.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad(self, p):
@@ -65,6 +88,7 @@ class BucketedGradAllReduce:
     def zero_grad(self):
         """Gradients accumulate into the flat buffer; clear it with one memset per step."""
         self.flat.zero_()
+        self._home = torch.cuda.current_stream(self.flat.device) if self.flat.is_cuda else None
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
 

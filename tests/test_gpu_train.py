@@ -53,6 +53,75 @@ def test_training_matches_oracle(tmp_path, oracle_maps):
     assert abs(vg["val/loss"] - vc["val/loss"]) < 8e-2
 
 
+def _schedule(model, multi, lazy_fork=False):
+    """multi=True: every overlap the training loops use (prepare-ahead on its stream, weight
+    gradients on the side stream, shortcut branch on its own stream) with each auxiliary stream
+    DELAYED by ~1 ms per use (Fn._SKEW), so a missing cross-stream dependency changes the result
+    instead of passing by luck.  multi=False: everything on one stream."""
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    Fn._SKEW = 2_000_000 if multi else 0
+    Fn.set_wgrad_overlap(multi)
+    Fn.set_branch_fork(True)  # (a data-parallel reducer switches both off by default; the tests force them)
+    model.prepare_ahead = multi and not lazy_fork
+    for m in model.modules():
+        if hasattr(m, "_fork"):
+            m._fork = multi
+            m._fork_unprepared = lazy_fork  # maps built on demand from whichever stream asks first
+
+
+def _train_steps(model, batches, labels, steps, reducer=None):
+    """The step loop of bench.py / train.py (two-phase prepare-ahead, fused SGD)."""
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
+    tf = model.process_input(batches[0])
+    for i in range(steps):
+        nxt = model.process_input(batches[(i + 1) % len(batches)], defer=True)
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        F.cross_entropy(model(tf), labels[i % len(batches)]).backward()
+        if os.environ.get("MINK_TEST_TRACE"):
+            torch.cuda.synchronize()
+            print(f"[trace] step {i} backward done (reducer={reducer is not None})", flush=True)
+        tf = model.finish_input(nxt)
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+    torch.cuda.synchronize()
+    return torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
+
+
+def test_multi_stream_schedule_is_bitwise_single_stream():
+    """Five training steps with every stream overlap on and the auxiliary streams skewed ==
+    the same five steps on a single stream, bit for bit (all kernels are deterministic)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import batch_scenes
+
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    dev = torch.device("cuda", 0)
+    batches, labels = [], []
+    for j in range(2):
+        coords, feats = batch_scenes([70 + 3 * j, 71 + 3 * j, 72 + 3 * j], grid=32, cin=28)
+        batches.append({"coordinates": coords.to(dev), "features": feats.to(dev)})
+        labels.append(torch.tensor([j, 1 + j, 2 + j], device=dev))
+    out = {}
+    try:
+        for mode, (multi, lazy_fork) in {"single": (False, False), "multi": (True, False), "multi-lazy": (True, True)}.items():
+            torch.manual_seed(5)
+            m = get_model("ResNet14", 28, 5).to(dev)
+            _schedule(m, multi, lazy_fork)
+            out[mode] = _train_steps(m, batches, labels, 5)
+    finally:
+        Fn._SKEW = 0
+        Fn.set_wgrad_overlap(True)
+    assert torch.isfinite(out["multi"]).all()
+    assert torch.equal(out["single"], out["multi"])
+    assert torch.equal(out["single"], out["multi-lazy"])
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -60,6 +129,9 @@ def _free_port():
 
 
 def _dp_worker(rank, world, port, out):
+    import faulthandler
+
+    faulthandler.enable()  # a GPU fault aborts the process: show where the host was
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -86,6 +158,18 @@ def _dp_worker(rank, world, port, out):
     m2 = get_model("ResNet14", 28, 5).to(dev)
     F.cross_entropy(m2(m2.process_input({"coordinates": coords.to(dev), "features": feats.to(dev)})), labels).backward()
     torch.save(torch.cat([p.grad.flatten() for p in list(m2.parameters())[::-1]]).cpu(), f"{out}/local{rank}.pt")
+    # four data-parallel training steps: every stream overlap on + skewed auxiliary streams must
+    # give the single-stream parameters bit for bit (the 2-rank sum is order independent)
+    batches = [{"coordinates": coords.to(dev), "features": feats.to(dev)}]
+    params = {}
+    for multi in (False, True):
+        torch.manual_seed(4)
+        m3 = get_model("ResNet14", 28, 5).to(dev)
+        red3 = BucketedGradAllReduce(m3, bucket_bytes=8 << 20)  # (switches the overlaps off by default ...)
+        _schedule(m3, multi)                                     # (... the multi run forces them back on)
+        params[multi] = _train_steps(m3, batches, [labels], 4, reducer=red3)
+    torch.save({"equal": bool(torch.equal(params[False], params[True])), "finite": bool(torch.isfinite(params[True]).all())},
+               f"{out}/sched{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -97,6 +181,9 @@ def test_data_parallel_two_ranks_on_card(tmp_path):
     assert torch.equal(r0["g"], r1["g"])
     ref = 0.5 * (torch.load(tmp_path / "local0.pt") + torch.load(tmp_path / "local1.pt"))
     assert torch.allclose(r0["g"], ref, atol=1e-5 * float(ref.abs().max()), rtol=1e-4)
+    for r in (0, 1):
+        sched = torch.load(tmp_path / f"sched{r}.pt")
+        assert sched["finite"] and sched["equal"], (r, sched)
 
 
 def _syncbn_worker(rank, world, port, out):
