@@ -85,12 +85,11 @@ def pmc_traffic(tag, meta):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not files:
         return None
-    want = "wgrad_kernel" if tag.startswith("wgrad") else "gather_gemm2_kernel"
+    stem_wgrad = tag.startswith("wgrad") and meta["cin"] <= 32 and meta["K"] == 27
+    want = "wgrad_stream_kernel" if stem_wgrad else "wgrad_kernel" if tag.startswith("wgrad") else "gather_gemm2_kernel"
     best = None
     for e in json.load(open(files[-1])):
         if want in e["kernel"] and "hbm_traffic_bytes_per_launch" in e:
-            if tag.startswith("wgrad") and meta["cin"] <= 32 and "<9, true" not in e["kernel"]:
-                continue
             if not tag.startswith("wgrad") and e["workgroups"] != -(-meta["n_out"] // 128):
                 continue
             if best is None or e["hbm_traffic_bytes_per_launch"] > best:

@@ -12,7 +12,7 @@ import sys
 out, dirs = sys.argv[1], sys.argv[2:]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in dirs:
-    for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+    for f in glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
