@@ -91,6 +91,11 @@ def lib():
                 f"{LIB_PATH} not found: the HIP backend is mandatory (no CPU fallback). "
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C nerf_downstream_amd/csrc`."
             )
+        # One HIP runtime per process: torch ships its own libamdhip64; load it first so that
+        # libmink_hip.so (linked against the same soname) binds to that instance instead of
+        # bringing /opt/rocm's copy in beside it (two runtimes = "no ROCm-capable device").
+        import torch  # noqa: F401
+
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
