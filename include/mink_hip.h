@@ -192,6 +192,17 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
                           const int32_t *row_perm, int64_t n_virtual, float *y, int32_t ldy,
                           int32_t cout, const float *bias, int32_t ksplit, float *workspace,
                           void *stream);
+/* Forward convolution that also emits the column statistics of its output for the batch norm that
+ * follows (reference resnet_block.py:53-60: every 3x3x3 convolution feeds a norm): the un-split
+ * kernel sums its tile in the epilogue, the split-K reduce sums while it adds the slabs -- y is
+ * not read again.  stats_out: double [<= 512][2][cout]; *stats_rows (host) = partial rows written,
+ * 0 when this launch shape cannot produce them (the caller then calls mink_bn_stats);
+ * stats_ws >= mink_conv_stats_workspace_bytes(n_out, cout). */
+int64_t mink_conv_stats_workspace_bytes(int64_t n_out, int32_t cout);
+int mink_conv_gather_gemm_stats(const float *x, int32_t ldx, int32_t cin, const float *w, const int32_t *nbr,
+                                int64_t n_out, int32_t K, float *y, int32_t ldy, int32_t cout,
+                                const float *bias, int32_t ksplit, float *workspace, double *stats_out,
+                                int32_t *stats_rows, void *stats_ws, void *stream);
 
 /* Weight gradient dW[k] = X[nbr[.][k]]^T @ dY, split over row blocks and reduced
  * deterministically (no atomics).  x has n_in rows (every nbr entry is -1 or in [0, n_in)).
@@ -246,6 +257,11 @@ int mink_bn_apply(const float *x, int64_t n, int32_t C, const float *mean, const
 int mink_bn_fwd(const float *x, int64_t n, int32_t C, float eps, float momentum, const float *gamma,
                 const float *beta, const float *residual, int32_t relu, float *y, float *mean, float *invstd,
                 float *running_mean, float *running_var, void *workspace, void *stream);
+/* Statistics from column partials [rows][2][C] (sum, sum of squares; double) that the producer of
+ * x already computed -- mink_conv_gather_gemm_stats -- instead of a reduction pass over x. */
+int mink_bn_stats_from_partials(const double *partial, int32_t rows, int64_t n, int32_t C, float eps,
+                                float momentum, float *mean, float *invstd, float *running_mean,
+                                float *running_var, void *stream);
 
 /* Backward of the op above.  y (the forward output) is only read when relu != 0.
  * dgamma[C], dbeta[C]; dx[n][C]; dresidual (may be NULL) receives the masked grad. */

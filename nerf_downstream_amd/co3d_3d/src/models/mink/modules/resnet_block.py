@@ -63,13 +63,15 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         if self._may_fork(x):
             shortcut, join = self._forked_shortcut(x)
-            h = self.conv2(self.norm1(self.conv1(x), relu=True))
+            st = self.training  # the convolutions hand their output's column statistics to the norm that follows
+            h = self.conv2(self.norm1(self.conv1(x, bn_stats=st), relu=True), bn_stats=st)
             join()
             return self.norm2(h, relu=True, residual=shortcut)
         shortcut = x if self.downsample is None else self.downsample(x)
         if self._fused:
-            h = self.norm1(self.conv1(x), relu=True)
-            return self.norm2(self.conv2(h), relu=True, residual=shortcut)
+            st = self.training
+            h = self.norm1(self.conv1(x, bn_stats=st), relu=True)
+            return self.norm2(self.conv2(h, bn_stats=st), relu=True, residual=shortcut)
         h = self.nonlinearity(self.norm1(self.conv1(x)))
         h = self.norm2(self.conv2(h))
         h += shortcut

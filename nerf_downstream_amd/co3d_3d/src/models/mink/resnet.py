@@ -76,11 +76,11 @@ class ResNetBase(MinkowskiBaseModel):
     def forward(self, x):
         if self.training and self._norms:
             torch._foreach_add_([m.bn.num_batches_tracked for m in self._norms], 1)
-        out = self.conv1(x.sparse())
-        if self._fused:  # bn1 -> relu -> pool in one pass over the finest-level activation
-            out = self.pool(out, norm=self.bn1)
+        if self._fused:  # bn1 -> relu -> pool in one pass over the finest-level activation; its
+            # statistics come out of the stem convolution's epilogue (no extra pass over 825 k x 64)
+            out = self.pool(self.conv1(x.sparse(), bn_stats=self.training), norm=self.bn1)
         else:
-            out = self.pool(self.relu(self.bn1(out)))
+            out = self.pool(self.relu(self.bn1(self.conv1(x.sparse()))))
         out = self.layer4(self.layer3(self.layer2(self.layer1(out))))
         return self.final(self.glob_avg(out)).F
 

@@ -8,6 +8,8 @@
 // element has exactly one owner, so results are bitwise reproducible run to run.
 #include <type_traits>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace mink {
@@ -31,6 +33,7 @@ struct GemmParams {
   int64_t n_out;        // rows of y / of the neighbour table
   int64_t n_virtual;    // rows iterated (== n_out without a permutation)
   int ldx, cin, ldy, cout, K, flip_k, kper, stagger;
+  float *stats;  // optional [row tiles][2][cout]: per-tile column (sum, sum of squares) of y (un-split launches only)
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float *p, int valid, bool vec) {
@@ -639,13 +642,90 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
   const int c_a = n0 + col, c_b = n0 + 32 + col;
   const float bias_a = (direct && p.bias && c_a < p.cout) ? p.bias[c_a] : 0.f;
   const float bias_b = (direct && p.bias && c_b < p.cout) ? p.bias[c_b] : 0.f;
+  float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;  // column statistics of this wave's 32 rows (for the batch norm that follows)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t row = s_orow[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
     if (row >= 0) {
-      if (c_a < p.cout) dst[row * ldd + c_a] = acc0[r] + bias_a;
-      if (c_b < p.cout) dst[row * ldd + c_b] = acc1[r] + bias_b;
+      const float va = acc0[r] + bias_a, vb = acc1[r] + bias_b;
+      if (c_a < p.cout) dst[row * ldd + c_a] = va;
+      if (c_b < p.cout) dst[row * ldd + c_b] = vb;
+      sa += va, qa += va * va, sb += vb, qb += vb * vb;
     }
+  }
+  if (p.stats && direct) {  // uniform
+    sa += __shfl_xor(sa, 32), qa += __shfl_xor(qa, 32), sb += __shfl_xor(sb, 32), qb += __shfl_xor(qb, 32);
+    float *red = reinterpret_cast<float *>(s_a_raw[0]);  // [wave][sum a, sq a, sum b, sq b][32]; the tiles are dead (last barrier)
+    if (h == 0) {
+      red[(wave * 4 + 0) * 32 + col] = sa, red[(wave * 4 + 1) * 32 + col] = qa;
+      red[(wave * 4 + 2) * 32 + col] = sb, red[(wave * 4 + 3) * 32 + col] = qb;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 5, c = n0 + (which >= 2 ? 32 : 0) + (tid & 31);
+      const float v = (red[(0 * 4 + which) * 32 + (tid & 31)] + red[(1 * 4 + which) * 32 + (tid & 31)]) +
+                      (red[(2 * 4 + which) * 32 + (tid & 31)] + red[(3 * 4 + which) * 32 + (tid & 31)]);
+      if (c < p.cout) p.stats[((int64_t)blockIdx.x * 2 + (which & 1)) * p.cout + c] = v;
+    }
+  }
+}
+
+// stage 2 of the fused statistics: per-tile float partials [rows][cols] -> double partials [gridDim.x][cols]
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float *__restrict__ in, int64_t rows, int cols,
+                                                         double *__restrict__ out) {
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    double s = 0.0;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) s += (double)in[r * cols + c];
+    out[(int64_t)blockIdx.x * cols + c] = s;
+  }
+}
+
+// split-K reduce fused with the column statistics: y = sum_z ws[z] + bias, partial[blk][2][C] = (sum y, sum y^2).
+// Thread layout of the batch-norm column reduction: a thread owns one float4 column and strides over rows.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float *__restrict__ ws, int64_t n_out, int cout,
+                                                                  int ksplit, const float *__restrict__ bias,
+                                                                  float *__restrict__ y, int ldy,
+                                                                  double *__restrict__ partial) {
+  extern __shared__ double s_red[];  // [row lanes][2][C]
+  const int tpr = cout >> 2, rlanes = 256 / tpr;
+  const int c4 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const int64_t total = n_out * cout;
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
+  if (rl < rlanes) {
+    const float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * c4) : make_float4(0, 0, 0, 0);
+    // four rows per trip: all their slab loads are in flight together (the pass is latency-bound)
+    const int64_t stride = (int64_t)gridDim.x * rlanes;
+    for (int64_t row = (int64_t)blockIdx.x * rlanes + rl; row < n_out; row += 4 * stride) {
+      float4 v[4] = {b, b, b, b};
+      for (int z = 0; z < ksplit; ++z) {
+        float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t r = row + u * stride;
+          t[u] = *reinterpret_cast<const float4 *>(ws + (int64_t)z * total + (r < n_out ? r : row) * cout + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u].x += t[u].x, v[u].y += t[u].y, v[u].z += t[u].z, v[u].w += t[u].w;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = row + u * stride;
+        if (r < n_out) {
+          *reinterpret_cast<float4 *>(y + r * ldy + 4 * c4) = v[u];
+          s0.x += v[u].x, s0.y += v[u].y, s0.z += v[u].z, s0.w += v[u].w;
+          s1.x += v[u].x * v[u].x, s1.y += v[u].y * v[u].y, s1.z += v[u].z * v[u].z, s1.w += v[u].w * v[u].w;
+        }
+      }
+    }
+    double *d = s_red + ((int64_t)rl * 2) * cout + 4 * c4;
+    d[0] = s0.x, d[1] = s0.y, d[2] = s0.z, d[3] = s0.w;
+    d[cout + 0] = s1.x, d[cout + 1] = s1.y, d[cout + 2] = s1.z, d[cout + 3] = s1.w;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * cout; e += 256) {
+    double s = 0.0;
+    for (int r = 0; r < rlanes; ++r) s += s_red[(int64_t)r * 2 * cout + e];
+    partial[(int64_t)blockIdx.x * 2 * cout + e] = s;
   }
 }
 
@@ -1117,10 +1197,14 @@ int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_cl
   return best;
 }
 
-int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
-                          int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, const int32_t *row_perm,
-                          int64_t n_virtual, float *y, int32_t ldy, int32_t cout, const float *bias, int32_t ksplit,
-                          float *workspace, void *stream) {
+// stats_out (optional): double [<= 512][2][cout] column (sum, sum of squares) partials of y for the
+// batch norm that follows; *stats_rows receives how many partial rows were written (0: this
+// launch configuration cannot produce them and the caller reduces y itself).
+static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
+                            int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, const int32_t *row_perm,
+                            int64_t n_virtual, float *y, int32_t ldy, int32_t cout, const float *bias, int32_t ksplit,
+                            float *workspace, double *stats_out, int32_t *stats_rows, void *stats_ws, void *stream) {
+  if (stats_rows) *stats_rows = 0;
   MINK_REQUIRE(K >= 1 && K <= KMAX, "gather_gemm: kernel volume %d unsupported", K);
   MINK_REQUIRE(cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0, "gather_gemm: bad shape");
   MINK_REQUIRE(ksplit >= 1 && ksplit <= K, "gather_gemm: bad ksplit %d", ksplit);
@@ -1136,12 +1220,18 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
   p.x = x, p.w = w, p.nbr = nbr, p.bias = bias, p.y = y, p.ws = workspace;
   p.n_out = n_out, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K, p.flip_k = flip_k;
   p.kper = (int)cdiv(K, ksplit);
+  p.stats = nullptr;
   const int zs = (int)cdiv(K, p.kper);
   const dim3 grid((unsigned)cdiv(n_virtual, BM), (unsigned)cdiv(cout, BN), (unsigned)zs);
   hipStream_t st = (hipStream_t)stream;
+  const bool al = (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && (ldx & 3) == 0 && (cin & 3) == 0;
+  const bool vec = al && (w_transposed ? true : (cout & 3) == 0);
+  const bool want_stats = stats_out && stats_rows && stats_ws && !row_perm && !w_transposed;
+  const bool stats_direct = want_stats && zs == 1 && vec && g_pipeline;  // conv epilogue -> per-tile partials -> stage 2
+  const bool stats_split = want_stats && zs > 1 && (cout & 3) == 0 && cout <= 1024 && (ldy & 3) == 0 &&
+                           (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
+  if (stats_direct) p.stats = (float *)stats_ws;
   {
-    const bool al = (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && (ldx & 3) == 0 && (cin & 3) == 0;
-    const bool vec = al && (w_transposed ? true : (cout & 3) == 0);
     const bool stage = row_perm != nullptr;
     if (vec && g_pipeline) {
       const bool flat = cin == 28 && zs == 1 && !flip_k && !w_transposed && !stage && g_flat;
@@ -1163,12 +1253,46 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
     else gather_gemm_kernel<false, false><<<grid, 256, 0, st>>>(p);
   }
   MINK_CHECK_LAUNCH();
-  if (zs > 1) {
+  if (stats_direct) {
+    const int rows = (int)std::min<int64_t>(64, cdiv((int64_t)grid.x, 16));
+    colsum_f32_kernel<<<dim3((unsigned)rows), 256, 0, st>>>((const float *)stats_ws, (int64_t)grid.x, 2 * cout, stats_out);
+    MINK_CHECK_LAUNCH();
+    *stats_rows = rows;
+  }
+  if (zs > 1 && stats_split) {
+    const int tpr = cout >> 2, rlanes = 256 / tpr;
+    const int rows = (int)std::max<int64_t>(1, std::min<int64_t>(512, cdiv(n_out, (int64_t)rlanes * 8)));
+    splitk_reduce_stats_kernel<<<dim3((unsigned)rows), 256, (size_t)rlanes * 2 * cout * sizeof(double), st>>>(
+        workspace, n_out, cout, zs, bias, y, ldy, stats_out);
+    MINK_CHECK_LAUNCH();
+    *stats_rows = rows;
+  } else if (zs > 1) {
     splitk_reduce_kernel<<<dim3((unsigned)cdiv(n_out * cout, 256)), 256, 0, st>>>(workspace, n_out, cout, zs, bias, y,
                                                                                   ldy);
     MINK_CHECK_LAUNCH();
   }
   return MINK_OK;
+}
+
+int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
+                          int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, const int32_t *row_perm,
+                          int64_t n_virtual, float *y, int32_t ldy, int32_t cout, const float *bias, int32_t ksplit,
+                          float *workspace, void *stream) {
+  return gather_gemm_impl(x, ldx, cin, w, w_transposed, flip_k, nbr, n_out, K, row_perm, n_virtual, y, ldy, cout, bias,
+                          ksplit, workspace, nullptr, nullptr, nullptr, stream);
+}
+
+int64_t mink_conv_stats_workspace_bytes(int64_t n_out, int32_t cout) {
+  return (int64_t)cdiv(n_out > 0 ? n_out : 1, BM) * 2 * cout * sizeof(float);
+}
+
+int mink_conv_gather_gemm_stats(const float *x, int32_t ldx, int32_t cin, const float *w, const int32_t *nbr,
+                                int64_t n_out, int32_t K, float *y, int32_t ldy, int32_t cout, const float *bias,
+                                int32_t ksplit, float *workspace, double *stats_out, int32_t *stats_rows,
+                                void *stats_ws, void *stream) {
+  MINK_REQUIRE(stats_out && stats_rows && stats_ws, "gather_gemm_stats: NULL statistics buffers");
+  return gather_gemm_impl(x, ldx, cin, w, 0, 0, nbr, n_out, K, nullptr, 0, y, ldy, cout, bias, ksplit, workspace,
+                          stats_out, stats_rows, stats_ws, stream);
 }
 
 int64_t mink_conv_wgrad_workspace_bytes(int64_t n_out, int32_t K, int32_t cin, int32_t cout) {

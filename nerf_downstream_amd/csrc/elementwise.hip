@@ -454,6 +454,17 @@ int mink_bn_stats(const float *x, int64_t n, int32_t C, float eps, float momentu
   return MINK_OK;
 }
 
+int mink_bn_stats_from_partials(const double *partial, int32_t rows, int64_t n, int32_t C, float eps, float momentum,
+                                float *mean, float *invstd, float *running_mean, float *running_var, void *stream) {
+  MINK_REQUIRE(partial && rows >= 1 && n >= 1 && C >= 1 && mean && invstd, "bn_stats_from_partials: bad arguments");
+  MINK_REQUIRE((running_mean == nullptr) == (running_var == nullptr),
+               "bn_stats_from_partials: running stats must come in pairs");
+  bn_stats_finalize_kernel<<<dim3((unsigned)cdiv(C, kFinCh)), 256, 0, (hipStream_t)stream>>>(
+      partial, rows, n, C, eps, momentum, mean, invstd, running_mean, running_var);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
 int mink_bn_apply(const float *x, int64_t n, int32_t C, const float *mean, const float *invstd, const float *gamma,
                   const float *beta, const float *residual, int32_t relu, float *y, void *stream) {
   REQ_C4(C, "bn_apply");

@@ -4,6 +4,7 @@
 Semantics follow SURVEY.md Appendix A (A6 convolution, A8 batch norm, A9 sum pooling,
 A10 global average pooling); the reference call sites are cited on the modules.
 """
+import ctypes
 import os
 
 import torch
@@ -99,8 +100,10 @@ class _timed:
 _FORCE_KSPLIT = 0  # benchmarking hook (scripts/kbench.py ksweep)
 
 
-def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, row_perm=None):
-    """y[o] = sum_k x[nbr[o,k]] @ W[k] (+bias) on the fp32 matrix cores."""
+def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, row_perm=None, stats=False):
+    """y[o] = sum_k x[nbr[o,k]] @ W[k] (+bias) on the fp32 matrix cores.  `stats=True` (forward
+    only) also returns the column (sum, sum of squares) partials [rows,2,cout] (float64) of y for
+    the batch norm that follows, or None when the launch shape cannot produce them."""
     L = lib()
     n_out, K = nbr.shape
     cin = x.shape[1]
@@ -109,15 +112,28 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, ro
     ksplit = _FORCE_KSPLIT or int(L.mink_conv_plan_ksplit(n_rows, K, cout, int(row_perm is not None)))
     ws = _scratch(4 * ksplit * n_out * cout, x.device, "splitk") if ksplit > 1 else None
     tag = f"{'dgrad' if w_transposed else 'fwd'}[{n_out}x{K}:{cin}->{cout}]"
+    partial = None
     with _timed(tag, kind="gather_gemm", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr, ksplit=ksplit):
-        check(
-            L.mink_conv_gather_gemm(
-                x.data_ptr(), x.stride(0), cin, w.data_ptr(), int(w_transposed), int(flip_k), nbr.data_ptr(), n_out, K,
-                _ptr(row_perm), 0 if row_perm is None else row_perm.numel(),
-                y.data_ptr(), cout, cout, _ptr(bias), ksplit, _ptr(ws), _stream(),
+        if stats and not w_transposed and row_perm is None and n_out > 0:
+            partial = torch.empty(512, 2, cout, dtype=torch.float64, device=x.device)
+            sws = _scratch(L.mink_conv_stats_workspace_bytes(n_out, cout), x.device, "convstats")
+            rows = ctypes.c_int32(0)
+            check(
+                L.mink_conv_gather_gemm_stats(
+                    x.data_ptr(), x.stride(0), cin, w.data_ptr(), nbr.data_ptr(), n_out, K, y.data_ptr(), cout, cout,
+                    _ptr(bias), ksplit, _ptr(ws), partial.data_ptr(), ctypes.addressof(rows), sws.data_ptr(), _stream(),
+                )
             )
-        )
-    return y
+            partial = partial[: rows.value] if rows.value > 0 else None
+        else:
+            check(
+                L.mink_conv_gather_gemm(
+                    x.data_ptr(), x.stride(0), cin, w.data_ptr(), int(w_transposed), int(flip_k), nbr.data_ptr(), n_out, K,
+                    _ptr(row_perm), 0 if row_perm is None else row_perm.numel(),
+                    y.data_ptr(), cout, cout, _ptr(bias), ksplit, _ptr(ws), _stream(),
+                )
+            )
+    return (y, partial) if stats else y
 
 
 def conv_wgrad(x, dy, nbr, kernel_shape):
@@ -219,7 +235,9 @@ class ConvolutionFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, kernel, table_fn, same_map):
+    def forward(ctx, x, kernel, table_fn, same_map, stats_holder=None):
+        """`stats_holder`: a list that receives the column-statistics partials of the output (or
+        None) -- the batch norm that follows then skips its own reduction pass."""
         x = _f32c(x)
         w = _f32c(kernel)
         cin = x.shape[1]
@@ -233,7 +251,11 @@ class ConvolutionFunction(torch.autograd.Function):
         nbr = table_fn(False)[0]
         ctx.save_for_backward(x, w)
         ctx.table_fn, ctx.same_map, ctx.nbr = table_fn, same_map, nbr
-        return gather_gemm(x, w, nbr, w.shape[-1])
+        if stats_holder is None:
+            return gather_gemm(x, w, nbr, w.shape[-1])
+        y, partial = gather_gemm(x, w, nbr, w.shape[-1], stats=True)
+        stats_holder.append(partial)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
@@ -285,16 +307,41 @@ class ConvolutionFunction(torch.autograd.Function):
                 gw = conv_wgrad(x, gy, ctx.nbr, w.shape)
             if gw.shape[1] != ctx.cin:  # drop the gradient of the zero-padded input channels
                 gw = gw[:, : ctx.cin].contiguous()
-        return gx, gw, None, None
+        return gx, gw, None, None, None
 
 
 # -------------------------------------------------------------------------- batch norm
+def _bn_statistics(L, x, n, C, eps, momentum, running_mean, running_var, partial):
+    """mean / invstd of the batch (+ running-stat update): from the producer's column partials
+    when it supplied them, else by a reduction pass over x."""
+    dev = x.device
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    invstd = torch.empty(C, dtype=torch.float32, device=dev)
+    mom = momentum if running_mean is not None else 0.0
+    if partial is not None:
+        check(
+            L.mink_bn_stats_from_partials(
+                partial.data_ptr(), partial.shape[0], n, C, eps, mom, mean.data_ptr(), invstd.data_ptr(),
+                _ptr(running_mean), _ptr(running_var), _stream(),
+            )
+        )
+    else:
+        ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
+        check(
+            L.mink_bn_stats(
+                x.data_ptr(), n, C, eps, mom, mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                ws.data_ptr(), _stream(),
+            )
+        )
+    return mean, invstd
+
+
 class BatchNormFunction(torch.autograd.Function):
     """BatchNorm1d over the rows of F, optionally fused with the residual add and ReLU that
     follow it in the reference block (modules/resnet_block.py:53-69; A8)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, residual, relu, partial=None):
         L = lib()
         x = _f32c(x)
         n, C = x.shape
@@ -302,7 +349,7 @@ class BatchNormFunction(torch.autograd.Function):
         if residual is not None:
             residual = _f32c(residual)
         y = torch.empty_like(x)
-        if training:
+        if training and partial is None:
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             invstd = torch.empty(C, dtype=torch.float32, device=dev)
             ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
@@ -314,8 +361,11 @@ class BatchNormFunction(torch.autograd.Function):
                 )
             )
         else:
-            mean = running_mean.float()
-            invstd = torch.rsqrt(running_var.float() + eps)
+            if training:
+                mean, invstd = _bn_statistics(L, x, n, C, eps, momentum, running_mean, running_var, partial)
+            else:
+                mean = running_mean.float()
+                invstd = torch.rsqrt(running_var.float() + eps)
             check(
                 L.mink_bn_apply(
                     x.data_ptr(), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
@@ -337,7 +387,7 @@ class BatchNormFunction(torch.autograd.Function):
             g = gy * (y > 0) if ctx.relu else gy
             xhat = (x - mean) * invstd
             return (g * (gamma * invstd), (g * xhat).sum(0), g.sum(0), None, None, None, None, None,
-                    g if ctx.has_res else None, None)
+                    g if ctx.has_res else None, None, None)
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if ctx.has_res else None
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
@@ -349,7 +399,7 @@ class BatchNormFunction(torch.autograd.Function):
                 int(ctx.relu), gx.data_ptr(), _ptr(gres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(),
             )
         )
-        return gx, dgamma, dbeta, None, None, None, None, None, gres, None
+        return gx, dgamma, dbeta, None, None, None, None, None, gres, None, None
 
 
 class SyncBatchNormFunction(torch.autograd.Function):
@@ -427,21 +477,13 @@ class BNReLUSumPoolFunction(torch.autograd.Function):
     largest activation of the network -- is never written; backward recomputes the ReLU mask."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, nbr, in2out):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, nbr, in2out, partial=None):
         L = lib()
         x = _f32c(x)
         n, C = x.shape
         dev = x.device
         if training:
-            mean = torch.empty(C, dtype=torch.float32, device=dev)
-            invstd = torch.empty(C, dtype=torch.float32, device=dev)
-            ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
-            check(
-                L.mink_bn_stats(
-                    x.data_ptr(), n, C, eps, momentum if running_mean is not None else 0.0, mean.data_ptr(),
-                    invstd.data_ptr(), _ptr(running_mean), _ptr(running_var), ws.data_ptr(), _stream(),
-                )
-            )
+            mean, invstd = _bn_statistics(L, x, n, C, eps, momentum, running_mean, running_var, partial)
         else:
             mean = running_mean.float()
             invstd = torch.rsqrt(running_var.float() + eps)
@@ -475,7 +517,7 @@ class BNReLUSumPoolFunction(torch.autograd.Function):
                 ctx.in2out.data_ptr(), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(),
             )
         )
-        return gx, dgamma, dbeta, None, None, None, None, None, None, None
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- eltwise

@@ -49,10 +49,14 @@ class MinkowskiConvolution(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-stdv, stdv)
 
-    def forward(self, input, coordinates=None):
+    def forward(self, input, coordinates=None, bn_stats=False):
+        """`bn_stats` (extension): also produce the per-channel (sum, sum of squares) partials of the
+        output while it is being written (attribute `_bn_partial` of the result), so that a
+        MinkowskiBatchNorm in training mode applied to it skips its own reduction pass."""
         assert coordinates is None, "explicit output coordinates are out of scope"
         m = input.coordinate_manager
         in_key = input.coordinate_map_key
+        holder = [] if (bn_stats and self.bias is None and not self.use_mm) else None
         if self.use_mm:  # plain matmul on the feature matrix, same coordinates
             out_key = in_key
             out = input.F.mm(self.kernel)
@@ -65,10 +69,13 @@ class MinkowskiConvolution(nn.Module):
                 perm = m.class_perm(in_key) if transposed and self.stride == 2 else None
                 return nbr, nbr_t, perm
 
-            out = Fn.ConvolutionFunction.apply(input.F, self.kernel, table_fn, self.stride == 1)
+            out = Fn.ConvolutionFunction.apply(input.F, self.kernel, table_fn, self.stride == 1, holder)
         if self.bias is not None:
             out = out + self.bias
-        return SparseTensor(out, out_key, m)
+        res = SparseTensor(out, out_key, m)
+        if holder:
+            res._bn_partial = holder[0]
+        return res
 
     def extra_repr(self):
         return (f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, "
@@ -100,7 +107,8 @@ class MinkowskiBatchNorm(nn.Module):
         out = Fn.BatchNormFunction.apply(
             input.F, gamma, beta, bn.running_mean, bn.running_var, training,
             bn.momentum if bn.momentum is not None else 0.1, bn.eps,
-            residual.F if residual is not None else None, bool(relu))
+            residual.F if residual is not None else None, bool(relu),
+            getattr(input, "_bn_partial", None) if training else None)
         return SparseTensor(out, input.coordinate_map_key, input.coordinate_manager)
 
 
@@ -180,7 +188,8 @@ class MinkowskiSumPooling(nn.Module):
             if training and bn.track_running_stats and not norm.counted_by_parent:
                 bn.num_batches_tracked += 1
             out = Fn.BNReLUSumPoolFunction.apply(input.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                                                 bn.momentum if bn.momentum is not None else 0.1, bn.eps, nbr, i2o)
+                                                 bn.momentum if bn.momentum is not None else 0.1, bn.eps, nbr, i2o,
+                                                 getattr(input, "_bn_partial", None) if training else None)
         else:
             if norm is not None:
                 input = norm(input, relu=True)
