@@ -211,6 +211,18 @@ int64_t mink_conv_wgrad_workspace_bytes(int64_t n_out, int32_t K, int32_t cin, i
 int mink_conv_wgrad(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *dy, int32_t ldy,
                     int32_t cout, const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace,
                     void *stream);
+/* Weight gradient of a convolution whose output y feeds  pool(relu(bn(y)))  (the stem of the
+ * reference ResNets, resnet.py:58-64) and whose input needs no gradient: the gradient with respect
+ * to y is recomputed from (y, pooled gradient, batch statistics, dgamma, dbeta -- mink_bn_relu_pool_bwd
+ * with dx = NULL) inside the kernel's operand load and never written to memory.
+ * Only for shapes the streaming kernel takes (K = 27, cin <= 32, many rows): ask _supported() first. */
+int mink_conv_wgrad_bn_relu_pool_supported(int64_t n_in, int32_t ldx, int32_t cin, int64_t n_out, int32_t K,
+                                           int32_t cout);
+int mink_conv_wgrad_bn_relu_pool(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *y, int32_t cout,
+                                 const float *dy_pool, int64_t n_pool, const int32_t *in2out, const float *mean,
+                                 const float *invstd, const float *gamma, const float *beta,
+                                 const float *dgamma, const float *dbeta, const int32_t *nbr, int64_t n_out,
+                                 int32_t K, float *dw, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------ pooling / reductions
  * MinkowskiSumPooling(k=2,s=2) (resnet.py:62-64): out[o] = sum_k in[nbr[o][k]] with the

@@ -54,6 +54,11 @@ SIGNATURES = {
     "mink_bn_stats_from_partials": (ctypes.c_int, [_p, _i32, _i64, _i32, _f32, _f32, _p, _p, _p, _p, _p]),
     "mink_conv_wgrad_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32]),
     "mink_conv_wgrad": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _p, _p]),
+    "mink_conv_wgrad_bn_relu_pool_supported": (ctypes.c_int, [_i64, _i32, _i32, _i64, _i32, _i32]),
+    "mink_conv_wgrad_bn_relu_pool": (
+        ctypes.c_int,
+        [_p, _i64, _i32, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p],
+    ),
     "mink_pool_sum_fwd": (ctypes.c_int, [_p, _i32, _i32, _p, _i64, _i32, _p, _p]),
     "mink_pool_sum_bwd": (ctypes.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "mink_global_avg_fwd": (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p]),

@@ -78,7 +78,9 @@ class ResNetBase(MinkowskiBaseModel):
             torch._foreach_add_([m.bn.num_batches_tracked for m in self._norms], 1)
         if self._fused:  # bn1 -> relu -> pool in one pass over the finest-level activation; its
             # statistics come out of the stem convolution's epilogue (no extra pass over 825 k x 64)
-            out = self.pool(self.conv1(x.sparse(), bn_stats=self.training), norm=self.bn1)
+            # -- and, in training, conv1 + bn1 + relu + pool are one autograd node (the input needs no
+            # gradient) whose backward keeps the gradient of the convolution output in registers
+            out = self.pool(x.sparse(), norm=self.bn1, conv=self.conv1)
         else:
             out = self.pool(self.relu(self.bn1(self.conv1(x.sparse()))))
         out = self.layer4(self.layer3(self.layer2(self.layer1(out))))

@@ -765,6 +765,13 @@ struct WgradParams {
   int64_t n_out, rows_per_split;
   int ldx, cin, ldy, cout, K, ct_tiles, ngroups, ablate;
   unsigned x_bytes, dy_bytes, nbr_bytes;  // streaming kernel only (buffer descriptors)
+  // streaming kernel, FUSE: `dy` is the batch-norm INPUT y and the B operand is recomputed on the fly as the
+  // input gradient of  pool(relu(bn(y)))  from the pooled gradient -- that gradient is never materialised
+  const float *dyp;   // [n_pool][cout] gradient of the pooled output
+  const int *in2out;  // [n_out] fine row -> pooled row
+  const float *mean, *invstd, *gamma, *beta, *dgamma, *dbeta;
+  float inv_n;
+  unsigned dyp_bytes, i2o_bytes;
 };
 
 // G: offsets per workgroup.  NARROW: cin <= 32 -- the x tile is 32 floats wide and the two
@@ -958,7 +965,7 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byt
 }
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 
-template <int D>
+template <int D, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   static_assert(D % 2 == 0, "the neighbour staging ring has two slots");
   constexpr int G = 9;                   // K == 27: three groups of nine offsets
@@ -984,6 +991,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   const unsigned xcol = 4u * min(col, p.cin - 1);
   const unsigned dcol = 4u * min(co0 + 32 * wn + col, p.cout - 1);
   const unsigned ncol = col < G ? 4u * (k0 + col) : OOB;
+  // FUSE: per-lane constants of this lane's output channel
+  const int cco = min(co0 + 32 * wn + col, p.cout - 1);
+  const __amdgpu_buffer_rsrc_t rp = make_rsrc(FUSE ? (const void *)p.dyp : (const void *)p.dy, FUSE ? p.dyp_bytes : 0u),
+                               ri = make_rsrc(FUSE ? (const void *)p.in2out : (const void *)p.nbr, FUSE ? p.i2o_bytes : 0u);
+  const float c_mu = FUSE ? p.mean[cco] : 0.f, c_is = FUSE ? p.invstd[cco] : 0.f, c_ga = FUSE ? p.gamma[cco] : 0.f,
+              c_be = FUSE ? p.beta[cco] : 0.f, c_dgn = FUSE ? p.dgamma[cco] * p.inv_n : 0.f,
+              c_dbn = FUSE ? p.dbeta[cco] * p.inv_n : 0.f;
+  float dp[D];        // FUSE: pooled gradient of the row's parent
+  unsigned i2or[D];   // FUSE: parent row of a pair whose operands are still to be requested
 
   f32x16 acc[G];
 #pragma unroll
@@ -1003,9 +1019,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   auto stash = [&](int s, int slot) {
     sN[wave][slot][h][col] = nraw[s];  // lanes col >= 9 store padding: no exec-mask branch in the loop
   };
+  auto load_i2o = [&](int s, int q) {  // (a row past the end reads parent 0: its x operand is zero anyway)
+    if (FUSE) {
+      const int64_t R = row_of(q);
+      i2or[s] = __builtin_amdgcn_raw_buffer_load_b32(ri, (int)(R < rend ? (unsigned)R * 4u : OOB), 0, 0);
+    }
+  };
   auto load_dy = [&](int s, int q) {
     const int64_t R = row_of(q);
     db[s] = buf_load(rd, R < rend ? (unsigned)R * ldy4 + dcol : OOB);
+    if (FUSE) dp[s] = buf_load(rp, __umul24(i2or[s], ldy4) + dcol);  // the pooled gradient has the same row pitch
+  };
+  auto b_operand = [&](int s) {
+    if (!FUSE) return db[s];
+    const float xh = (db[s] - c_mu) * c_is;
+    const float g = xh * c_ga + c_be > 0.f ? dp[s] : 0.f;
+    return c_ga * c_is * (g - c_dbn - xh * c_dgn);
   };
   auto load_xs = [&](int s, int slot, int q, auto &&between) {  // the nine x values of pair q
     const uint4 n0 = *reinterpret_cast<const uint4 *>(&sN[wave][slot][h][0]);
@@ -1022,7 +1051,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
 
   if (rbeg < rend) {
 #pragma unroll
-    for (int s = 0; s < D; ++s) load_raw(s, s);
+    for (int s = 0; s < D; ++s) {
+      load_raw(s, s);
+      load_i2o(s, s);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < D; ++s) {  // same load order as the loop body: the vmcnt waits there are FIFO distances
@@ -1030,13 +1062,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
       load_xs(s, s & 1, s, [](int) {});
       load_dy(s, s);
       load_raw(s, s + D);
+      load_i2o(s, s + D);
       __builtin_amdgcn_sched_barrier(0);
     }
     stash(0, 0);  // pair D
     for (int q0 = 0; q0 < nq; q0 += D) {
 #pragma unroll
       for (int s = 0; s < D; ++s) {  // pair q0 + s from slot s; pairs past nq were loaded as zeros
-        const float b = db[s];
+        const float b = b_operand(s);
         float a[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) a[g] = xa[s][g];
@@ -1046,6 +1079,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
         load_dy(s, q0 + s + D);
         stash((s + 1) % D, (s + 1) & 1);  // pair q0 + s + D + 1, loaded D - 1 pairs ago
         load_raw(s, q0 + s + 2 * D);
+        load_i2o(s, q0 + s + 2 * D);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
@@ -1300,8 +1334,21 @@ int64_t mink_conv_wgrad_workspace_bytes(int64_t n_out, int32_t K, int32_t cin, i
   return pl.nsplit > 1 ? (int64_t)pl.nsplit * K * cin * cout * 4 : 0;
 }
 
-int mink_conv_wgrad(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
-                    const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace, void *stream) {
+struct WgradFuse {  // dy = input gradient of pool(relu(bn(y))): see mink_conv_wgrad_bn_relu_pool
+  const float *dyp;
+  const int32_t *in2out;
+  int64_t n_pool;
+  const float *mean, *invstd, *gamma, *beta, *dgamma, *dbeta;
+};
+
+static bool wgrad_stream_ok(int64_t n_in, int32_t ldx, int32_t cin, int32_t ldy, int32_t cout, int64_t n_out, int32_t K) {
+  return K == 27 && cin <= 32 && ldx < 64 && n_in < (1 << 24) && 4 * n_in * ldx < (1ll << 31) &&
+         4 * n_out * ldy < (1ll << 31) && 4 * n_out * K < (1ll << 31);  // what the buffer-offset arithmetic assumes
+}
+
+static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
+                      const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace, const WgradFuse *fuse,
+                      void *stream) {
   MINK_REQUIRE(K >= 1 && K <= KMAX && cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0 && n_in >= 0,
                "wgrad: bad shape");
   MINK_REQUIRE(dw, "wgrad: NULL dw");
@@ -1322,9 +1369,15 @@ int mink_conv_wgrad(const float *x, int64_t n_in, int32_t ldx, int32_t cin, cons
   const dim3 grid((unsigned)(pl.ngroups * cdiv(cin, WT) * p.ct_tiles), (unsigned)pl.nsplit);
   const int64_t xb = 4 * n_in * ldx, db = 4 * n_out * ldy, nb = 4 * n_out * K;
   p.x_bytes = (unsigned)xb, p.dy_bytes = (unsigned)db, p.nbr_bytes = (unsigned)nb;
-  const bool stream_ok = K == 27 && cin <= 32 && ldx < 64 && n_in < (1 << 24) && xb < (1ll << 31) && db < (1ll << 31) &&
-                         nb < (1ll << 31);  // what the buffer-offset arithmetic of the streaming kernel assumes
-  if (pl.G == 9 && stream_ok && g_wgrad_stream) wgrad_stream_kernel<4><<<grid, 256, 0, st>>>(p);
+  const bool stream_ok = wgrad_stream_ok(n_in, ldx, cin, ldy, cout, n_out, K);
+  if (fuse) {
+    MINK_REQUIRE(pl.G == 9 && stream_ok && g_wgrad_stream && 4 * fuse->n_pool * ldy < (1ll << 31),
+                 "wgrad_bn_relu_pool: shape not supported by the streaming kernel (ask mink_conv_wgrad_bn_relu_pool_supported)");
+    p.dyp = fuse->dyp, p.in2out = fuse->in2out, p.mean = fuse->mean, p.invstd = fuse->invstd, p.gamma = fuse->gamma;
+    p.beta = fuse->beta, p.dgamma = fuse->dgamma, p.dbeta = fuse->dbeta, p.inv_n = 1.f / (float)n_out;
+    p.dyp_bytes = (unsigned)(4 * fuse->n_pool * ldy), p.i2o_bytes = (unsigned)(4 * n_out);
+    wgrad_stream_kernel<4, true><<<grid, 256, 0, st>>>(p);
+  } else if (pl.G == 9 && stream_ok && g_wgrad_stream) wgrad_stream_kernel<4><<<grid, 256, 0, st>>>(p);
   else if (pl.G == 9) launch_wgrad<9>(p, grid, st);
   else if (pl.G == 3) launch_wgrad<3>(p, grid, st);
   else launch_wgrad<1>(p, grid, st);
@@ -1335,6 +1388,27 @@ int mink_conv_wgrad(const float *x, int64_t n_in, int32_t ldx, int32_t cin, cons
     MINK_CHECK_LAUNCH();
   }
   return MINK_OK;
+}
+
+int mink_conv_wgrad(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
+                    const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace, void *stream) {
+  return wgrad_impl(x, n_in, ldx, cin, dy, ldy, cout, nbr, n_out, K, dw, workspace, nullptr, stream);
+}
+
+int mink_conv_wgrad_bn_relu_pool_supported(int64_t n_in, int32_t ldx, int32_t cin, int64_t n_out, int32_t K, int32_t cout) {
+  if (n_out <= 0) return 0;
+  return wgrad_plan(n_out, K, cin, cout).G == 9 && wgrad_stream_ok(n_in, ldx, cin, cout, cout, n_out, K) && g_wgrad_stream;
+}
+
+int mink_conv_wgrad_bn_relu_pool(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *y, int32_t cout,
+                                 const float *dy_pool, int64_t n_pool, const int32_t *in2out, const float *mean,
+                                 const float *invstd, const float *gamma, const float *beta, const float *dgamma,
+                                 const float *dbeta, const int32_t *nbr, int64_t n_out, int32_t K, float *dw,
+                                 void *workspace, void *stream) {
+  MINK_REQUIRE(y && dy_pool && in2out && mean && invstd && gamma && beta && dgamma && dbeta && n_pool >= 1,
+               "wgrad_bn_relu_pool: NULL pointer");
+  const WgradFuse f = {dy_pool, in2out, n_pool, mean, invstd, gamma, beta, dgamma, dbeta};
+  return wgrad_impl(x, n_in, ldx, cin, y, cout, cout, nbr, n_out, K, dw, workspace, &f, stream);
 }
 
 }  // extern "C"

@@ -578,11 +578,11 @@ int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32
                           const float *invstd, const float *gamma, const float *beta, const int32_t *in2out, float *dx,
                           float *dgamma, float *dbeta, void *workspace, void *stream) {
   REQ_C4(C, "bn_relu_pool_bwd");
-  MINK_REQUIRE(n >= 1 && dy_pool && x && mean && invstd && gamma && beta && in2out && dx && dgamma && dbeta && workspace,
+  MINK_REQUIRE(n >= 1 && dy_pool && x && mean && invstd && gamma && beta && in2out && dgamma && dbeta && workspace,
                "bn_relu_pool_bwd: bad arguments");
   REQ_A16(dy_pool, "bn_relu_pool_bwd");
   REQ_A16(x, "bn_relu_pool_bwd");
-  REQ_A16(dx, "bn_relu_pool_bwd");
+  REQ_A16(dx, "bn_relu_pool_bwd");  // dx == NULL: parameter gradients only (the consumer recomputes dx on the fly)
   hipStream_t st = (hipStream_t)stream;
   const int tpr = C >> 2;
   MINK_REQUIRE(tpr <= EB, "bn_relu_pool_bwd: too many channels");
@@ -596,6 +596,7 @@ int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32
   bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, kFinCh)), 256, 0, st>>>((const double *)workspace, (int)nblk, C, gamma,
                                                                      dgamma, dbeta);
   MINK_CHECK_LAUNCH();
+  if (!dx) return MINK_OK;
   const int64_t n4 = n * (C >> 2);
   bn_relu_pool_bwd_kernel<<<dim3(ew_grid(n4)), EB, 0, st>>>(dy_pool, x, in2out, n, C >> 2, 1.f / (float)n, mean, invstd,
                                                            gamma, beta, dgamma, dbeta, dx);

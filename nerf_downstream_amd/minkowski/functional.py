@@ -520,6 +520,77 @@ class BNReLUSumPoolFunction(torch.autograd.Function):
         return gx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+class ConvBNReLUSumPoolFunction(torch.autograd.Function):
+    """pool(relu(bn(conv(x)))) of the network stem (reference resnet.py:58-64) as ONE autograd node,
+    for an input that needs no gradient: forward = convolution (+ column statistics in its epilogue)
+    and the fused bn+relu+sum-pool pass; backward = (dgamma, dbeta) reduction and the streaming
+    weight-gradient kernel recomputing the gradient w.r.t. the conv output inside its operand load
+    -- neither bn(conv(x)) nor its gradient (825 k x 64 floats each at B=16) is ever written."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, gamma, beta, running_mean, running_var, momentum, eps, nbr, nbr_pool, in2out):
+        L = lib()
+        x, w = _f32c(x), _f32c(kernel)
+        cin = x.shape[1]
+        ctx.cin = cin
+        if cin % 4:
+            pad = 4 - cin % 4
+            x = torch.nn.functional.pad(x, (0, pad))
+            w = torch.nn.functional.pad(w, (0, 0, 0, pad))
+        C = w.shape[-1]
+        y, partial = gather_gemm(x, w, nbr, C, stats=True)
+        n = y.shape[0]
+        mean, invstd = _bn_statistics(L, y, n, C, eps, momentum, running_mean, running_var, partial)
+        n_pool, K = nbr_pool.shape
+        out = torch.empty(n_pool, C, dtype=torch.float32, device=x.device)
+        check(
+            L.mink_bn_relu_pool_fwd(
+                y.data_ptr(), C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), nbr_pool.data_ptr(),
+                n_pool, K, out.data_ptr(), _stream(),
+            )
+        )
+        ctx.save_for_backward(x, w, y, mean, invstd, gamma, beta)
+        ctx.nbr, ctx.in2out = nbr, in2out
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = lib()
+        x, w, y, mean, invstd, gamma, beta = ctx.saved_tensors
+        gy = _f32c(gy)
+        n, C = y.shape
+        dev = y.device
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
+        check(
+            L.mink_bn_relu_pool_bwd(
+                gy.data_ptr(), y.data_ptr(), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                ctx.in2out.data_ptr(), None, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(),
+            )
+        )
+        nbr = ctx.nbr
+        K = nbr.shape[1]
+        gw = torch.empty(w.shape, dtype=torch.float32, device=dev)
+        wws = _scratch(L.mink_conv_wgrad_workspace_bytes(n, K, x.shape[1], C), dev, "wgrad")
+        with _timed(f"wgrad[{n}x{K}:{x.shape[1]}->{C}]", kind="wgrad", n_in=x.shape[0], n_out=n, K=K, cin=x.shape[1], cout=C, nbr=nbr):
+            check(
+                L.mink_conv_wgrad_bn_relu_pool(
+                    x.data_ptr(), x.shape[0], x.stride(0), x.shape[1], y.data_ptr(), C, gy.data_ptr(), gy.shape[0],
+                    ctx.in2out.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                    dgamma.data_ptr(), dbeta.data_ptr(), nbr.data_ptr(), n, K, gw.data_ptr(), wws.data_ptr(), _stream(),
+                )
+            )
+        if gw.shape[1] != ctx.cin:
+            gw = gw[:, : ctx.cin].contiguous()
+        return None, gw, dgamma, dbeta, None, None, None, None, None, None, None
+
+    @staticmethod
+    def supported(x, kernel, nbr):
+        cin = x.shape[1] + (-x.shape[1]) % 4
+        return bool(lib().mink_conv_wgrad_bn_relu_pool_supported(x.shape[0], cin, cin, nbr.shape[0], nbr.shape[1], kernel.shape[-1]))
+
+
 # ----------------------------------------------------------------------------- eltwise
 def _eltwise(a, b, mode):
     y = torch.empty_like(a)

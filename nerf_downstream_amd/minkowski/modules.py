@@ -174,9 +174,17 @@ class MinkowskiSumPooling(nn.Module):
         assert self.kernel_size == self.stride and self.kernel_size ** 3 <= 27, \
             "only non-overlapping pooling (kernel_size == stride) is implemented"
 
-    def forward(self, input, norm=None):
+    def forward(self, input, norm=None, conv=None):
         """`norm` (extension): a MinkowskiBatchNorm to apply, followed by ReLU, to `input` on the
-        fly -- pool(relu(norm(input))) in one pass without materialising the normalised tensor."""
+        fly -- pool(relu(norm(input))) in one pass without materialising the normalised tensor.
+        `conv` (extension, with `norm`): a MinkowskiConvolution to apply first --
+        pool(relu(norm(conv(input)))), the stem of the reference ResNets, as one autograd node
+        whose backward never materialises the gradient of the convolution output either."""
+        if conv is not None:
+            fused = self._conv_norm_pool(input, norm, conv)
+            if fused is not None:
+                return fused
+            input = conv(input, bn_stats=norm is not None and norm.bn.training)
         m, in_key = input.coordinate_manager, input.coordinate_map_key
         out_key = m.stride(in_key, self.stride)
         nbr, _ = m.kernel_table(in_key, out_key, self.kernel_size, 1)
@@ -194,6 +202,30 @@ class MinkowskiSumPooling(nn.Module):
             if norm is not None:
                 input = norm(input, relu=True)
             out = Fn.SumPoolFunction.apply(input.F, nbr, i2o)
+        return SparseTensor(out, out_key, m)
+
+
+    def _conv_norm_pool(self, input, norm, conv):
+        """The fully fused stem, or None when it does not apply (eval mode, input gradient wanted,
+        conv with bias / stride, SyncBN, or a shape the streaming weight-gradient kernel leaves
+        to the general one)."""
+        if (norm is None or type(norm) is not MinkowskiBatchNorm or not norm.bn.affine or not norm.bn.training
+                or not norm.bn.track_running_stats or conv.bias is not None or conv.use_mm or conv.stride != 1
+                or conv.kernel_volume != 27 or conv.dilation != 1 or input.F.requires_grad or not torch.is_grad_enabled()):
+            return None
+        m, in_key = input.coordinate_manager, input.coordinate_map_key
+        nbr, _ = m.kernel_table(in_key, in_key, conv.kernel_size, conv.dilation)
+        if not Fn.ConvBNReLUSumPoolFunction.supported(input.F, conv.kernel, nbr):
+            return None
+        out_key = m.stride(in_key, self.stride)
+        nbr_pool, _ = m.kernel_table(in_key, out_key, self.kernel_size, 1)
+        i2o = m.stride_map(in_key, out_key)
+        bn = norm.bn
+        if not norm.counted_by_parent:
+            bn.num_batches_tracked += 1
+        out = Fn.ConvBNReLUSumPoolFunction.apply(
+            input.F, conv.kernel, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+            bn.momentum if bn.momentum is not None else 0.1, bn.eps, nbr, nbr_pool, i2o)
         return SparseTensor(out, out_key, m)
 
 

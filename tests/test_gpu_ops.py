@@ -335,3 +335,35 @@ def test_full_size_stem_convolution_against_fp64_torch():
         err = float((got.double() - ref).abs().max())
         assert err <= 3e-5 * scale, (name, err, scale)  # fp32 sums of <= 756 (fwd/dgrad) / ~6e5 (wgrad) products
     assert torch.allclose(Fn.gather_gemm(2.0 * xin, w, nbr, 64), 2.0 * y, rtol=1e-6, atol=1e-6)  # exact scaling by 2
+
+
+@pytest.mark.parametrize("cin", [28, 27])
+def test_fused_stem_conv_bn_relu_pool(cin):
+    """pool(relu(bn(conv(x)))) as one autograd node (weight gradient with the batch-norm backward
+    folded into its operand load) against the same modules applied one after the other, at a size
+    the streaming kernel takes (124 k rows)."""
+    import copy
+
+    from nerf_downstream_amd import minkowski as ME
+
+    coords, feats = batch_scenes([41, 42, 43], grid=80, cin=cin)
+    x = ME.TensorField(coordinates=coords.cuda(), features=feats.cuda()).sparse()
+    torch.manual_seed(cin)
+    conv = ME.MinkowskiConvolution(cin, 64, kernel_size=3, dimension=3).cuda()
+    bn = ME.MinkowskiBatchNorm(64).cuda()
+    with torch.no_grad():
+        bn.bn.weight.uniform_(0.5, 1.5), bn.bn.bias.uniform_(-0.3, 0.3)
+    conv2, bn2 = copy.deepcopy(conv), copy.deepcopy(bn)
+    pool = ME.MinkowskiSumPooling(kernel_size=2, stride=2, dimension=3)
+    fused = pool(x, norm=bn, conv=conv)
+    assert type(fused.F.grad_fn).__name__ == "ConvBNReLUSumPoolFunctionBackward"  # the fused node really ran
+    plain = pool(conv2(x), norm=bn2)
+    assert torch.allclose(fused.F, plain.F, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(bn.bn.running_var, bn2.bn.running_var, rtol=1e-5) and int(bn.bn.num_batches_tracked) == 1
+    g = torch.randn_like(plain.F)
+    fused.F.backward(g)
+    plain.F.backward(g)
+    for a, b, name in ((conv.kernel.grad, conv2.kernel.grad, "dW"), (bn.bn.weight.grad, bn2.bn.weight.grad, "dgamma"),
+                       (bn.bn.bias.grad, bn2.bn.bias.grad, "dbeta")):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (name, float((a - b).abs().max()), scale)
