@@ -136,11 +136,13 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, ro
     return (y, partial) if stats else y
 
 
-def conv_wgrad(x, dy, nbr, kernel_shape):
+def conv_wgrad(x, dy, nbr, kernel_shape, out=None):
+    """dW[k] = X[nbr[:, k]]^T dY.  `out`: write into this contiguous fp32 tensor (a slice of a
+    data-parallel reducer's flat gradient buffer) instead of a fresh one."""
     L = lib()
     n_out, K = nbr.shape
     cin, cout = x.shape[1], dy.shape[1]
-    dw = torch.empty(kernel_shape, dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty(kernel_shape, dtype=torch.float32, device=x.device)
     ws = _scratch(L.mink_conv_wgrad_workspace_bytes(n_out, K, cin, cout), x.device, "wgrad")
     with _timed(f"wgrad[{n_out}x{K}:{cin}->{cout}]", kind="wgrad", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr):
         check(
@@ -169,6 +171,20 @@ def set_wgrad_overlap(on=True):
     return old
 
 
+_GRAD_SINK = None  # a data-parallel reducer that owns the gradient memory (see set_grad_sink)
+
+
+def set_grad_sink(sink):
+    """`sink.view_for(param)` -> the tensor the weight gradient of `param` is to be WRITTEN into (or
+    None: hand the gradient to autograd as usual); `sink.ready(param)` is called once that write
+    has been queued.  This lets a bucketed all-reduce keep the weight-gradient side stream: without
+    it every gradient would have to be accumulated into the reducer's buffer on the compute stream,
+    i.e. joined layer by layer."""
+    global _GRAD_SINK
+    old, _GRAD_SINK = _GRAD_SINK, sink
+    return old
+
+
 _DEFERRED = {"pending": False, "callback": False}
 _HOME_STREAMS = {}  # device index -> the stream the network itself runs on (noted where a branch forks off)
 _BRANCH_STREAMS = {}
@@ -183,6 +199,10 @@ def skew(stream):
     if _SKEW:
         with torch.cuda.stream(stream):
             torch.cuda._sleep(_SKEW)
+
+
+def side_stream_if_any(device):
+    return _SIDE_STREAMS.get(device.index)
 
 
 def compute_streams(device):
@@ -279,11 +299,20 @@ class ConvolutionFunction(torch.autograd.Function):
                 _, nbr_t, perm = ctx.table_fn(True)
                 gx = gather_gemm(gy, w, nbr_t, w.shape[-2], w_transposed=True, row_perm=perm)
         if want_gw:
+            sink = _GRAD_SINK
+            out = sink.view_for(w) if (sink is not None and w.shape[1] == ctx.cin) else None
             if side is not None:
                 with torch.cuda.stream(side):
-                    gw = conv_wgrad(x, gy, ctx.nbr, w.shape)
+                    gw = conv_wgrad(x, gy, ctx.nbr, w.shape, out=out)
                 for t in (x, gy, ctx.nbr, gw):  # every buffer the side stream reads, and its output
                     t.record_stream(side if t is not gw else main)
+                if out is not None:  # written in place into the reducer's buffer: nothing for autograd to do
+                    _DEFERRED["pending"] = True
+                    if not _DEFERRED["callback"]:
+                        _DEFERRED["callback"] = True
+                        torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+                    sink.ready(w)
+                    return gx, None, None, None, None
                 # Nothing reads gw before backward ends when autograd merely installs it as
                 # w.grad: then the join is deferred to the end-of-backward callback and the
                 # wgrad kernels overlap the rest of the backward chain.  An existing .grad
@@ -304,7 +333,10 @@ class ConvolutionFunction(torch.autograd.Function):
                 else:
                     main.wait_stream(side)
             else:
-                gw = conv_wgrad(x, gy, ctx.nbr, w.shape)
+                gw = conv_wgrad(x, gy, ctx.nbr, w.shape, out=out)
+                if out is not None:
+                    sink.ready(w)
+                    return gx, None, None, None, None
             if gw.shape[1] != ctx.cin:  # drop the gradient of the zero-padded input channels
                 gw = gw[:, : ctx.cin].contiguous()
         return gx, gw, None, None, None

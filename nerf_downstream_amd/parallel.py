@@ -53,33 +53,61 @@ class BucketedGradAllReduce:
         if self.world > 1:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-            if dev.type == "cuda" and os.environ.get("MINK_DP_MULTISTREAM", "0") == "0":
-                # Gradients land in the flat buffer as they are produced, so the weight-gradient
-                # stream would have to re-join at every layer (no gain), and one process already
-                # drives compute + prepare + RCCL queues: keep data-parallel ranks on those.
-                # (MINK_DP_MULTISTREAM=1 keeps the single-process schedule; the reducer joins the
-                # auxiliary streams before each collective either way.)
+            if dev.type == "cuda":
                 from .minkowski import functional as Fn
 
-                Fn.set_wgrad_overlap(False)
-                Fn.set_branch_fork(False)
+                if os.environ.get("MINK_DP_MULTISTREAM", "1") == "0":  # conservative schedule: compute + prepare streams only
+                    Fn.set_wgrad_overlap(False)
+                    Fn.set_branch_fork(False)
+                else:
+                    # convolution weight gradients are written straight into the flat buffer by the
+                    # weight-gradient stream (no per-layer accumulate + join on the compute stream)
+                    Fn.set_grad_sink(self)
+        self._written = set()  # parameters whose gradient was written in place this step
+        self._counted = set()  # parameters already counted towards their bucket this step
+
+    # ---- gradient sink protocol (minkowski.functional.set_grad_sink)
+    def view_for(self, p):
+        """The slice of the flat buffer to write the gradient of `p` into -- once per step (a second
+        gradient of the same parameter in one step must ADD, which autograd's accumulate does)."""
+        if self.world == 1 or p not in self._bucket_of or p in self._written or p.grad is None:
+            return None
+        g = p.grad
+        lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
+        if not (g.is_contiguous() and lo <= g.data_ptr() < hi):
+            return None  # somebody replaced .grad: fall back to autograd
+        self._written.add(p)
+        return g
+
+    def ready(self, p):
+        self._on_grad(p)
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
         if self.flat.is_cuda:
-            # The gradients of one bucket may have been accumulated from several HIP streams (the
-            # step's own stream, the shortcut-branch stream, the weight-gradient stream); the
-            # collective orders itself after the CURRENT stream only, so join the others first.
+            # The gradients of one bucket may have been produced on several HIP streams (the step's
+            # own stream, the shortcut-branch stream, the weight-gradient stream); the collective
+            # orders itself after the CURRENT stream only.  Launch it from the weight-gradient
+            # stream (after making that one wait for the others): the compute stream is not held up.
             from .minkowski import functional as Fn
 
-            cur = torch.cuda.current_stream(self.flat.device)
-            for st in [self._home] + Fn.compute_streams(self.flat.device):
-                if st is not None and st != cur:
-                    cur.wait_stream(st)
+            dev = self.flat.device
+            cur = torch.cuda.current_stream(dev)
+            side = Fn.side_stream_if_any(dev)
+            launch_from = side if side is not None else cur
+            for st in [self._home, cur] + Fn.compute_streams(dev):
+                if st is not None and st != launch_from:
+                    launch_from.wait_stream(st)
+            with torch.cuda.stream(launch_from):
+                self._work.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
         self._work.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_grad(self, p):
+        if p in self._counted:  # a gradient written in place is reported by the kernel launcher AND (on
+            return              # some torch versions) by the post-accumulate hook of the undefined grad
+        self._counted.add(p)
         b = self._bucket_of[p]
         self._ready[b] += 1
         if self._ready[b] == self.buckets[b][2] and not self._launched[b]:
@@ -87,8 +115,15 @@ class BucketedGradAllReduce:
 
     def zero_grad(self):
         """Gradients accumulate into the flat buffer; clear it with one memset per step."""
+        if self.flat.is_cuda:
+            self._home = torch.cuda.current_stream(self.flat.device)
+            from .minkowski import functional as Fn
+
+            for st in Fn.compute_streams(self.flat.device):  # last step's collectives / writes on the side streams
+                self._home.wait_stream(st)
         self.flat.zero_()
-        self._home = torch.cuda.current_stream(self.flat.device) if self.flat.is_cuda else None
+        self._written.clear()
+        self._counted.clear()
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
 
