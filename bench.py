@@ -228,9 +228,19 @@ def main():
     for i in range(args.warmup):
         step(i)
     dominant = None
+    layer_table = []
     if not args.no_kernel_timing:
         torch.cuda.synchronize()
-        tot = {t: sum(s.elapsed_time(e) for s, e in v["events"]) for t, v in Fn.kernel_timings().items()}
+        warm = Fn.kernel_timings()
+        tot = {t: sum(s.elapsed_time(e) for s, e in v["events"]) for t, v in warm.items()}
+        for t, v in warm.items():  # (N_in, N_out, P, Cin, Cout) per layer so the roofline can be recomputed
+            m = v["meta"]
+            pairs = int((m["nbr"] >= 0).sum().item())
+            layer_table.append({
+                "op": t, "n_in": m["n_in"], "n_out": m["n_out"], "pairs": pairs, "cin": m["cin"], "cout": m["cout"],
+                "avg_ms": round(tot[t] / max(1, len(v["events"])), 4), "gflop": round(2e-9 * pairs * m["cin"] * m["cout"], 3),
+                "algorithmic_mb": round((4.0 * (m["n_in"] * m["cin"] + m["n_out"] * m["cout"] + m["K"] * m["cin"] * m["cout"]) + 8.0 * pairs) / 1e6, 2),
+            })
         if tot:
             dominant = max(tot, key=tot.get)
             conv_share = tot[dominant] / sum(tot.values())
@@ -282,6 +292,26 @@ def main():
         if timings:
             res["roofline"] = roofline_from_timings(timings)
             res["roofline"]["share_of_conv_kernel_time_in_warmup"] = conv_share
+        if world == 1:
+            # forward only (north_star: "fraction of HBM roofline on the sparse-conv forward"): the network
+            # forward on an already prepared batch, training-mode batch norm, no autograd graph
+            fwd_steps = 10
+            with torch.no_grad():
+                model(state["tf"])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(fwd_steps):
+                    model(state["tf"])
+                torch.cuda.synchronize()
+                fwd_ms = (time.perf_counter() - t1) / fwd_steps * 1e3
+            fwd_bytes = sum(r["algorithmic_mb"] for r in layer_table if r["op"].startswith("fwd")) * 1e6
+            res.setdefault("roofline", {})["forward_only"] = {
+                "voxels_per_s": vox_per_step[0] / (fwd_ms * 1e-3), "ms": fwd_ms,
+                "conv_algorithmic_bytes": fwd_bytes,
+                "hbm_frac_at_algorithmic_bytes": fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fwd_bytes else None,
+            }
+        if layer_table:
+            print("[bench] per-layer conv kernels (warm-up, HIP events): " + json.dumps(layer_table), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.model, args.in_channel, args.num_classes, args.grid, state0)
         print(json.dumps(res))
