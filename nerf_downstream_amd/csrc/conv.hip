@@ -1011,29 +1011,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   // rows interleave their pairs
   const int64_t npairs = (rend - rbeg + 1) >> 1;
   const int nq = (int)((npairs + 1 - wa) >> 1);
-  auto row_of = [&](int q) { return rbeg + 2 * (2 * (int64_t)q + wa) + h; };
+  // 32-bit row arithmetic relative to the split (every VALU instruction issued here is a slot the matrix pipe
+  // does not get: PMC shows MFMA busy + 4 x VALU instructions ~ 87 % of the SIMD cycles, no co-execution)
+  const int nrel = (int)(rend - rbeg);
+  const unsigned nbase = (unsigned)rbeg * K4 + ncol;     // >= 2^31 for the padding lanes (ncol == OOB): stays out of range
+  const unsigned ibase = (unsigned)rbeg * 4u;
+  const unsigned dbase = (unsigned)rbeg * ldy4 + dcol;
+  auto rel_of = [&](int q) { return 2 * (2 * q + wa) + h; };
   auto load_raw = [&](int s, int q) {  // rows past the end read as entry 0; their x offset is forced out of range below
-    const int64_t R = row_of(q);
-    nraw[s] = __builtin_amdgcn_raw_buffer_load_b32(rn, (int)(R < rend ? (unsigned)R * K4 + ncol : OOB), 0, 0);
+    const int r = rel_of(q);
+    nraw[s] = __builtin_amdgcn_raw_buffer_load_b32(rn, (int)(r < nrel ? __umul24(r, K4) + nbase : OOB), 0, 0);
   };
   auto stash = [&](int s, int slot) {
     sN[wave][slot][h][col] = nraw[s];  // lanes col >= 9 store padding: no exec-mask branch in the loop
   };
   auto load_i2o = [&](int s, int q) {  // (a row past the end reads parent 0: its x operand is zero anyway)
     if (FUSE) {
-      const int64_t R = row_of(q);
-      i2or[s] = __builtin_amdgcn_raw_buffer_load_b32(ri, (int)(R < rend ? (unsigned)R * 4u : OOB), 0, 0);
+      const int r = rel_of(q);
+      i2or[s] = __builtin_amdgcn_raw_buffer_load_b32(ri, (int)(r < nrel ? 4u * r + ibase : OOB), 0, 0);
     }
   };
   auto load_dy = [&](int s, int q) {
-    const int64_t R = row_of(q);
-    db[s] = buf_load(rd, R < rend ? (unsigned)R * ldy4 + dcol : OOB);
+    const int r = rel_of(q);
+    db[s] = buf_load(rd, r < nrel ? __umul24(r, ldy4) + dbase : OOB);
     if (FUSE) dp[s] = buf_load(rp, __umul24(i2or[s], ldy4) + dcol);  // the pooled gradient has the same row pitch
   };
   auto b_operand = [&](int s) {
     if (!FUSE) return db[s];
     const float xh = (db[s] - c_mu) * c_is;
-    const float g = xh * c_ga + c_be > 0.f ? dp[s] : 0.f;
+    const float g = dp[s] * (xh * c_ga + c_be > 0.f ? 1.f : 0.f);  // (a select of the loaded value itself became an exec branch
+                                                                     //  and, with it, a copy of all 144 accumulators per trip)
     return c_ga * c_is * (g - c_dbn - xh * c_dgn);
   };
   auto load_xs = [&](int s, int slot, int q, auto &&between) {  // the nine x values of pair q
@@ -1041,7 +1048,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
     const uint4 n1 = *reinterpret_cast<const uint4 *>(&sN[wave][slot][h][4]);
     const unsigned n2 = sN[wave][slot][h][8];
     const unsigned nbv[G] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2};
-    const unsigned xbase = row_of(q) < rend ? xcol : OOB;
+    const unsigned xbase = rel_of(q) < nrel ? xcol : OOB;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       between(g);
