@@ -3,8 +3,9 @@
 #include <stdio.h>
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <int MODE>  // 0: register operands; 1: operands re-read from LDS every step (ds_read_b32)
-__global__ __launch_bounds__(256) void k(float *out, int iters) {
+template <int MODE>  // 0: register operands; 1: operands re-read from LDS every step (ds_read_b32); 2: + barrier;
+// 3: + six ds_write_b128 per item; 4: + six global dwordx4 loads per item (consumed one item later); 5: + ~100 VALU per item
+__global__ __launch_bounds__(256, 2) void k(float *out, int iters, const float4 *src = nullptr) {
   __shared__ float sA[128 * 36];
   __shared__ float sB[32 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -13,6 +14,8 @@ __global__ __launch_bounds__(256) void k(float *out, int iters) {
   __syncthreads();
   f32x16 acc0 = {0}, acc1 = {0};
   float a = lane * 0.001f, b = 0.5f;
+  float4 g[6] = {}, g2[6] = {};
+  unsigned junk = tid;
   const int arow = wave * 32 + (lane & 31), h = lane >> 5, col = lane & 31;
   for (int it = 0; it < iters; ++it) {
     if (MODE == 0) {
@@ -42,9 +45,35 @@ __global__ __launch_bounds__(256) void k(float *out, int iters) {
           acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b1[4 * t + j], acc1, 0, 0, 0);
         }
       }
-      if (MODE == 2) __syncthreads();
+      if (MODE >= 3) {
+        float4 *wA = reinterpret_cast<float4 *>(sA), *wB = reinterpret_cast<float4 *>(sB);
+        const float4 v0 = MODE >= 4 ? g[0] : make_float4(a, b, a, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wA[(tid >> 3) * 9 + (tid & 7) + 288 * i] = MODE >= 4 ? g[i] : v0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wB[tid + 256 * i] = MODE >= 4 ? g[4 + i] : v0;
+      }
+      if (MODE >= 4) {
+        if (MODE == 6) {  // keep the loads in flight for two items: the set just stored is reloaded, the other one waits
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const float4 t = g2[i];
+            g2[i] = src[((size_t)(blockIdx.x * 131 + it * 17 + i * 1031) * 256 + tid) & ((1u << 22) - 1)];
+            g[i] = t;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) g[i] = src[((size_t)(blockIdx.x * 131 + it * 17 + i * 1031) * 256 + tid) & ((1u << 22) - 1)];
+        }
+      }
+      if (MODE == 5) {
+#pragma unroll
+        for (int i = 0; i < 100; ++i) junk = junk * 1664525u + 1013904223u + (unsigned)i;
+      }
+      if (MODE >= 2) __syncthreads();
     }
   }
+  if (junk == 0x12345u) out[0] = g[0].x + g[5].y + g2[1].x;
   float s = 0;
   for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
   out[blockIdx.x * 256 + tid] = s;
@@ -54,12 +83,15 @@ template <int MODE>
 void run(const char *name, int blocks, int iters) {
   float *out;
   hipMalloc(&out, blocks * 256 * 4);
+  float4 *src;
+  hipMalloc(&src, sizeof(float4) << 22);
+  hipMemset(src, 0, sizeof(float4) << 22);
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
-  k<MODE><<<blocks, 256>>>(out, iters);
+  k<MODE><<<blocks, 256>>>(out, iters, src);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k<MODE><<<blocks, 256>>>(out, iters);
+  k<MODE><<<blocks, 256>>>(out, iters, src);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -67,13 +99,18 @@ void run(const char *name, int blocks, int iters) {
   const double flops = (double)blocks * 4 * iters * 32 * 4096.0;
   printf("%-34s blocks=%5d iters=%d  %.3f ms  %.1f TFLOP/s\n", name, blocks, iters, ms, flops / ms / 1e9);
   hipFree(out);
+  hipFree(src);
 }
 
 int main() {
-  for (int bpc : {1, 2, 3}) {
+  for (int bpc : {2}) {
     run<0>("register operands", 256 * bpc, 2000);
     run<1>("LDS-fed operands", 256 * bpc, 2000);
     run<2>("LDS-fed + barrier per 32 MFMA", 256 * bpc, 2000);
+    run<3>("  + 6 ds_write_b128 per item", 256 * bpc, 2000);
+    run<4>("  + 6 global dwordx4 loads per item", 256 * bpc, 2000);
+    run<5>("  + 100 VALU per item", 256 * bpc, 2000);
+    run<6>("  loads kept in flight for 2 items", 256 * bpc, 2000);
   }
   return 0;
 }
