@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int iters, const float4 
 #pragma unroll
         for (int i = 0; i < 100; ++i) junk = junk * 1664525u + 1013904223u + (unsigned)i;
       }
-      if (MODE >= 2) __syncthreads();
+      if (MODE >= 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (not __syncthreads: that drains vmcnt and exposes every load)
     }
   }
   if (junk == 0x12345u) out[0] = g[0].x + g[5].y + g2[1].x;
