@@ -242,6 +242,13 @@ def train(
             if scheduler is not None:
                 scheduler.step()
             step += 1
+            if step == 3:
+                # the warmed-up model / optimizer / coordinate plans are permanent: keep the cyclic collector's
+                # periodic full collections from re-traversing them (0.4 ms per step on average at ~5 ms steps)
+                import gc
+
+                gc.collect()
+                gc.freeze()
             if step % log_every_n_steps == 0:
                 loss_float = float(loss.detach().cpu())
                 ClassificationTraining.check_finite(loss_float)
