@@ -311,6 +311,20 @@ int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32
  * mode 2: y = a + b. */
 int mink_eltwise(const float *a, const float *b, int64_t count, int32_t mode, float *y, void *stream);
 
+/* ------------------------------------------------------------------ dataset front-end
+ * PeRFception-CO3D `data.npz` batch on the device (reference co3d.py:160-166 de-quantisation,
+ * :196-205 links -> coordinates and feature selection): `links[n]` flat indices x*ry*rz + y*rz + z,
+ * `density[n]`, `sh_q[n][27]` uint8, per scene b (rows scene_offsets[b] .. scene_offsets[b+1])
+ * `sh_scale[b][27]`, `sh_min[b][27]`.  Writes coords int32 [n][4] = (b, x, y, z) and the selected
+ * feature columns: density at col_density, the 27 de-quantised SH coefficients at col_sh, ones at
+ * col_ones (-1 = not selected; the columns must tile 0..C-1).  sh = float(sh_q) * scale + min with
+ * separate multiply and add, bit-identical to the numpy expression of the reference. */
+int mink_decode_plenoxel(const int32_t *links, const float *density, const uint8_t *sh_q,
+                         const int32_t *scene_offsets, int32_t n_scenes, const float *sh_scale,
+                         const float *sh_min, int64_t n, int32_t reso_y, int32_t reso_z, int32_t col_density,
+                         int32_t col_sh, int32_t col_ones, int32_t C, int32_t *coords, float *feats, int32_t ldf,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,11 +43,18 @@ def select_features(coordinates, density, sh, names):
 @gin.configurable()
 class Co3DDatasetBase(Dataset):
     def __init__(self, phase, data_root="co3d_3d/datasets/co3d", train_transformations=(), eval_transformations=(),
-                 downsample_mode=1, downsample_stride=2, num_points=-1, features=("sh",), filelist_dir="filelist"):
+                 downsample_mode=1, downsample_stride=2, num_points=-1, features=("sh",), filelist_dir="filelist",
+                 compact=False):
+        """`compact` (extension): samples stay in the on-disk form (links / density / uint8 sh + scale, min:
+        35 bytes per voxel instead of 128) and are decoded on the GPU by `mink_decode_plenoxel` when the
+        batch reaches the model (`MinkowskiBaseModel.process_input`).  Not with the "xyzs" feature."""
         phase = "test" if phase in ("val", "test") else "train"  # reference :84 (val == test list)
         if (train_transformations if phase == "train" else eval_transformations):
             raise NotImplementedError("CPU augmentations (reference transforms.py) are outside the MI355X hot path")
         self.phase, self.data_root, self.features = phase, data_root, list(features)
+        self.compact = bool(compact)
+        if self.compact and "xyzs" in self.features:
+            raise ValueError('compact=True cannot produce the "xyzs" feature (a per-scene reduction)')
         with open(os.path.join(filelist_dir, f"{phase}.txt")) as f:
             self.files = [line.split()[:2] for line in f if line.strip()]
         self.CLASS_LABELS, self.NUM_CLASSES = CLASSES, len(CLASSES)
@@ -60,8 +67,24 @@ class Co3DDatasetBase(Dataset):
         sh = z["sh"].astype(np.float32) * z["sh_scale"] + z["sh_min"]
         return torch.from_numpy(z["links"]), torch.from_numpy(z["density"].astype(np.float32)), torch.from_numpy(sh)
 
+    def load_compact(self, inst_id):
+        path = os.path.join(self.data_root, f"plenoxel_co3d_{inst_id}", "data.npz")
+        if not os.path.exists(path):
+            raise ValueError(f"{inst_id} not exist in {self.data_root} (only the data.npz format is supported)")
+        z = np.load(path)
+        bc = lambda a: np.broadcast_to(np.asarray(a, np.float32).reshape(-1), (27,)).copy()  # noqa: E731
+        return {"links": torch.from_numpy(z["links"].astype(np.int32)),
+                "density": torch.from_numpy(z["density"].astype(np.float32).reshape(-1)),
+                "sh_q": torch.from_numpy(np.ascontiguousarray(z["sh"]).reshape(len(z["links"]), -1)),
+                "sh_scale": torch.from_numpy(bc(z["sh_scale"])), "sh_min": torch.from_numpy(bc(z["sh_min"]))}
+
     def __getitem__(self, index):
         label, inst_id = self.files[index]
+        if self.compact:
+            sample = self.load_compact(inst_id)
+            sample["labels"] = np.array([self.CLASS_LABELS.index(label)])
+            sample["feature_names"] = tuple(self.features)
+            return sample
         links, density, sh = self.load_data(inst_id)
         coordinates = links_to_coordinates(links, [128, 128, 128])
         feats, xyzs = select_features(coordinates, density.reshape(-1, 1), sh.reshape(len(links), -1), self.features)

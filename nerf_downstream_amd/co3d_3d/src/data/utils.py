@@ -8,6 +8,19 @@ from nerf_downstream_amd.minkowski import utils as me_utils
 def collate_mink(list_data):
     """list of sample dicts -> {"coordinates": f32 [sumN,4] (batch,x,y,z), "features": f32 [sumN,C],
     "labels": int64 [B]}.  Runs in DataLoader workers: CPU only."""
+    if "links" in list_data[0]:  # compact on-disk form (Co3DDatasetBase(compact=True)): decoded on the GPU later
+        n = [int(d["links"].shape[0]) for d in list_data]
+        package = {
+            "links": torch.cat([d["links"] for d in list_data]),
+            "density": torch.cat([d["density"] for d in list_data]),
+            "sh_q": torch.cat([d["sh_q"] for d in list_data]),
+            "scene_offsets": torch.tensor(np.concatenate([[0], np.cumsum(n)]), dtype=torch.int32),
+            "sh_scale": torch.stack([d["sh_scale"] for d in list_data]),
+            "sh_min": torch.stack([d["sh_min"] for d in list_data]),
+            "labels": torch.from_numpy(np.concatenate([np.asarray(d["labels"]) for d in list_data])),
+            "feature_names": list_data[0]["feature_names"],
+        }
+        return package
     coords, feats = me_utils.sparse_collate(
         [d["coordinates"] for d in list_data], [d["features"] for d in list_data], dtype=torch.float32
     )

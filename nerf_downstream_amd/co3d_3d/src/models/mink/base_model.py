@@ -32,6 +32,10 @@ class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
         batch's forward/backward have been queued -- reads the row counts back (already there by
         then, so the host never blocks) and builds the kernel maps."""
         ME = self._ME
+        if "links" in batch:  # compact PeRFception batch: de-quantise + links -> coordinates on the device
+            with self._prepare_stream_ctx(batch["links"]):
+                coords, feats = ME.utils.decode_plenoxel_batch(batch)
+            batch = dict(batch, coordinates=coords, features=feats)
         coords, feats = batch["coordinates"], batch["features"]
         if not (self.prepare_ahead and getattr(ME, "SUPPORTS_PREPARE_AHEAD", False) and coords.is_cuda):
             return ME.TensorField(coordinates=coords, features=feats)
@@ -51,6 +55,20 @@ class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
             tf = ME.TensorField(coordinates=coords, features=feats, plan=self._coord_plan or [], defer=defer)
         self._recent_traces = [tf.coordinate_manager.trace] + self._recent_traces[:2]
         return tf
+
+    def _prepare_stream_ctx(self, t):
+        """The prepare stream as a context (made to wait for the current stream, where the H2D copies of
+        the batch were queued), or a null context without prepare-ahead."""
+        import contextlib
+
+        import torch
+
+        if not (self.prepare_ahead and t.is_cuda):
+            return contextlib.nullcontext()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=t.device)
+        self._side.wait_stream(torch.cuda.current_stream(t.device))
+        return torch.cuda.stream(self._side)
 
     @staticmethod
     def finish_input(field):

@@ -298,6 +298,63 @@ __global__ __launch_bounds__(kBlock) void batch_offsets_kernel(const int *__rest
 
 using namespace mink;
 
+// ------------------------------------------------------------------ PeRFception data.npz front-end
+// One thread per (voxel, group of four feature columns).  links -> (batch, x, y, z); features =
+// the selected columns of [density | sh_q * sh_scale + sh_min (27) | ones] in the caller's order.
+// The de-quantisation is a separate multiply and add (no fma): bit-identical to numpy's
+// `sh.astype(float32) * sh_scale + sh_min` of the reference loader (co3d.py:160-166).
+__global__ __launch_bounds__(kBlock) void decode_plenoxel_kernel(
+    const int *__restrict__ links, const float *__restrict__ density, const unsigned char *__restrict__ sh_q,
+    const int *__restrict__ scene_offsets, int n_scenes, const float *__restrict__ sh_scale,
+    const float *__restrict__ sh_min, int64_t n, int ry, int rz, int col_density, int col_sh, int col_ones, int C,
+    int *__restrict__ coords, float *__restrict__ feats, int ldf, bool vec) {
+  const int groups = (C + 3) >> 2;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n * groups) return;
+  const int64_t i = t / groups;
+  const int gq = (int)(t - i * groups);
+  int lo = 0, hi = n_scenes;  // scene b with scene_offsets[b] <= i < scene_offsets[b+1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)scene_offsets[mid] <= i) lo = mid;
+    else hi = mid;
+  }
+  const int b = lo;
+  if (gq == 0) {
+    const int l = links[i];
+    const int yz = ry * rz;
+    const int x = l / yz, rem = l - x * yz;
+    const int y = rem / rz, z = rem - y * rz;
+    *reinterpret_cast<int4 *>(coords + 4 * i) = make_int4(b, x, y, z);
+  }
+  float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * gq + e;
+    if (c >= C) break;
+    float v;
+    if (col_sh >= 0 && c >= col_sh && c < col_sh + 27) {
+      const int j = c - col_sh;
+      float prod = (float)sh_q[i * 27 + j] * sh_scale[b * 27 + j];
+      asm volatile("" : "+v"(prod));  // keep the product rounded: hipcc contracts a*b+c (and __fmul_rn is a plain multiply)
+      v = prod + sh_min[b * 27 + j];
+    } else if (c == col_density) {
+      v = density[i];
+    } else {  // c == col_ones
+      v = 1.f;
+    }
+    out[e] = v;
+  }
+  float *dst = feats + i * ldf + 4 * gq;
+  if (vec && 4 * gq + 4 <= C) {
+    *reinterpret_cast<float4 *>(dst) = make_float4(out[0], out[1], out[2], out[3]);  // one 16-byte store per thread
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * gq + e < C) dst[e] = out[e];
+  }
+}
+
 extern "C" {
 
 const char *mink_last_error(void) { return g_err; }
@@ -525,6 +582,29 @@ int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *bat
   const int64_t work = (n > B + 1) ? n : B + 1;
   batch_offsets_kernel<<<dim3((unsigned)cdiv(work, kBlock)), kBlock, 0, (hipStream_t)stream>>>(coords, n, B,
                                                                                               batch_offsets, status);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+
+int mink_decode_plenoxel(const int32_t *links, const float *density, const uint8_t *sh_q, const int32_t *scene_offsets,
+                         int32_t n_scenes, const float *sh_scale, const float *sh_min, int64_t n, int32_t reso_y,
+                         int32_t reso_z, int32_t col_density, int32_t col_sh, int32_t col_ones, int32_t C, int32_t *coords,
+                         float *feats, int32_t ldf, void *stream) {
+  MINK_REQUIRE(n >= 0 && n_scenes >= 1 && reso_y >= 1 && reso_z >= 1 && C >= 1 && ldf >= C, "decode_plenoxel: bad shape");
+  const int want = (col_density >= 0) + 27 * (col_sh >= 0) + (col_ones >= 0);
+  MINK_REQUIRE(want == C && col_density < C && col_ones < C && (col_sh < 0 || col_sh + 27 <= C),
+               "decode_plenoxel: the feature columns (density %d, sh %d, ones %d) do not tile %d channels", col_density,
+               col_sh, col_ones, C);
+  if (n == 0) return MINK_OK;
+  MINK_REQUIRE(links && scene_offsets && coords && feats && (col_density < 0 || density) &&
+                   (col_sh < 0 || (sh_q && sh_scale && sh_min)),
+               "decode_plenoxel: NULL pointer");
+  MINK_REQUIRE(((uintptr_t)coords & 15) == 0, "decode_plenoxel: coords must be 16-byte aligned");
+  const int64_t threads = n * ((C + 3) / 4);
+  decode_plenoxel_kernel<<<dim3((unsigned)cdiv(threads, kBlock)), kBlock, 0, (hipStream_t)stream>>>(
+      links, density, sh_q, scene_offsets, n_scenes, sh_scale, sh_min, n, reso_y, reso_z, col_density, col_sh, col_ones, C,
+      coords, feats, ldf, ((uintptr_t)feats & 15) == 0 && (ldf & 3) == 0);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

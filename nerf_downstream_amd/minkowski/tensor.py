@@ -130,6 +130,8 @@ class TensorField:
             cur = torch.cuda.current_stream()
             cur.wait_event(self._ready)
             m.hand_over(cur)
+            for t in (self._F, self._C):  # may have been produced on the build stream (GPU-side decode)
+                t.record_stream(cur)
             self._ready = None
         n_unique = m.levels[1].n
         F = self._F

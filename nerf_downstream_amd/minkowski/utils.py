@@ -28,3 +28,36 @@ def sparse_collate(coords, feats, labels=None, dtype=torch.int32, device=None):
     if labels is None:
         return bcoords, bfeats
     return bcoords, bfeats, torch.cat([_t(l) for l in labels], 0)
+
+
+def decode_plenoxel_batch(batch, reso=(128, 128, 128)):
+    """Compact PeRFception `data.npz` batch (device tensors: links, density, sh_q, scene_offsets,
+    sh_scale, sh_min + `feature_names`) -> (coordinates int32 [N,4], features f32 [N,C]) with one
+    HIP kernel (`mink_decode_plenoxel`; reference co3d.py:160-166,196-229)."""
+    import torch
+
+    from .._lib import check, lib
+
+    links = batch["links"]
+    if not links.is_cuda:
+        raise RuntimeError("decode_plenoxel_batch runs on the GPU: move the batch to cuda first")
+    names = list(batch["feature_names"])
+    width = {"density": 1, "sh": 27, "ones": 1}
+    col, C = {"density": -1, "sh": -1, "ones": -1}, 0
+    for f in names:
+        if f not in width or col[f] >= 0:
+            raise ValueError(f"feature {f!r} cannot be decoded on the GPU (supported once each: density, sh, ones)")
+        col[f] = C
+        C += width[f]
+    n = links.shape[0]
+    coords = torch.empty(n, 4, dtype=torch.int32, device=links.device)
+    feats = torch.empty(n, C, dtype=torch.float32, device=links.device)
+    stream = torch._C._cuda_getCurrentRawStream(links.device.index)
+    check(
+        lib().mink_decode_plenoxel(
+            links.data_ptr(), batch["density"].data_ptr(), batch["sh_q"].data_ptr(), batch["scene_offsets"].data_ptr(),
+            batch["scene_offsets"].numel() - 1, batch["sh_scale"].data_ptr(), batch["sh_min"].data_ptr(), n, reso[1], reso[2],
+            col["density"], col["sh"], col["ones"], C, coords.data_ptr(), feats.data_ptr(), C, stream,
+        )
+    )
+    return coords, feats

@@ -71,6 +71,20 @@ if which == "wablate":
     b = Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64))
     lib().mink_conv_set_stagger(0)
     print("stream vs tiled wgrad: max |diff|", float((a - b).abs().max()), "max |ref|", float(b.abs().max()))
+if which == "decode":
+    import numpy as np
+    n = x.F.shape[0]
+    rng = np.random.default_rng(0)
+    batch = {
+        "links": torch.from_numpy(rng.integers(0, 128 ** 3, n).astype(np.int32)).to(dev),
+        "density": torch.rand(n, device=dev), "sh_q": torch.randint(0, 256, (n, 27), dtype=torch.uint8, device=dev),
+        "scene_offsets": torch.arange(0, n + 1, n // 16, dtype=torch.int32, device=dev)[:17].contiguous(),
+        "sh_scale": torch.rand(16, 27, device=dev), "sh_min": torch.rand(16, 27, device=dev), "feature_names": ("density", "sh"),
+    }
+    batch["scene_offsets"][-1] = n
+    t = timeit(lambda: ME.utils.decode_plenoxel_batch(batch), reps)
+    nbytes = n * (4 + 4 + 27 + 16 + 112)
+    print(f"decode_plenoxel n={n}: {t*1e3:.1f} us, {nbytes/1e6:.1f} MB algorithmic -> {nbytes/t/1e6:.0f} GB/s ({nbytes/t/1e6/8000*100:.1f} % of 8 TB/s)")
 if which == "ksweep":
     keys = {1: k1}
     for ts in (2, 4, 8, 16, 32):

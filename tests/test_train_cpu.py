@@ -83,6 +83,49 @@ def test_co3d_npz_loader(tmp_path, monkeypatch):
     assert torch.allclose(s["features"][:, 1:], torch.from_numpy(sh.astype(np.float32) * 0.01 - 2.0))
 
 
+def _write_scenes(tmp_path, n_scenes=2, per_channel=False):
+    rng = np.random.default_rng(1)
+    (tmp_path / "filelist").mkdir()
+    lines, raw = [], []
+    for j in range(n_scenes):
+        n = 300 + 57 * j
+        links = np.sort(rng.choice(128 ** 3, n, replace=False)).astype(np.int32)
+        sh = rng.integers(0, 256, (n, 27)).astype(np.uint8)
+        dens = rng.random((n, 1)).astype(np.float32)
+        scale = (rng.random(27).astype(np.float32) * 0.02 + 0.001) if per_channel else np.float32(0.0123 + j)
+        mn = (rng.standard_normal(27).astype(np.float32)) if per_channel else np.float32(-1.5 - j)
+        scene = tmp_path / "data" / f"plenoxel_co3d_s{j}"
+        scene.mkdir(parents=True)
+        np.savez(scene / "data.npz", links=links, density=dens, sh=sh, sh_min=mn, sh_scale=scale, reso=[[128] * 3, [256] * 3])
+        lines.append(f"cup s{j}")
+        raw.append({"links": links, "density": dens, "sh_q": sh, "sh_scale": scale, "sh_min": mn})
+    (tmp_path / "filelist" / "train.txt").write_text("\n".join(lines) + "\n")
+    return raw
+
+
+@pytest.mark.parametrize("per_channel", [False, True])
+def test_compact_co3d_batch_and_decode_oracle(tmp_path, monkeypatch, per_channel):
+    """Compact (on-disk form) samples + collate, and the decode oracle against the CPU loader: the
+    decoded batch must be exactly what the ordinary loader + collate produce."""
+    from nerf_downstream_amd.co3d_3d.src.data.co3d import Co3DDataset
+    from nerf_downstream_amd.co3d_3d.src.data.utils import collate_mink
+    from oracle.decode import decode_batch
+
+    raw = _write_scenes(tmp_path, per_channel=per_channel)
+    monkeypatch.chdir(tmp_path)
+    feats = ["sh", "density"]  # order matters: columns follow the list (reference co3d.py:226-229)
+    plain = collate_mink([Co3DDataset(phase="train", data_root=str(tmp_path / "data"), features=feats)[i] for i in range(2)])
+    ds = Co3DDataset(phase="train", data_root=str(tmp_path / "data"), features=feats, compact=True)
+    batch = collate_mink([ds[0], ds[1]])
+    assert batch["links"].dtype == torch.int32 and batch["sh_q"].dtype == torch.uint8 and batch["sh_scale"].shape == (2, 27)
+    assert batch["scene_offsets"].tolist() == [0, 300, 657] and batch["feature_names"] == ("sh", "density")
+    coords, f = decode_batch(raw, features=feats)
+    assert np.array_equal(coords, plain["coordinates"].numpy().astype(np.int32))
+    assert np.array_equal(f, plain["features"].numpy())  # bit-exact: same float32 multiply-then-add
+    with pytest.raises(ValueError):
+        Co3DDataset(phase="train", data_root=str(tmp_path / "data"), features=["xyzs", "sh"], compact=True)
+
+
 def test_model_parameter_names_and_counts():
     """State-dict layout of the reference ResNetBase and its parameter counts."""
     from nerf_downstream_amd.co3d_3d.src.models import get_model
