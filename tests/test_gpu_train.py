@@ -250,3 +250,50 @@ def test_train_cli_with_dataloader_workers(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "val/acc1" in r.stdout
     assert (tmp_path / "cli" / "last.ckpt").exists() and (tmp_path / "cli" / "metrics.csv").exists()
+
+
+def _write_co3d_scenes(root, n_scenes=16):
+    """A tiny PeRFception-CO3D tree in the reference's on-disk format (scripts/preprocess.py:30-57)."""
+    rng = np.random.default_rng(3)
+    (root / "filelist").mkdir(parents=True)
+    lines = []
+    for j in range(n_scenes):
+        cls = ("cup", "apple")[j % 2]
+        g = np.arange(32)
+        x, y, z = np.meshgrid(g, g, g, indexing="ij")
+        r = np.sqrt(((x - 15.5) / (9 + 3 * (j % 2))) ** 2 + ((y - 15.5) / 8) ** 2 + ((z - 15.5) / 10) ** 2)
+        occ = (np.abs(r - 1.0) < 0.15) & (rng.random(r.shape) > 0.1)
+        xyz = np.stack(np.nonzero(occ), 1)
+        links = (xyz[:, 0] * 128 * 128 + xyz[:, 1] * 128 + xyz[:, 2]).astype(np.int32)
+        scene = root / "data" / f"plenoxel_co3d_s{j}"
+        scene.mkdir(parents=True)
+        np.savez(scene / "data.npz", links=links, density=rng.random((len(links), 1)).astype(np.float32),
+                 sh=rng.integers(0, 256, (len(links), 27)).astype(np.uint8), sh_min=np.float32(-1.0 - 0.5 * (j % 2)),
+                 sh_scale=np.float32(0.008), reso=[[128] * 3, [256] * 3])
+        lines.append(f"{cls} s{j}")
+    for phase in ("train", "test"):
+        (root / "filelist" / f"{phase}.txt").write_text("\n".join(lines) + "\n")
+
+
+def test_train_on_co3d_format_compact_equals_decoded(tmp_path, monkeypatch):
+    """train() on a tiny tree in the reference's on-disk format, DataLoader workers included: the
+    compact path (GPU-side decode) and the ordinary path (CPU decode) give the same loss history."""
+    from nerf_downstream_amd.co3d_3d.train import train
+
+    _write_co3d_scenes(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    hist = {}
+    for compact in (False, True):
+        gin.clear_config()
+        gin.parse_config_files_and_bindings(
+            [f"{CFG}/co3d_cls.gin", f"{CFG}/resnet14.gin"],
+            ["train.gpus=1", "train.max_steps=6", "train.val_every_n_steps=6", "train.log_every_n_steps=1", "train.loggers=['csv']",
+             f"Co3DDatasetBase.data_root='{tmp_path}/data'", "Co3DDatasetBase.features=['density','sh']",
+             f"Co3DDatasetBase.compact={compact}", "get_model.in_channel=28", "train.batch_size=4", "train.val_batch_size=4",
+             "train.lr=0.003", "train.train_num_workers=2", "train.val_num_workers=0"],
+        )
+        res = train(save_path=str(tmp_path / f"run{int(compact)}"), resume_training=False, run_name="r", run_name_postfix=None, seed=9)
+        gin.clear_config()
+        hist[compact] = [h["train/loss"] for h in res["history"] if "train/loss" in h]
+        assert [h for h in res["history"] if "val/acc1" in h]
+    assert len(hist[True]) == 6 and hist[True] == hist[False]
