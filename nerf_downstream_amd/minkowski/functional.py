@@ -232,6 +232,9 @@ def branch_stream(device, home=None):
     s = _BRANCH_STREAMS.get(device.index)
     if s is None:
         s = _BRANCH_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:  # parameters of the branch get their gradient from this stream on purpose
+            quiet(False)
     if home is not None:
         _HOME_STREAMS[device.index] = home
     return s
