@@ -1295,7 +1295,7 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   }
   MINK_CHECK_LAUNCH();
   if (stats_direct) {
-    const int rows = (int)std::min<int64_t>(64, cdiv((int64_t)grid.x, 16));
+    const int rows = (int)std::min<int64_t>(512, cdiv((int64_t)grid.x, 8));  // >= 8 tiles per partial row: a latency-bound pass
     colsum_f32_kernel<<<dim3((unsigned)rows), 256, 0, st>>>((const float *)stats_ws, (int64_t)grid.x, 2 * cout, stats_out);
     MINK_CHECK_LAUNCH();
     *stats_rows = rows;
