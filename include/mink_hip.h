@@ -325,6 +325,56 @@ int mink_decode_plenoxel(const int32_t *links, const float *density, const uint8
                          int32_t col_sh, int32_t col_ones, int32_t C, int32_t *coords, float *feats, int32_t ldf,
                          void *stream);
 
+/* ------------------------------------------------------------------ scene augmentation
+ * The reference augments every scene on the CPU in its DataLoader workers (co3d.py:216-219 applies
+ * transforms.Compose of the gin-listed classes of transforms.py; configs/co3d_aug3.gin:2-23).  Here
+ * the host only DRAWS the per-scene randomness and the whole batch is transformed on the device.
+ * Per scene b a row of MINK_AUG_PARAMS floats (all matrices row-major, applied as row-vector * M):
+ *     p = c * A + a                          stages before the flip (rotation, affine, ...)
+ *     q_j = FLIP[j] ? max_j - p_j : p_j      max over the scene's surviving voxels (over all voxels
+ *                                            when FLIP_ALL != 0: dropout listed after the flip)
+ *     r = q * B + b + jitter * BJ            jitter_j = JITTER * (u_j - 0.5), u uniform [0,1)
+ *     voxel kept iff u >= DROPOUT            (CoordinateDropout; 0 keeps everything)
+ *     feats[:, raw column in [FEAT_START, FEAT_START + FEAT_DIM)] += (normal - 0.5) * FEAT_STD
+ * (transforms.py: RandomRotation :351-358, RandomAffine :416-427, CoordinateDropout :255-265,
+ * RandomHorizontalFlip :444-450, CoordinateUniformTranslation :288-294, CoordinateJitter :276-281,
+ * RandomScale :367-373, RandomFeatureJitter :34-41.)  Differences from the reference, by design:
+ * the dropout is an independent coin per voxel and keeps the voxel order (the reference draws an
+ * exact-size random subset in random order); the per-voxel random numbers are Philox4x32-10 with
+ * key = seed, counter = (voxel index in its scene, draw, streams[b], 0): draw 0 -> (dropout u, jitter
+ * u_x, u_y, u_z), draw 1+j/4 -> four Box-Muller normals for noise columns 4(j/4)..4(j/4)+3.
+ * Coordinates are computed in fp32 with every product and sum rounded separately, in the order
+ * ((v0*M0j + v1*M1j) + v2*M2j) + t_j, so a CPU restatement reproduces them bit for bit. */
+enum {
+  MINK_AUG_A = 0,           /* 9 */
+  MINK_AUG_a = 9,           /* 3 */
+  MINK_AUG_FLIP = 12,       /* 3 flags */
+  MINK_AUG_B = 15,          /* 9 */
+  MINK_AUG_b = 24,          /* 3 */
+  MINK_AUG_BJ = 27,         /* 9 */
+  MINK_AUG_JITTER = 36,     /* 2 * jitter_std, 0 = none */
+  MINK_AUG_DROPOUT = 37,    /* dropout ratio, 0 = none */
+  MINK_AUG_FEAT_STD = 38,   /* 0 = none */
+  MINK_AUG_FEAT_START = 39, /* raw-layout column, co3d.py:205-214: [xyzs 0:3 | density 3 | sh 4:31] */
+  MINK_AUG_FEAT_DIM = 40,
+  MINK_AUG_FLIP_ALL = 41,
+  MINK_AUG_PARAMS = 44,
+  MINK_AUG_MAX_CHANNELS = 32
+};
+
+int64_t mink_augment_workspace_bytes(int64_t n, int32_t n_scenes);
+
+/* coords [n][4] (batch, x, y, z) sorted by batch, float32 or -- coords_are_int32 -- int32 as written by
+ * mink_decode_plenoxel; feats [n][ldf] (C columns used);
+ * scene_offsets [n_scenes+1], params [n_scenes][MINK_AUG_PARAMS], streams [n_scenes] on the device.
+ * raw_cols[C] is a HOST array: the raw-layout column of every feature column (-1 = never jittered).
+ * Writes the survivors, in order, to out_coords [>= n][4] / out_feats [>= n][ldo] and their number
+ * to the device int *n_kept (n_kept == n whenever every DROPOUT is 0: no read-back needed then). */
+int mink_augment_scenes(const void *coords, int32_t coords_are_int32, const float *feats, int64_t ldf, int32_t C, int64_t n,
+                        const int32_t *scene_offsets, int32_t n_scenes, const float *params,
+                        const uint32_t *streams, uint64_t seed, const int32_t *raw_cols, float *out_coords,
+                        float *out_feats, int64_t ldo, int32_t *n_kept, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

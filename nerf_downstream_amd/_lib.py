@@ -40,6 +40,11 @@ SIGNATURES = {
     "mink_class_partition": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _p]),
     "mink_batch_offsets": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p]),
     "mink_decode_plenoxel": (ctypes.c_int, [_p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p]),
+    "mink_augment_workspace_bytes": (_i64, [_i64, _i32]),
+    "mink_augment_scenes": (
+        ctypes.c_int,
+        [_p, _i32, _p, _i64, _i32, _i64, _p, _i32, _p, _p, ctypes.c_uint64, _p, _p, _p, _i64, _p, _p, _p],
+    ),
     "mink_conv_set_stagger": (ctypes.c_int, [ctypes.c_int]),
     "mink_conv_set_math": (ctypes.c_int, [ctypes.c_int]),
     "mink_conv_plan_ksplit": (ctypes.c_int, [_i64, _i32, _i32, _i32]),

@@ -6,8 +6,9 @@ Scene directory `<data_root>/plenoxel_co3d_<scene>/data.npz` holds
     density f32   [N,1]
     sh      uint8 [N,27]  de-quantised as sh * sh_scale + sh_min
 `filelist/<phase>.txt` (relative to the CWD, like the reference :100) lists "<class> <scene>".
-Sample dict / feature selection follow co3d.py:185-242.  Augmentations (transforms.py) are out
-of scope (the classification configs run with none: co3d_cls.gin:9-10)."""
+Sample dict / feature selection follow co3d.py:185-242.  Augmentations (`train_transformations`, names of
+classes in transforms.py as in configs/co3d_aug3.gin) are only DRAWN here: the sample carries its
+parameter row (`aug_params`, `aug_stream`) and the batch is transformed on the GPU (transforms.py)."""
 import os
 
 import numpy as np
@@ -15,6 +16,8 @@ import torch
 from torch.utils.data import Dataset
 
 from nerf_downstream_amd import gin_lite as gin
+
+from . import transforms
 
 CLASSES = (
     "apple backpack ball banana baseballbat baseballglove bench bicycle book bottle bowl broccoli cake car carrot "
@@ -49,8 +52,12 @@ class Co3DDatasetBase(Dataset):
         35 bytes per voxel instead of 128) and are decoded on the GPU by `mink_decode_plenoxel` when the
         batch reaches the model (`MinkowskiBaseModel.process_input`).  Not with the "xyzs" feature."""
         phase = "test" if phase in ("val", "test") else "train"  # reference :84 (val == test list)
-        if (train_transformations if phase == "train" else eval_transformations):
-            raise NotImplementedError("CPU augmentations (reference transforms.py) are outside the MI355X hot path")
+        names = list(train_transformations if phase == "train" else eval_transformations)
+        unknown = [t for t in names if not hasattr(getattr(transforms, t, None), "draw")]
+        if unknown:
+            raise NotImplementedError(f"augmentations {unknown} have no GPU counterpart (supported: the classes of "
+                                      "data/transforms.py)")
+        self.transformations = transforms.Compose([getattr(transforms, t)() for t in names]) if names else None
         self.phase, self.data_root, self.features = phase, data_root, list(features)
         self.compact = bool(compact)
         if self.compact and "xyzs" in self.features:
@@ -84,12 +91,19 @@ class Co3DDatasetBase(Dataset):
             sample = self.load_compact(inst_id)
             sample["labels"] = np.array([self.CLASS_LABELS.index(label)])
             sample["feature_names"] = tuple(self.features)
-            return sample
+            return self._with_program(sample)
         links, density, sh = self.load_data(inst_id)
         coordinates = links_to_coordinates(links, [128, 128, 128])
         feats, xyzs = select_features(coordinates, density.reshape(-1, 1), sh.reshape(len(links), -1), self.features)
-        return {"coordinates": coordinates, "features": feats, "xyzs": xyzs,
-                "labels": np.array([self.CLASS_LABELS.index(label)])}
+        return self._with_program({"coordinates": coordinates, "features": feats, "xyzs": xyzs,
+                                   "labels": np.array([self.CLASS_LABELS.index(label)]),
+                                   "feature_names": tuple(self.features)})
+
+    def _with_program(self, sample):
+        if self.transformations is not None:  # drawn here (DataLoader worker), applied on the GPU
+            params, stream = self.transformations.sample()
+            sample["aug_params"], sample["aug_stream"] = torch.from_numpy(params), stream
+        return sample
 
     def __len__(self):
         return len(self.files)

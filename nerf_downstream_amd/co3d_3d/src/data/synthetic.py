@@ -53,8 +53,14 @@ def make_scene(index, split=0, num_classes=51, grid=128, box_for_odd=False):
 @gin.configurable
 class SparseVoxelDataset(Dataset):
     def __init__(self, phase="train", num_samples=512, num_classes=51, grid=128, features=("density", "sh"),
-                 box_for_odd=False):
+                 box_for_odd=False, train_transformations=()):
+        """`train_transformations`: names of data/transforms.py classes, drawn per scene for the training split
+        and applied on the GPU (like Co3DDatasetBase)."""
+        from . import transforms
+
         self.phase, self.split = phase, SPLIT_ID.get(phase, 2)
+        names = list(train_transformations) if self.split == 0 else []
+        self.transformations = transforms.Compose([getattr(transforms, t)() for t in names]) if names else None
         self.num_samples = num_samples if self.split == 0 else max(1, num_samples // 4)
         self.num_classes, self.grid, self.features, self.box_for_odd = num_classes, grid, list(features), box_for_odd
         self.NUM_CLASSES = num_classes
@@ -71,4 +77,8 @@ class SparseVoxelDataset(Dataset):
         cols = {"xyzs": xyzs, "density": torch.from_numpy(density), "sh": torch.from_numpy(sh)}
         cols["ones"] = torch.ones_like(cols["density"])
         feats = torch.cat([cols[f] for f in self.features], dim=1).float()
-        return {"coordinates": coordinates, "features": feats, "xyzs": xyzs, "labels": np.array([label])}
+        sample = {"coordinates": coordinates, "features": feats, "xyzs": xyzs, "labels": np.array([label])}
+        if self.transformations is not None:
+            params, stream = self.transformations.sample()
+            sample.update(aug_params=torch.from_numpy(params), aug_stream=stream, feature_names=tuple(self.features))
+        return sample

@@ -20,7 +20,7 @@ def collate_mink(list_data):
             "labels": torch.from_numpy(np.concatenate([np.asarray(d["labels"]) for d in list_data])),
             "feature_names": list_data[0]["feature_names"],
         }
-        return package
+        return _with_programs(package, list_data, n)
     coords, feats = me_utils.sparse_collate(
         [d["coordinates"] for d in list_data], [d["features"] for d in list_data], dtype=torch.float32
     )
@@ -31,4 +31,17 @@ def collate_mink(list_data):
     for key in ("metadata", "dataset", "colors"):
         if key in list_data[0]:
             package[key] = [d[key] for d in list_data]
+    return _with_programs(package, list_data, [int(d["coordinates"].shape[0]) for d in list_data])
+
+
+def _with_programs(package, list_data, n):
+    """Augmentation programs drawn by the dataset (transforms.Compose.sample): one parameter row and one
+    Philox stream id per scene, plus a seed for the batch; applied on the GPU in process_input."""
+    if "aug_params" in list_data[0]:
+        package["aug_params"] = torch.stack([d["aug_params"] for d in list_data])
+        streams = np.array([d["aug_stream"] for d in list_data], dtype=np.uint32)
+        package["aug_streams"] = torch.from_numpy(streams.view(np.int32).copy())
+        package["aug_seed"] = int(np.random.randint(0, 2 ** 63 - 1, dtype=np.int64))
+        package.setdefault("scene_offsets", torch.tensor(np.concatenate([[0], np.cumsum(n)]), dtype=torch.int32))
+        package.setdefault("feature_names", list_data[0].get("feature_names"))
     return package

@@ -55,7 +55,9 @@ class CSVLogger:
 
 
 def _to_device(batch, device):
-    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    # the augmentation parameter rows stay on the host too: `augment_batch` uploads them itself and can tell
+    # from them, without a read-back, whether any voxel will be dropped
+    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) and k != "aug_params" else v) for k, v in batch.items()}
 
 
 def _dist_env():

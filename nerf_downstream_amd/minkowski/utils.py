@@ -1,5 +1,7 @@
 """ME.utils subset.  Runs in DataLoader worker processes (reference data_module.py:54-65), so it
 is pure-CPU torch and must never touch HIP."""
+import ctypes
+
 import numpy as np
 import torch
 
@@ -61,3 +63,49 @@ def decode_plenoxel_batch(batch, reso=(128, 128, 128)):
         )
     )
     return coords, feats
+
+
+def augment_batch(coords, feats, scene_offsets, params, streams, seed, raw_cols):
+    """Apply the drawn per-scene augmentation programs to a whole batch with `mink_augment_scenes`
+    (reference transforms.py, applied per scene on the CPU at co3d.py:216-219).
+
+    coords int32/f32 [N,4] (batch,x,y,z) sorted by batch, feats f32 [N,C], scene_offsets int32 [S+1],
+    params f32 [S, MINK_AUG_PARAMS], streams int32 [S] (uint32 bits) -- all on the device; `raw_cols`
+    a host list (transforms.raw_columns).  Returns float coordinates and features of the surviving
+    voxels.  The survivor count is read back (one small synchronisation of the current stream) unless
+    `params` is a host tensor whose DROPOUT column is all zero (then every voxel survives)."""
+    import torch
+
+    from .._lib import check, lib
+
+    if not coords.is_cuda:
+        raise RuntimeError("augment_batch runs on the GPU: move the batch to cuda first")
+    n, C = coords.shape[0], feats.shape[1]
+    dev = coords.device
+    if coords.dtype not in (torch.int32, torch.float32) or feats.dtype != torch.float32:
+        raise TypeError("augment_batch: coordinates int32 or float32, features float32")
+    coords, feats = coords.contiguous(), feats.contiguous()
+    host_params = params if not params.is_cuda else None
+    params = params.to(dev, torch.float32, non_blocking=True).contiguous()
+    out_c = torch.empty(n, 4, dtype=torch.float32, device=dev)
+    out_f = torch.empty(n, C, dtype=torch.float32, device=dev)
+    kept = torch.empty(1, dtype=torch.int32, device=dev)
+    n_scenes = scene_offsets.numel() - 1
+    offs = scene_offsets.to(dev, torch.int32, non_blocking=True).contiguous()
+    strm = streams.to(dev, torch.int32, non_blocking=True).contiguous()
+    ws = torch.empty(max(1, lib().mink_augment_workspace_bytes(n, n_scenes)), dtype=torch.uint8, device=dev)
+    cols = (ctypes.c_int32 * C)(*[int(c) for c in raw_cols])
+    stream = torch._C._cuda_getCurrentRawStream(dev.index)
+    check(
+        lib().mink_augment_scenes(
+            coords.data_ptr(), int(coords.dtype == torch.int32), feats.data_ptr(), C, C, n,
+            offs.data_ptr(), n_scenes, params.data_ptr(), strm.data_ptr(),
+            int(seed) & (2 ** 64 - 1), ctypes.cast(cols, ctypes.c_void_p), out_c.data_ptr(), out_f.data_ptr(), C,
+            kept.data_ptr(), ws.data_ptr(), stream,
+        )
+    )
+    # column 37 = MINK_AUG_DROPOUT: without dropout every voxel survives and the count is known on the host
+    if host_params is not None and not bool((host_params[:, 37] != 0).any()):
+        return out_c, out_f
+    k = int(kept.item())
+    return out_c[:k], out_f[:k]

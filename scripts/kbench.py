@@ -85,6 +85,29 @@ if which == "decode":
     t = timeit(lambda: ME.utils.decode_plenoxel_batch(batch), reps)
     nbytes = n * (4 + 4 + 27 + 16 + 112)
     print(f"decode_plenoxel n={n}: {t*1e3:.1f} us, {nbytes/1e6:.1f} MB algorithmic -> {nbytes/t/1e6:.0f} GB/s ({nbytes/t/1e6/8000*100:.1f} % of 8 TB/s)")
+if which == "augment":  # the full co3d_aug3 recipe on a whole batch (dropout, flip bounds, jitter, SH noise)
+    import random
+
+    import numpy as np
+    from nerf_downstream_amd.co3d_3d.src.data import transforms as T
+    n = x.F.shape[0]
+    random.seed(0), np.random.seed(0)
+    stages = [("linear", T.rotation_matrix([0.01, 1, 0.02], 1.0)), ("dropout", 0.2), ("flip", (0, 2)), ("translate", [0.1, -0.1, 0.05]),
+              ("jitter", 1.0), ("linear", np.eye(3) * 1.2), ("feature_jitter", 0.01, 4, 27)]
+    params = torch.from_numpy(np.stack([T.compile_program(stages)] * 16))
+    offs = torch.arange(0, n + 1, n // 16, dtype=torch.int32)[:17].contiguous()
+    offs[-1] = n
+    streams = torch.arange(16, dtype=torch.int32)
+    coords = x.C.contiguous()
+    feats = torch.randn(n, 28, device=dev)
+    raw = T.raw_columns(["density", "sh"])
+    for label, pr in (("aug3 (with dropout: +1 read-back)", params), ("aug3 without dropout", params.clone())):
+        if "without" in label:
+            pr[:, T.AUG["DROPOUT"]] = 0
+        t = timeit(lambda: ME.utils.augment_batch(coords, feats, offs, pr, streams, 1234, raw), reps)
+        kept = ME.utils.augment_batch(coords, feats, offs, pr, streams, 1234, raw)[0].shape[0]
+        nbytes = n * (16 + 112) + kept * (16 + 112)
+        print(f"augment n={n} kept={kept} {label}: {t*1e3:.1f} us, {nbytes/1e6:.1f} MB algorithmic -> {nbytes/t/1e6:.0f} GB/s ({nbytes/t/1e6/8000*100:.1f} % of 8 TB/s)")
 if which == "ksweep":
     keys = {1: k1}
     for ts in (2, 4, 8, 16, 32):
