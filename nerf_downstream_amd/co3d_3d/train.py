@@ -57,7 +57,10 @@ class CSVLogger:
 def _to_device(batch, device):
     # the augmentation parameter rows stay on the host too: `augment_batch` uploads them itself and can tell
     # from them, without a read-back, whether any voxel will be dropped
-    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) and k != "aug_params" else v) for k, v in batch.items()}
+    out = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) and k != "aug_params" else v) for k, v in batch.items()}
+    if device.type == "cuda":  # process_input prepares the batch on another stream: it waits for the copies through this
+        out["h2d_event"] = torch.cuda.current_stream(device).record_event()
+    return out
 
 
 def _dist_env():

@@ -65,7 +65,7 @@ def decode_plenoxel_batch(batch, reso=(128, 128, 128)):
     return coords, feats
 
 
-def augment_batch(coords, feats, scene_offsets, params, streams, seed, raw_cols):
+def augment_batch(coords, feats, scene_offsets, params, streams, seed, raw_cols, count_async=False):
     """Apply the drawn per-scene augmentation programs to a whole batch with `mink_augment_scenes`
     (reference transforms.py, applied per scene on the CPU at co3d.py:216-219).
 
@@ -73,7 +73,9 @@ def augment_batch(coords, feats, scene_offsets, params, streams, seed, raw_cols)
     params f32 [S, MINK_AUG_PARAMS], streams int32 [S] (uint32 bits) -- all on the device; `raw_cols`
     a host list (transforms.raw_columns).  Returns float coordinates and features of the surviving
     voxels.  The survivor count is read back (one small synchronisation of the current stream) unless
-    `params` is a host tensor whose DROPOUT column is all zero (then every voxel survives)."""
+    `params` is a host tensor whose DROPOUT column is all zero (then every voxel survives).
+    `count_async=True` never blocks: it returns (coords, feats, pending) with full-length buffers and
+    pending = None or (pinned int32 count, event recorded after its copy) for the caller to slice later."""
     import torch
 
     from .._lib import check, lib
@@ -106,6 +108,12 @@ def augment_batch(coords, feats, scene_offsets, params, streams, seed, raw_cols)
     )
     # column 37 = MINK_AUG_DROPOUT: without dropout every voxel survives and the count is known on the host
     if host_params is not None and not bool((host_params[:, 37] != 0).any()):
-        return out_c, out_f
+        return (out_c, out_f, None) if count_async else (out_c, out_f)
+    if count_async:
+        count = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        count.copy_(kept, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return out_c, out_f, (count, ev)
     k = int(kept.item())
     return out_c[:k], out_f[:k]

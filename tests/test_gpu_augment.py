@@ -107,3 +107,29 @@ def test_augmented_batch_trains():
         loss.backward()
         opt.step()
         assert torch.isfinite(loss)
+
+
+def test_deferred_augmented_batch_equals_immediate():
+    """Two-phase prepare of an augmented batch with dropout: process_input(defer=True) never blocks (the
+    survivor count travels through pinned memory), finish_input builds the same field as the blocking path."""
+    from nerf_downstream_amd.co3d_3d.src.data.synthetic import SparseVoxelDataset
+    from nerf_downstream_amd.co3d_3d.src.data.utils import collate_mink
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from nerf_downstream_amd.co3d_3d.src.models.mink.base_model import _PendingField
+
+    random.seed(1), np.random.seed(1)
+    ds = SparseVoxelDataset("train", num_samples=4, num_classes=4, grid=48,
+                            train_transformations=["RandomRotation", "CoordinateDropout", "RandomHorizontalFlip", "RandomScale"])
+    ds.transformations.transforms[1].application_ratio = 1.0  # every scene drops voxels
+    host = collate_mink([ds[j] for j in range(4)])
+    batch = {k: (v.cuda() if torch.is_tensor(v) and k != "aug_params" else v) for k, v in host.items()}
+    torch.manual_seed(0)
+    net = get_model("ResNet14", 28, 4).cuda().eval()
+    with torch.no_grad():
+        want = net(net.process_input(batch))
+        pend = net.process_input(batch, defer=True)
+        assert isinstance(pend, _PendingField)
+        got = net(net.finish_input(pend))
+        again = net.process_input(batch, defer=True)
+        got2 = net(again)  # forward on the pending object itself also works (sparse() finishes it)
+    assert torch.equal(want, got) and torch.equal(want, got2)
