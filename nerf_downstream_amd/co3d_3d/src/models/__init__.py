@@ -2,9 +2,9 @@
 lookup by class name through the gin-configurable `get_model`)."""
 from nerf_downstream_amd import gin_lite as gin
 
-from .mink.resnet import ResNet14, ResNet18, ResNet34
+from .mink.resnet import ResNet14, ResNet18, ResNet34, ResNet50, ResNet101
 
-MODELS = {c.__name__: c for c in (ResNet14, ResNet18, ResNet34)}
+MODELS = {c.__name__: c for c in (ResNet14, ResNet18, ResNet34, ResNet50, ResNet101)}
 
 
 @gin.configurable

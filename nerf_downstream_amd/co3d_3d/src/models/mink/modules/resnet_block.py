@@ -1,8 +1,10 @@
-"""Residual block of Mink-ResNet14/18/34 (counterpart of the reference's
-co3d_3d/src/models/mink/modules/resnet_block.py:11-73; parameter names conv1/norm1/conv2/
-norm2/downsample are kept for state-dict compatibility).
+"""Residual blocks of the Mink-ResNet family (counterpart of the reference's
+co3d_3d/src/models/mink/modules/resnet_block.py: BasicBlock :11-73, Bottleneck :76-132; parameter
+names conv1/norm1/conv2/norm2[/conv3/norm3]/downsample are kept for state-dict compatibility).
 
-    y = relu( norm2(conv2( relu(norm1(conv1(x))) )) + (downsample(x) or x) )
+    BasicBlock:  y = relu( norm2(conv2( relu(norm1(conv1(x))) )) + (downsample(x) or x) )
+    Bottleneck:  y = relu( norm3(conv3( relu(norm2(conv2( relu(norm1(conv1(x))) ))) )) + (downsample(x) or x) )
+                 conv1, conv3 are 1x1x1 (plain feature-matrix products), conv2 is 3x3x3 and carries the stride
 
 With a backend that advertises SUPPORTS_FUSED_NORM the three elementwise tails
 (norm1+relu, downsample norm, norm2+add+relu) each run as ONE fused HIP pass."""
@@ -74,5 +76,49 @@ class BasicBlock(nn.Module):
             return self.norm2(self.conv2(h, bn_stats=st), relu=True, residual=shortcut)
         h = self.nonlinearity(self.norm1(self.conv1(x)))
         h = self.norm2(self.conv2(h))
+        h += shortcut
+        return self.nonlinearity(h)
+
+
+class Bottleneck(BasicBlock):
+    """ResNet50/101 block (reference resnet_block.py:76-132): 1x1x1 reduce -> 3x3x3 (stride) -> 1x1x1
+    expand to 4 * planes, residual add, ReLU.  Shares the forked-shortcut machinery of BasicBlock."""
+
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, norm_type="BN",
+                 nonlinearity_type="MinkowskiReLU", bn_momentum=0.1, D=3, conv_mode=0, ME=None):
+        nn.Module.__init__(self)
+        ME = ME or default_me()
+        mk = dict(D=D, conv_mode=conv_mode, ME=ME)
+        self.conv1 = conv(inplanes, planes, kernel_size=1, **mk)
+        self.norm1 = get_norm(norm_type, planes, D, bn_momentum=bn_momentum, ME=ME)
+        self.conv2 = conv(planes, planes, kernel_size=3, stride=stride, dilation=dilation, **mk)
+        self.norm2 = get_norm(norm_type, planes, D, bn_momentum=bn_momentum, ME=ME)
+        self.conv3 = conv(planes, planes * self.expansion, kernel_size=1, **mk)
+        self.norm3 = get_norm(norm_type, planes * self.expansion, D, bn_momentum=bn_momentum, ME=ME)
+        self.downsample = downsample
+        self.nonlinearity = get_nonlinearity(nonlinearity_type, ME)()
+        self._fused = bool(getattr(ME, "SUPPORTS_FUSED_NORM", False))
+        self._fork = self._fused and os.environ.get("MINK_FORK_SHORTCUT", "1") != "0"
+        self._fork_unprepared = False
+
+    def forward(self, x):
+        join = None
+        if self._may_fork(x):
+            shortcut, join = self._forked_shortcut(x)
+        else:
+            shortcut = x if self.downsample is None else self.downsample(x)
+        if self._fused:
+            st = self.training
+            h = self.norm1(self.conv1(x), relu=True)
+            h = self.norm2(self.conv2(h, bn_stats=st), relu=True)
+            h = self.conv3(h)
+            if join is not None:
+                join()
+            return self.norm3(h, relu=True, residual=shortcut)
+        h = self.nonlinearity(self.norm1(self.conv1(x)))
+        h = self.nonlinearity(self.norm2(self.conv2(h)))
+        h = self.norm3(self.conv3(h))
         h += shortcut
         return self.nonlinearity(h)

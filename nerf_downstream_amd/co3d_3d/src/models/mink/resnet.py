@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .base_model import MinkowskiBaseModel
 from .modules.common import conv, get_norm
-from .modules.resnet_block import BasicBlock
+from .modules.resnet_block import BasicBlock, Bottleneck
 
 
 class GlobalAvgPool(nn.Module):
@@ -100,3 +100,13 @@ class ResNet18(ResNetBase):
 class ResNet34(ResNetBase):
     BLOCK = BasicBlock
     LAYERS = (3, 4, 6, 3)
+
+
+class ResNet50(ResNetBase):
+    BLOCK = Bottleneck
+    LAYERS = (3, 4, 6, 3)
+
+
+class ResNet101(ResNetBase):
+    BLOCK = Bottleneck
+    LAYERS = (3, 4, 23, 3)

@@ -25,7 +25,16 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
                                                        const float *__restrict__ invstd, double *__restrict__ partial,
                                                        const int *__restrict__ in2out = nullptr,
                                                        const float *__restrict__ gamma = nullptr,
-                                                       const float *__restrict__ beta = nullptr) {
+                                                       const float *__restrict__ beta = nullptr, int ld = 0) {
+  // more than 4 * EB channels (the Bottleneck nets reach 2048): blockIdx.y walks slabs of C channels
+  // of rows that are LD floats long; `partial` keeps the [blk][2][LD] layout
+  const int LD = ld ? ld : C;
+  {
+    const int c0 = blockIdx.y * C;
+    a += c0, b = b ? b + c0 : b, yrelu = yrelu ? yrelu + c0 : yrelu, partial += c0;
+    mean = mean ? mean + c0 : mean, invstd = invstd ? invstd + c0 : invstd;
+    gamma = gamma ? gamma + c0 : gamma, beta = beta ? beta + c0 : beta;
+  }
   extern __shared__ double s_red[];  // [rows_in_block][2][C] reduced over the row lanes
   const int tpr = C >> 2;            // threads per row
   const int rlanes = EB / tpr;       // rows handled concurrently
@@ -38,7 +47,7 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
   if (MODE == 2 && active) ga = ld4(gamma + 4 * c4), be = ld4(beta + 4 * c4);
   if (active) {
     for (int64_t row = (int64_t)blockIdx.x * rlanes + rl; row < n; row += (int64_t)gridDim.x * rlanes) {
-      const int64_t off = row * C + 4 * c4;
+      const int64_t off = row * LD + 4 * c4;
       if (MODE == 0) {
         const float4 v = ld4(a + off);
         s0.x += v.x, s0.y += v.y, s0.z += v.z, s0.w += v.w;
@@ -58,8 +67,8 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int64_t r = rows[u] < n ? rows[u] : row;
-          xs[u] = ld4(b + r * C + 4 * c4);
-          gs[u] = ld4(a + (int64_t)par[u] * C + 4 * c4);
+          xs[u] = ld4(b + r * LD + 4 * c4);
+          gs[u] = ld4(a + (int64_t)par[u] * LD + 4 * c4);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
   for (int e = threadIdx.x; e < 2 * C; e += EB) {
     double s = 0.0;
     for (int r = 0; r < rlanes; ++r) s += s_red[(int64_t)r * 2 * C + e];
-    partial[(int64_t)blockIdx.x * 2 * C + e] = s;
+    partial[(int64_t)blockIdx.x * 2 * LD + (e < C ? e : LD + e - C)] = s;
   }
 }
 
@@ -421,17 +430,20 @@ int64_t mink_bn_workspace_bytes(int64_t n, int32_t C) { return (int64_t)kRedBloc
 
 static int launch_colreduce(int mode, const float *a, const float *b, const float *yrelu, int64_t n, int C,
                             const float *mean, const float *invstd, double *partial, hipStream_t st, int *nblk_out) {
-  const int tpr = C >> 2;
-  MINK_REQUIRE(tpr <= EB, "bn: at most %d channels supported", 4 * EB);
+  int slabs = 1;  // slabs of at most 4 * EB channels
+  while (slabs <= C && (C % slabs != 0 || C / slabs > 4 * EB || ((C / slabs) & 3) != 0)) ++slabs;
+  MINK_REQUIRE(slabs <= C, "bn: %d channels cannot be cut into slabs of at most %d", C, 4 * EB);
+  const int Cs = C / slabs, tpr = Cs >> 2;
   const int rlanes = EB / tpr;
   int64_t nblk = cdiv(n, (int64_t)rlanes * 8);
   if (nblk > kRedBlocks) nblk = kRedBlocks;
   if (nblk < 1) nblk = 1;
-  const size_t shm = (size_t)rlanes * 2 * C * sizeof(double);
+  const size_t shm = (size_t)rlanes * 2 * Cs * sizeof(double);
+  const dim3 grid((unsigned)nblk, (unsigned)slabs);
   if (mode == 0)
-    colreduce_kernel<0><<<dim3((unsigned)nblk), EB, shm, st>>>(a, b, yrelu, n, C, mean, invstd, partial);
+    colreduce_kernel<0><<<grid, EB, shm, st>>>(a, b, yrelu, n, Cs, mean, invstd, partial, nullptr, nullptr, nullptr, C);
   else
-    colreduce_kernel<1><<<dim3((unsigned)nblk), EB, shm, st>>>(a, b, yrelu, n, C, mean, invstd, partial);
+    colreduce_kernel<1><<<grid, EB, shm, st>>>(a, b, yrelu, n, Cs, mean, invstd, partial, nullptr, nullptr, nullptr, C);
   MINK_CHECK_LAUNCH();
   *nblk_out = (int)nblk;
   return MINK_OK;

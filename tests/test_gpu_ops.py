@@ -72,7 +72,8 @@ def test_convolution_is_deterministic():
     assert torch.equal(a, b)  # no atomics anywhere: bitwise reproducible
 
 
-@pytest.mark.parametrize("C,relu,res", [(64, False, False), (64, True, False), (128, True, True), (512, False, True)])
+@pytest.mark.parametrize("C,relu,res", [(64, False, False), (64, True, False), (128, True, True), (512, False, True),
+                                        (2048, True, True), (1536, False, False)])  # > 1024 channels: column slabs
 def test_batch_norm(C, relu, res):
     from nerf_downstream_amd import minkowski as ME
 

@@ -24,6 +24,8 @@ def _models(name, cin, ncls):
     ("ResNet14", 28, 32, (11, 12, 13), True),
     ("ResNet14", 28, 32, (11, 12, 13), False),
     ("ResNet34", 27, 32, (11, 12, 13, 14, 15), True),
+    ("ResNet50", 28, 32, (11, 12, 13, 14, 15), True),   # Bottleneck blocks
+    ("ResNet50", 28, 32, (11, 12, 13, 14, 15), False),  # 5 scenes: BN over the 3 rows of a 3-scene batch at ts=32 amplifies rounding
 ])
 def test_resnet_matches_oracle(oracle_maps, name, cin, grid, seeds, fused):
     """Logits within the north_star tolerance (1e-3, fp32), then the gradients of every parameter.

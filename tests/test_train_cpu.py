@@ -143,6 +143,24 @@ def test_model_parameter_names_and_counts():
     m34 = get_model("ResNet34", 28, 51, ME=OME)
     assert sum(p.numel() for p in m34.parameters()) == 63_526_451
     assert len(m34.layer3) == 6
+    # Bottleneck family (reference resnet_block.py:76-132, resnet.py:195-202): 1x1x1 reduce, 3x3x3, 1x1x1 expand x4
+    m50 = get_model("ResNet50", 28, 51, ME=OME)
+    keys = list(m50.state_dict())
+    for k in ["layer1.0.conv1.kernel", "layer1.0.conv3.kernel", "layer1.0.norm3.bn.weight", "layer1.0.downsample.0.kernel",
+              "layer3.5.conv2.kernel", "layer4.2.norm3.bn.running_mean", "final.kernel"]:
+        assert k in keys, k
+    assert m50.layer1[0].conv1.kernel.shape == (64, 64) and m50.layer1[0].conv2.kernel.shape == (27, 64, 64)
+    assert m50.layer1[0].conv3.kernel.shape == (64, 256) and m50.layer2[0].downsample[0].kernel.shape == (1, 256, 512)
+    assert m50.layer2[0].conv2.stride == 2 and m50.layer2[0].conv1.stride == 1 and m50.final.kernel.shape == (2048, 51)
+    want, inp = 27 * 28 * 64 + 2 * 64 + 2048 * 51 + 51, 64
+    for planes, blocks in zip((64, 128, 256, 512), (3, 4, 6, 3)):
+        for j in range(blocks):
+            want += inp * planes + 27 * planes * planes + planes * 4 * planes + 2 * (planes + planes + 4 * planes)
+            if j == 0:
+                want += inp * 4 * planes + 2 * 4 * planes
+            inp = 4 * planes
+    assert sum(p.numel() for p in m50.parameters()) == want
+    assert [len(getattr(get_model("ResNet101", 28, 51, ME=OME), f"layer{i}")) for i in (1, 2, 3, 4)] == [3, 4, 23, 3]
 
 
 def test_product_train_refuses_cpu(tmp_path):
