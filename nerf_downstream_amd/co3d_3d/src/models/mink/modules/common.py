@@ -1,5 +1,5 @@
 """Layer factories of the Mink-ResNet family (counterpart of the reference's
-co3d_3d/src/models/mink/modules/common.py:22-32,73-125, DENSE branch only).
+co3d_3d/src/models/mink/modules/common.py:22-32,73-125,128-179, DENSE branch only).
 
 Every factory takes the ME namespace to build from, so one model definition runs on the HIP
 backend (default) and, in tests, on the CPU oracle."""
@@ -32,3 +32,13 @@ def conv(in_planes, out_planes, kernel_size, stride=1, dilation=1, bias=False, D
     ME = ME or _HIP_ME
     return ME.MinkowskiConvolution(in_channels=in_planes, out_channels=out_planes, kernel_size=kernel_size,
                                    stride=stride, dilation=dilation, bias=bias, dimension=D)
+
+
+def conv_tr(in_planes, out_planes, kernel_size, upsample_stride=1, dilation=1, bias=False, D=-1, conv_mode=0, ME=None):
+    """Up-sampling (transposed) convolution of the segmentation family (reference common.py:128-179)."""
+    assert D > 0, "Dimension must be a positive integer"
+    if int(getattr(conv_mode, "value", conv_mode)) != 0:
+        raise ValueError("only SparseConvMode.DENSE (0) is implemented; weight-sparse inference is out of scope")
+    ME = ME or _HIP_ME
+    return ME.MinkowskiConvolutionTranspose(in_channels=in_planes, out_channels=out_planes, kernel_size=kernel_size,
+                                            stride=upsample_stride, dilation=dilation, bias=bias, dimension=D)

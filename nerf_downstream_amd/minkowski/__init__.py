@@ -6,11 +6,13 @@ from .coords import CoordinateManager, CoordinateMapKey  # noqa: F401
 from .modules import (  # noqa: F401
     MinkowskiBatchNorm,
     MinkowskiConvolution,
+    MinkowskiConvolutionTranspose,
     MinkowskiGlobalAvgPooling,
     MinkowskiNetwork,
     MinkowskiReLU,
     MinkowskiSumPooling,
     MinkowskiSyncBatchNorm,
+    cat,
 )
 from .functional import set_conv_math  # noqa: F401
 from .tensor import SparseTensor, TensorField  # noqa: F401

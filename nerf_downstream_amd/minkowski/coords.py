@@ -336,6 +336,10 @@ class CoordinateManager:
             self._note_lazy(lev.coords, lev.tkeys, lev.tvals, inv)
         return CoordinateMapKey(ts_out)
 
+    def has_level(self, ts):
+        self._sync_lazy()
+        return int(ts) in self.levels
+
     def stride_map(self, in_key, out_key):
         k = (in_key.ts, out_key.ts)
         self._sync_lazy()

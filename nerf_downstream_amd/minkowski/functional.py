@@ -271,11 +271,12 @@ class ConvolutionFunction(torch.autograd.Function):
             pad = 4 - cin % 4
             x = torch.nn.functional.pad(x, (0, pad))
             w = torch.nn.functional.pad(w, (0, 0, 0, pad))
-        nbr = table_fn(False)[0]
+        tables = table_fn(False)
+        nbr = tables[0]
         ctx.save_for_backward(x, w)
         ctx.table_fn, ctx.same_map, ctx.nbr = table_fn, same_map, nbr
-        if stats_holder is None:
-            return gather_gemm(x, w, nbr, w.shape[-1])
+        if stats_holder is None:  # a transposed convolution brings the parity-class row order of its output
+            return gather_gemm(x, w, nbr, w.shape[-1], row_perm=tables[2] if len(tables) > 2 else None)
         y, partial = gather_gemm(x, w, nbr, w.shape[-1], stats=True)
         stats_holder.append(partial)
         return y

@@ -33,7 +33,7 @@ class MinkowskiConvolution(nn.Module):
         assert kernel_generator is None and not expand_coordinates, "custom kernel generators are out of scope"
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride, self.dilation = _as_int(kernel_size), _as_int(stride), _as_int(dilation)
-        assert self.kernel_size in (1, 3) or self.kernel_size % 2 == 1 and self.kernel_size ** 3 <= 27
+        assert self.kernel_size in (1, 2, 3), "kernel sizes 1, 2 (offsets {0,1}) and 3 (centred) are implemented"
         self.kernel_volume = self.kernel_size ** 3
         self.dimension = dimension
         self.use_mm = self.kernel_volume == 1 and self.stride == 1
@@ -80,6 +80,61 @@ class MinkowskiConvolution(nn.Module):
     def extra_repr(self):
         return (f"in={self.in_channels}, out={self.out_channels}, kernel_size={self.kernel_size}, "
                 f"stride={self.stride}, dilation={self.dilation}")
+
+
+class MinkowskiConvolutionTranspose(MinkowskiConvolution):
+    """ME.MinkowskiConvolutionTranspose as called by `conv_tr()` (reference modules/common.py:171-179;
+    res16unet.py:196-206): up-samples from tensor stride ts to ts / stride onto the coordinate map that
+    already exists there (the encoder's), out[i] += in[o] @ kernel[k] over the pairs (i, o, k) of the
+    ordinary convolution fine -> coarse.  kernel: (K, Cin, Cout), init U(+-1/sqrt(Cout*K)) (ME initialises
+    transposed kernels from the OUT channel count).
+
+    On the device this is the data-gradient kernel of the down-sampling convolution run forward: a gather
+    over the transposed neighbour table with rows grouped by parity class, so each 128-row tile multiplies
+    only the one kernel offset its rows can have (kernel_size == stride: one parent per voxel)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, expand_coordinates=False, convolution_mode=None, dimension=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, kernel_generator,
+                         expand_coordinates, convolution_mode, dimension)
+        assert self.stride == 2 and not self.use_mm, "the HIP backend up-samples by 2 (upsample_stride=2)"
+        stdv = 1.0 / math.sqrt(self.out_channels * self.kernel_volume)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def forward(self, input, coordinates=None, bn_stats=False):
+        assert coordinates is None, "explicit output coordinates are out of scope"
+        m = input.coordinate_manager
+        in_key = input.coordinate_map_key
+        ts = in_key.get_tensor_stride()[0]
+        if ts % self.stride or not m.has_level(ts // self.stride):
+            raise RuntimeError(f"MinkowskiConvolutionTranspose: no coordinate map at tensor stride {ts // self.stride} to "
+                               "up-sample onto (generative up-sampling is out of scope)")
+        out_key = CoordinateMapKey(ts // self.stride)
+        ks, dil = self.kernel_size, self.dilation
+
+        def table_fn(transposed, m=m, in_key=in_key, out_key=out_key):
+            # tables of the ordinary convolution fine (out_key) -> coarse (in_key), used the other way round
+            nbr, nbr_t = m.kernel_table(out_key, in_key, ks, dil, transposed=True)
+            if transposed:  # towards the coarse input: its rows gather their children
+                return nbr_t, nbr, None
+            return nbr_t, nbr, m.class_perm(out_key)
+
+        out = Fn.ConvolutionFunction.apply(input.F, self.kernel, table_fn, False, None)
+        if self.bias is not None:
+            out = out + self.bias
+        return SparseTensor(out, out_key, m)
+
+
+def cat(*tensors):
+    """ME.cat (reference res16unet.py:410-425): feature-wise concatenation of sparse tensors that share
+    one coordinate map."""
+    for t in tensors[1:]:
+        tensors[0]._check(t)
+    return SparseTensor(torch.cat([t.F for t in tensors], dim=1), tensors[0].coordinate_map_key,
+                        tensors[0].coordinate_manager)
 
 
 class MinkowskiBatchNorm(nn.Module):

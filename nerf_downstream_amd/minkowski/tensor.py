@@ -57,6 +57,15 @@ class SparseTensor:
         if not (self._manager is other._manager and self.coordinate_map_key == other.coordinate_map_key):
             raise ValueError("SparseTensors must share the coordinate manager and the coordinate map key")
 
+    def slice(self, field):
+        """`out.slice(x)` (reference res16unet.py:435): the features of this tensor-stride-1 tensor read
+        back at the rows of the TensorField it was quantised from (F[inverse mapping])."""
+        if not (_is_one(self.tensor_stride) and field.coordinate_manager is self._manager):
+            raise ValueError("slice: needs the tensor-stride-1 tensor and the field it came from")
+        m = self._manager
+        F = self._F if m.levels[1].n == field.F.shape[0] else self._F[m.field_inverse.long()]
+        return TensorField(features=F, coordinates=field.C, _manager=m)
+
     def __iadd__(self, other):  # `out += residual`, reference resnet_block.py:66
         self._check(other)
         self._F = Fn.AddFunction.apply(self._F, other._F)
@@ -87,6 +96,9 @@ class TensorField:
         -- called explicitly once other work has been queued, or implicitly by `.sparse()` --
         reads the row counts back and builds the rest of the plan on the same stream."""
         assert features is not None and coordinates is not None
+        if kwargs.get("_manager") is not None:  # a slice(): shares the manager of the field it came from
+            self._F, self._C, self._manager, self._plan, self._ready = features, coordinates, kwargs["_manager"], None, None
+            return
         if not coordinates.is_cuda:
             raise RuntimeError("nerf_downstream_amd.minkowski runs on the GPU only: move the batch to cuda first")
         self._F, self._C = features, coordinates

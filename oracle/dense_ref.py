@@ -8,6 +8,8 @@ the active output sites:
   * stride 2, k=3 at ts    -> conv3d(stride=2, padding=1); out index q <-> coord 2*ts*q
   * stride 2, k=1          -> conv3d(kernel 1, stride=2)  (pure sub-sampling)
   * sum-pool k=2,s=2       -> avg_pool3d(2,2) * 8
+  * stride 2, k=2          -> conv3d(kernel 2, stride=2, padding=0): even sizes use offsets {0,1}
+  * transposed k=2, s=2    -> conv_transpose3d(stride=2)
 
 Weight layout: W_dense[co,ci,dz,dy,dx] = kernel[(dx+1)+3(dy+1)+9(dz+1), ci, co];
 coordinate columns (x,y,z) <-> dense dims (W,H,D).  None of this shares code with
@@ -66,3 +68,16 @@ def sum_pool(in_coords, feats, ts_in, out_coords):
     g, shift = densify(in_coords, feats, ts_in, align=ts_in * 4)
     y = F.avg_pool3d(g, 2, 2) * 8.0
     return sample(y, out_coords, ts_in * 2, shift)
+
+
+def conv_transpose(in_coords, feats, kernel, ksize, stride, ts_in, out_coords):
+    """Dense evaluation of MinkowskiConvolutionTranspose(k=ksize, stride=ksize) from the step-`ts_in`
+    grid onto `out_coords` (step ts_in / stride): conv_transpose3d(stride) writes in[c] @ W[d] to the
+    fine site stride*c + d -- the transposed pairing of the even-size region {0..k-1} of conv()."""
+    assert ksize == stride, "non-overlapping up-sampling only (kernel_size == stride, as Res16UNet uses it)"
+    ts_out = ts_in // stride
+    g, shift = densify(in_coords, feats, ts_in, align=ts_in * 2)
+    k = kernel.reshape(ksize, ksize, ksize, kernel.shape[-2], kernel.shape[-1])
+    w = k.permute(3, 4, 0, 1, 2).contiguous()  # conv_transpose3d weight: [cin, cout, dz, dy, dx]
+    y = F.conv_transpose3d(g, w, stride=stride)
+    return sample(y, out_coords, ts_out, shift)

@@ -91,6 +91,15 @@ class CoordinateManager:
             self.tables[kk] = maps.kernel_map_table(self.coords[in_key.ts], self.coords[out_key.ts], off)
         return self.tables[kk]
 
+    def kernel_table_transposed(self, fine_key, coarse_key, kernel_size, dilation=1):
+        """Table of a transposed convolution coarse -> fine [ME-recall]: the kernel map of the ordinary
+        convolution fine -> coarse with in and out swapped, i.e. nbr_t[i][k] = o for every nbr[o][k] = i."""
+        nbr = self.kernel_table(fine_key, coarse_key, kernel_size, dilation)
+        nbr_t = np.full((self.coords[fine_key.ts].shape[0], nbr.shape[1]), -1, np.int32)
+        o, k = np.nonzero(nbr >= 0)
+        nbr_t[nbr[o, k], k] = o
+        return nbr_t
+
     def kernel_map(self, in_key, out_key, stride=1, kernel_size=3, dilation=1, is_transpose=False, is_pool=False):
         """ME-format kernel map {k: IntTensor[2,n]} (witness: sparse_conv.py:90-96,124-143)."""
         assert not is_transpose
@@ -144,6 +153,13 @@ class SparseTensor:
     def _check(self, other):
         assert self.coordinate_map_key == other.coordinate_map_key and self._manager is other._manager
 
+    def slice(self, field):
+        """`out.slice(x)` (reference res16unet.py:435) [ME-recall]: the features of this tensor-stride-1
+        sparse tensor read back at the rows of the field it was quantised from (F[inverse_mapping])."""
+        assert self.coordinate_map_key.ts == 1 and field._manager is self._manager
+        inv = torch.from_numpy(self._manager.field_inverse.astype(np.int64))
+        return TensorField(features=self.F[inv], coordinates=field.C, _manager=self._manager)
+
     def __iadd__(self, other):  # reference resnet_block.py:66
         self._check(other)
         self._F = self._F + other._F
@@ -154,6 +170,14 @@ class SparseTensor:
         return SparseTensor(self._F + other._F, self.coordinate_map_key, self._manager)
 
 
+def cat(*tensors):
+    """ME.cat [ME-recall]: feature-wise concatenation of sparse tensors that share one coordinate map
+    (reference res16unet.py:410,415,420,425)."""
+    for t in tensors[1:]:
+        tensors[0]._check(t)
+    return SparseTensor(torch.cat([t.F for t in tensors], dim=1), tensors[0].coordinate_map_key, tensors[0]._manager)
+
+
 class TensorField:
     """ME.TensorField(coordinates=[N,1+D] float, features=[N,C]) (base_model.py:10-13)."""
 
@@ -161,6 +185,9 @@ class TensorField:
         assert coordinates is not None and features is not None
         self._F = features
         self._C = coordinates
+        if kw.get("_manager") is not None:  # a slice(): shares the manager of the field it came from
+            self._manager = kw["_manager"]
+            return
         self._manager = CoordinateManager(D=coordinates.shape[1] - 1)
         self.coordinate_field_map_key = self._manager.insert_field(coordinates)
 
@@ -293,6 +320,33 @@ class MinkowskiConvolution(nn.Module):
             out_key = m.stride(input.coordinate_map_key, self.stride)
             nbr = m.kernel_table(input.coordinate_map_key, out_key, self.kernel_size, self.dilation)
             out = _ConvFn.apply(input.F, self.kernel, nbr)
+        if self.bias is not None:
+            out = out + self.bias
+        return SparseTensor(out, out_key, m)
+
+
+class MinkowskiConvolutionTranspose(MinkowskiConvolution):
+    """ME.MinkowskiConvolutionTranspose (reference modules/common.py:171-179) [ME-recall]: up-samples
+    from tensor stride ts to ts / stride onto the coordinate map that already exists there (the
+    encoder's), out[i] += in[o] @ kernel[k] over the pairs (i, o, k) of the ordinary convolution
+    fine -> coarse.  Weights are initialised from the OUT channel count (ME reset_parameters(True))."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, dimension=None, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, dimension)
+        assert not self.use_mm
+        stdv = 1.0 / math.sqrt(self.out_channels * self.kernel_volume)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def forward(self, input):
+        m = input._manager
+        ts = input.coordinate_map_key.ts
+        assert ts % self.stride == 0 and ts // self.stride in m.coords, "no coordinate map to up-sample onto"
+        out_key = CoordinateMapKey(ts // self.stride)
+        nbr_t = m.kernel_table_transposed(out_key, input.coordinate_map_key, self.kernel_size, self.dilation)
+        out = _ConvFn.apply(input.F, self.kernel, nbr_t)
         if self.bias is not None:
             out = out + self.bias
         return SparseTensor(out, out_key, m)

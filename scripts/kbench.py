@@ -108,6 +108,28 @@ if which == "augment":  # the full co3d_aug3 recipe on a whole batc
         kept = ME.utils.augment_batch(coords, feats, offs, pr, streams, 1234, raw)[0].shape[0]
         nbytes = n * (16 + 112) + kept * (16 + 112)
         print(f"augment n={n} kept={kept} {label}: {t*1e3:.1f} us, {nbytes/1e6:.1f} MB algorithmic -> {nbytes/t/1e6:.0f} GB/s ({nbytes/t/1e6/8000*100:.1f} % of 8 TB/s)")
+if which == "unet":  # Res16UNet forward + backward + SGD on the B=16 synthetic batch (per-voxel labels)
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    import torch.nn.functional as F
+    for name in ("Res16UNet14A", "Res16UNet34C"):
+        torch.manual_seed(0)
+        net = get_model(name, 28, 20).to(dev).train()
+        opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, fused=True)
+        batch = {"coordinates": b["coordinates"].to(dev), "features": b["features"].to(dev)}
+        labels = torch.randint(0, 20, (batch["coordinates"].shape[0],), device=dev)
+        state = {"tf": net.process_input(batch)}
+        def step():
+            tf = state["tf"]
+            nxt = net.process_input(batch, defer=True)
+            opt.zero_grad(set_to_none=True)
+            loss = F.cross_entropy(net(tf), labels)
+            loss.backward()
+            state["tf"] = net.finish_input(nxt)
+            opt.step()
+        for _ in range(3): step()
+        t = timeit(step, reps)
+        n = batch["coordinates"].shape[0]
+        print(f"{name}: {t:.2f} ms/step fwd+bwd+SGD, {n} voxels -> {n/t/1e3:.1f} M voxels/s")
 if which == "ksweep":
     keys = {1: k1}
     for ts in (2, 4, 8, 16, 32):

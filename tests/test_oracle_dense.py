@@ -44,6 +44,49 @@ def test_conv_matches_dense(oracle_maps, ksize, stride, negative):
         assert torch.allclose(conv.kernel.grad, k_ref.grad, atol=1e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("negative", [False, True])
+def test_even_kernel_and_transposed_conv_match_dense(oracle_maps, negative):
+    """The two extra operators of the segmentation family (reference res16unet.py:97-108,196-206):
+    convolution k=2 s=2 (even kernel: offsets {0,1}, x fastest) and its transposed counterpart that up-samples
+    onto the encoder's coordinate map; plus cat and slice."""
+    from oracle import dense_ref
+
+    torch.manual_seed(0)
+    ME, tf = _field([5, 6], 5, negative)
+    x = tf.sparse()
+    m = x._manager
+    down = ME.MinkowskiConvolution(5, 6, kernel_size=2, stride=2, dimension=3)
+    F_in = x.F.detach().clone().requires_grad_(True)
+    y = down(ME.SparseTensor(F_in, x.coordinate_map_key, m))
+    assert y.tensor_stride[0] == 2 and down.kernel.shape == (8, 5, 6)
+    F_ref, k_ref = x.F.detach().clone().requires_grad_(True), down.kernel.detach().clone().requires_grad_(True)
+    ref = dense_ref.conv(m.coords[1], F_ref, k_ref, 2, 2, 1, m.coords[2])
+    assert torch.allclose(y.F, ref, atol=1e-5, rtol=1e-5)
+    g = torch.randn_like(ref)
+    y.F.backward(g), ref.backward(g)
+    assert torch.allclose(F_in.grad, F_ref.grad, atol=1e-5) and torch.allclose(down.kernel.grad, k_ref.grad, atol=1e-4)
+
+    up = ME.MinkowskiConvolutionTranspose(6, 4, kernel_size=2, stride=2, dimension=3)
+    Y_in = y.F.detach().clone().requires_grad_(True)
+    z = up(ME.SparseTensor(Y_in, y.coordinate_map_key, m))
+    assert z.tensor_stride[0] == 1 and z.F.shape == (x.F.shape[0], 4) and z.coordinate_map_key == x.coordinate_map_key
+    Y_ref, u_ref = y.F.detach().clone().requires_grad_(True), up.kernel.detach().clone().requires_grad_(True)
+    zref = dense_ref.conv_transpose(m.coords[2], Y_ref, u_ref, 2, 2, 2, m.coords[1])
+    assert torch.allclose(z.F, zref, atol=1e-5, rtol=1e-5)
+    g = torch.randn_like(zref)
+    z.F.backward(g), zref.backward(g)
+    assert torch.allclose(Y_in.grad, Y_ref.grad, atol=1e-5) and torch.allclose(up.kernel.grad, u_ref.grad, atol=1e-4)
+    # every fine voxel has exactly one parent: one pair per output row
+    assert (m.kernel_table_transposed(x.coordinate_map_key, y.coordinate_map_key, 2) >= 0).sum(1).tolist() == [1] * x.F.shape[0]
+
+    c = ME.cat(z, x)
+    assert c.F.shape == (x.F.shape[0], 9) and torch.equal(c.F[:, 4:], x.F) and c.coordinate_map_key == x.coordinate_map_key
+    s = c.slice(tf)
+    assert s.F.shape == (tf.F.shape[0], 9)
+    inv = torch.from_numpy(m.field_inverse.astype("int64"))
+    assert torch.equal(s.F, c.F[inv]) and torch.equal(torch.floor(tf.C).int(), torch.from_numpy(m.coords[1])[inv])
+
+
 def test_sum_pool_matches_dense(oracle_maps):
     from oracle import dense_ref
 

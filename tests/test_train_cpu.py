@@ -163,6 +163,33 @@ def test_model_parameter_names_and_counts():
     assert [len(getattr(get_model("ResNet101", 28, 51, ME=OME), f"layer{i}")) for i in (1, 2, 3, 4)] == [3, 4, 23, 3]
 
 
+def test_res16unet_names_and_shapes():
+    """State-dict layout of the reference Res16UNet (res16unet.py:60-352) and the gin-configured base class."""
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from oracle import me_cpu as OME
+
+    m = get_model("Res16UNet14A", 28, 20, ME=OME)
+    keys = list(m.state_dict())
+    for k in ["conv0p1s1.0.kernel", "conv0p1s1.1.bn.weight", "conv0p1s1.3.kernel", "conv0p1s1.4.bn.running_mean", "conv1p1s2.0.kernel",
+              "block1.0.conv1.kernel", "block2.0.downsample.0.kernel", "conv4p8s2.1.bn.bias", "convtr4p16s2.0.kernel",
+              "block5.0.downsample.1.bn.weight", "convtr7p2s2.1.bn.num_batches_tracked", "block8.0.norm2.bn.bias", "final.kernel",
+              "final.bias"]:
+        assert k in keys, k
+    assert m.conv1p1s2[0].kernel.shape == (8, 32, 32) and m.conv1p1s2[0].stride == 2
+    assert m.convtr4p16s2[0].kernel.shape == (8, 256, 128) and m.block5[0].conv1.kernel.shape == (27, 128 + 128, 128)
+    assert m.block8[0].conv1.kernel.shape == (27, 96 + 32, 96) and m.final.kernel.shape == (96, 20) and m.final.bias.shape == (1, 20)
+    assert m.block2[0].downsample[0].kernel.shape == (32, 64)  # 1x1x1 stride 1: plain matrix (use_mm)
+    gin.clear_config()
+    gin.parse_config_file(f"{CFG}/res16unet.gin")
+    try:
+        u = get_model(in_channel=28, out_channel=20, ME=OME)
+        assert type(u).__name__ == "Res16UNet" and u.LAYERS == (1, 1, 2, 2, 2, 2, 1, 1) and len(u.block3) == 2
+        assert u.PLANES == (32, 48, 64, 96, 96, 96, 64, 64) and u.convtr5p8s2[0].kernel.shape == (8, 96, 96)
+    finally:
+        gin.clear_config()
+    assert len(get_model("Res16UNet34C", 28, 20, ME=OME).block4) == 6
+
+
 def test_product_train_refuses_cpu(tmp_path):
     from nerf_downstream_amd.co3d_3d.train import train
 
