@@ -389,6 +389,16 @@ class CoordinateManager:
         c = counts.tolist()
         return {k: torch.stack([pin[c[k] : c[k + 1]], pout[c[k] : c[k + 1]]]) for k in range(K) if c[k + 1] > c[k]}
 
+    def identity_table(self, key):
+        """nbr[n,1] = row index: lets the weight-gradient kernels serve the 1x1x1 convolutions."""
+        ck = ("ident", key.ts)
+        self._sync_lazy()
+        if ck not in self.tables:
+            n = self.size(key)
+            self.tables[ck] = torch.arange(n, dtype=torch.int32, device=self.device).reshape(n, 1)
+            self._note_lazy(self.tables[ck])
+        return self.tables[ck]
+
     def class_perm(self, key, pad=128):
         """Parity-class row permutation of the map `key` (for dgrad of stride-2 convolutions)."""
         ck = ("perm", key.ts, pad)

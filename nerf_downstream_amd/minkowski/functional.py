@@ -346,6 +346,30 @@ class ConvolutionFunction(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
+class PointwiseConvolutionFunction(torch.autograd.Function):
+    """1x1x1 stride-1 convolution = F @ W (`use_mm`, witness sparse_conv.py:323-335).  Forward and input
+    gradient are plain library GEMMs with a long M; the weight gradient X^T dY is [cin, cout] small with the
+    row count as its reduction dimension -- the library runs that on a few dozen workgroups (14 ms for
+    825 k x 128 -> 96), so it goes through the streaming weight-gradient kernel with an identity table."""
+
+    @staticmethod
+    def forward(ctx, x, w, ident_fn):
+        ctx.save_for_backward(x, w)
+        ctx.ident_fn = ident_fn
+        return x.mm(w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        # (W^T materialised: for the transposed-operand form the library picks a 12-wide macro tile -- 10 ms
+        # instead of 0.7 ms for 825 k x 96 -> 128)
+        gx = gy.mm(w.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = conv_wgrad(_f32c(x), _f32c(gy), ctx.ident_fn(), (1,) + tuple(w.shape)).view_as(w)
+        return gx, gw, None
+
+
 # -------------------------------------------------------------------------- batch norm
 def _bn_statistics(L, x, n, C, eps, momentum, running_mean, running_var, partial):
     """mean / invstd of the batch (+ running-stat update): from the producer's column partials

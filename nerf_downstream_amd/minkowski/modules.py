@@ -59,7 +59,10 @@ class MinkowskiConvolution(nn.Module):
         holder = [] if (bn_stats and self.bias is None and not self.use_mm) else None
         if self.use_mm:  # plain matmul on the feature matrix, same coordinates
             out_key = in_key
-            out = input.F.mm(self.kernel)
+            if input.F.shape[0] >= 4096 and self.kernel.requires_grad and torch.is_grad_enabled():
+                out = Fn.PointwiseConvolutionFunction.apply(input.F, self.kernel, lambda m=m, k=in_key: m.identity_table(k))
+            else:
+                out = input.F.mm(self.kernel)
         else:
             out_key = m.stride(in_key, self.stride)
             ks, dil = self.kernel_size, self.dilation

@@ -111,7 +111,8 @@ if which == "augment":  # the full co3d_aug3 recipe on a whole batc
 if which == "unet":  # Res16UNet forward + backward + SGD on the B=16 synthetic batch (per-voxel labels)
     from nerf_downstream_amd.co3d_3d.src.models import get_model
     import torch.nn.functional as F
-    for name in ("Res16UNet14A", "Res16UNet34C"):
+    import os
+    for name in os.environ.get("KB_UNET", "Res16UNet14A,Res16UNet34C").split(","):
         torch.manual_seed(0)
         net = get_model(name, 28, 20).to(dev).train()
         opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, fused=True)

@@ -368,3 +368,30 @@ def test_fused_stem_conv_bn_relu_pool(cin):
                        (bn.bn.bias.grad, bn2.bn.bias.grad, "dbeta")):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * scale, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("n,cin,cout", [(5000, 128, 96), (70001, 64, 256), (4096, 20, 36)])
+def test_pointwise_convolution_weight_gradient(n, cin, cout):
+    """1x1x1 stride-1 convolution (`use_mm`): library GEMMs forward / input gradient, the streaming
+    weight-gradient kernel (identity table) for X^T dY -- against torch in float64."""
+    from nerf_downstream_amd import minkowski as ME
+
+    torch.manual_seed(0)
+    coords = torch.zeros(n, 4)
+    coords[:, 1], coords[:, 2] = torch.arange(n) % 1000, torch.arange(n) // 1000
+    x = torch.randn(n, cin)
+    tf = ME.TensorField(coordinates=coords.cuda(), features=x.cuda())
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=1, stride=1, bias=True, dimension=3).cuda()
+    assert conv.use_mm and conv.kernel.shape == (cin, cout)
+    xg = x.cuda().requires_grad_(True)
+    y = conv(ME.SparseTensor(xg, ME.CoordinateMapKey(1), tf.coordinate_manager)).F
+    assert "PointwiseConvolution" in type(y.grad_fn.next_functions[0][0]).__name__
+    g = torch.randn(n, cout)
+    y.backward(g.cuda())
+    xd, wd = x.double().requires_grad_(True), conv.kernel.detach().cpu().double().requires_grad_(True)
+    yd = xd @ wd + conv.bias.detach().cpu().double()
+    yd.backward(g.double())
+    assert torch.allclose(y.detach().cpu().double(), yd.detach(), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(xg.grad.cpu().double(), xd.grad, atol=1e-4, rtol=1e-4)
+    scale = float(wd.grad.abs().max())
+    assert float((conv.kernel.grad.cpu().double() - wd.grad).abs().max()) < 2e-5 * scale
