@@ -2,9 +2,9 @@
 from nerf_downstream_amd import gin_lite as gin
 
 from .co3d import Co3D10pDataset, Co3DDataset
-from .synthetic import SparseVoxelDataset
+from .synthetic import SparseVoxelDataset, SparseVoxelSegDataset
 
-DATASETS = {c.__name__: c for c in (Co3DDataset, Co3D10pDataset, SparseVoxelDataset)}
+DATASETS = {c.__name__: c for c in (Co3DDataset, Co3D10pDataset, SparseVoxelDataset, SparseVoxelSegDataset)}
 
 
 @gin.configurable

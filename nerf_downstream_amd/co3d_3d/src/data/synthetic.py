@@ -82,3 +82,29 @@ class SparseVoxelDataset(Dataset):
             params, stream = self.transformations.sample()
             sample.update(aug_params=torch.from_numpy(params), aug_stream=stream, feature_names=tuple(self.features))
         return sample
+
+
+@gin.configurable
+class SparseVoxelSegDataset(SparseVoxelDataset):
+    """Per-voxel labels for the segmentation family (Res16UNet; the reference trains it on PeRFception-ScanNet,
+    data/scannet.py, which is not reproduced here): label = octant of the voxel about the grid centre, rotated by
+    the scene's class so the features matter, `ignore_ratio` of the voxels carry `ignore_label` (ScanNet's
+    unlabelled points).  Sample dict as the reference segmentation datasets: "labels" is int64 [N]."""
+
+    def __init__(self, phase="train", num_samples=64, num_classes=8, grid=64, features=("density", "sh"),
+                 ignore_label=255, ignore_ratio=0.05, train_transformations=()):
+        super().__init__(phase, num_samples, num_classes, grid, features, False, train_transformations)
+        self.ignore_label, self.ignore_ratio = ignore_label, ignore_ratio
+
+    def __getitem__(self, index):
+        if self.transformations is not None:
+            raise NotImplementedError("augmentation with dropout would need the per-voxel labels compacted alongside")
+        sample = super().__getitem__(index)
+        xyz = sample["coordinates"].numpy()
+        scene_class = int(sample["labels"][0])
+        oct_ = ((xyz[:, 0] >= self.grid / 2).astype(np.int64) + 2 * (xyz[:, 1] >= self.grid / 2) + 4 * (xyz[:, 2] >= self.grid / 2))
+        labels = (oct_ + scene_class) % min(self.num_classes, 8)
+        rng = np.random.default_rng(7_000_003 * self.split + index)
+        labels[rng.random(len(labels)) < self.ignore_ratio] = self.ignore_label
+        sample["labels"] = labels.astype(np.int64)
+        return sample

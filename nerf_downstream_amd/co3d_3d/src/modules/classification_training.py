@@ -17,6 +17,8 @@ def accuracy(output, target, topk=(1,)):
 
 
 class ClassificationTraining:
+    monitor = "val/acc1"
+
     def __init__(self, model):
         self.model = model
 
@@ -43,3 +45,19 @@ class ClassificationTraining:
         c1 = (top[:, 0] == labels).sum()
         c5 = (top == labels[:, None]).any(1).sum()
         return loss.detach(), c1, c5, labels.numel()
+
+    @torch.no_grad()
+    def train_metrics(self, out, batch):
+        acc1, acc5 = accuracy(out, batch["labels"].long(), topk=(1, 5))
+        return {"train/acc1": acc1, "train/acc5": acc5}
+
+    @torch.no_grad()
+    def val_accumulate(self, batch):
+        """-> float64 vector [loss * n, correct@1, correct@5, n] that validate() sums over batches and ranks."""
+        loss, c1, c5, n = self.validation_step(batch)
+        return torch.stack([loss.double() * n, c1.double(), c5.double(), torch.tensor(float(n), device=loss.device, dtype=torch.float64)])
+
+    @staticmethod
+    def val_metrics(tot):
+        n = max(float(tot[3]), 1.0)
+        return {"val/loss": float(tot[0]) / n, "val/acc1": 100.0 * float(tot[1]) / n, "val/acc5": 100.0 * float(tot[2]) / n}

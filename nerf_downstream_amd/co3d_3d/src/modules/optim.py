@@ -48,7 +48,37 @@ class CosineAnnealingLR(lr_scheduler.CosineAnnealingLR):
         super().__init__(optimizer, T_max, eta_min, last_epoch)
 
 
-SCHEDULERS = {c.__name__: c for c in (StepLR, CosineAnnealingLR)}
+class _Poly:  # picklable (checkpoints store the scheduler state)
+    def __init__(self, max_steps, poly_exp):
+        self.max_steps, self.poly_exp = max_steps, poly_exp
+
+    def __call__(self, step):
+        return (1 - step / (self.max_steps + 1)) ** self.poly_exp
+
+
+@gin.configurable
+class PolyLR(lr_scheduler.LambdaLR):
+    """lr * (1 - step / (max_steps + 1)) ** poly_exp -- the segmentation recipe's schedule (reference optim.py:180-205,
+    configs/scannet_semseg.gin:55-61)."""
+
+    def __init__(self, optimizer, poly_exp=0.9):
+        self.max_steps, self.poly_exp = gin.query_parameter("train.max_steps"), poly_exp
+        super().__init__(optimizer, _Poly(self.max_steps, poly_exp))
+
+
+@gin.configurable
+class MultiStepLR(lr_scheduler.MultiStepLR):
+    def __init__(self, optimizer, milestones=(20000, 40000), gamma=0.1, last_epoch=-1):
+        super().__init__(optimizer, list(milestones), gamma, last_epoch)
+
+
+@gin.configurable
+class ExponentialLR(lr_scheduler.ExponentialLR):
+    def __init__(self, optimizer, gamma=0.99):
+        super().__init__(optimizer, gamma)
+
+
+SCHEDULERS = {c.__name__: c for c in (StepLR, MultiStepLR, ExponentialLR, CosineAnnealingLR, PolyLR)}
 
 
 def get_scheduler(scheduler_name, optimizer, warmup_steps=-1):

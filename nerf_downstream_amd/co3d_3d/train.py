@@ -30,7 +30,10 @@ import torch.distributed as dist
 from nerf_downstream_amd import gin_lite as gin
 from nerf_downstream_amd.co3d_3d.src.data.data_module import DataModule
 from nerf_downstream_amd.co3d_3d.src.models import get_model
-from nerf_downstream_amd.co3d_3d.src.modules.classification_training import ClassificationTraining, accuracy
+from nerf_downstream_amd.co3d_3d.src.modules.classification_training import ClassificationTraining
+from nerf_downstream_amd.co3d_3d.src.modules.segmentation_training import SegmentationTraining
+
+TRAINING_MODULES = {"ClassificationTraining": ClassificationTraining, "SegmentationTraining": SegmentationTraining}
 from nerf_downstream_amd.co3d_3d.src.modules.optim import get_optimizer, get_scheduler
 from nerf_downstream_amd.parallel import BucketedGradAllReduce
 
@@ -98,16 +101,15 @@ def validate(module, loader, device, world):
     model = module.model
     was_training = model.training
     model.eval()
-    tot = torch.zeros(4, dtype=torch.float64, device=device)  # loss*n, correct1, correct5, n
+    tot = None  # the module's accumulable vector (classification: loss*n, correct@1, correct@5, n; segmentation: + confusion matrix)
     for batch in loader:
         batch = _to_device(batch, device)
-        loss, c1, c5, n = module.validation_step(batch)
-        tot += torch.stack([loss.double() * n, c1.double(), c5.double(), torch.tensor(float(n), device=device, dtype=torch.float64)])
+        v = module.val_accumulate(batch)
+        tot = v if tot is None else tot + v
     if world > 1:
         dist.all_reduce(tot)
     model.train(was_training)
-    n = max(tot[3].item(), 1.0)
-    return {"val/loss": tot[0].item() / n, "val/acc1": 100.0 * tot[1].item() / n, "val/acc5": 100.0 * tot[2].item() / n}
+    return module.val_metrics(tot)
 
 
 @gin.configurable
@@ -159,8 +161,6 @@ def train(
 ):
     """Same parameters (and gin bindings `train.*`) as the reference.  `ME` / `device` are test
     hooks: the CPU tests inject the oracle namespace to run BASELINE config #1 on the host."""
-    if training_module != "ClassificationTraining":
-        raise NotImplementedError(f"{training_module}: only ClassificationTraining is on the MI355X hot path")
     if scheduler_interval != "step":
         raise NotImplementedError("the classification configs step the scheduler per iteration")
     world, rank, local_rank = _dist_env()
@@ -190,7 +190,9 @@ def train(
 
     data = DataModule(train_phase, val_phase, test_phase, batch_size, val_batch_size, train_num_workers, val_num_workers,
                       collate_func_name, world_size=world, rank=rank, seed=seed)
-    module = ClassificationTraining(model)
+    if training_module not in TRAINING_MODULES:
+        raise ValueError(f"train.training_module = {training_module!r}; available: {sorted(TRAINING_MODULES)}")
+    module = TRAINING_MODULES[training_module](model)
     optimizer = get_optimizer(optimizer_name, model.parameters(), lr=lr, weight_decay=weight_decay)
     scheduler = get_scheduler(scheduler_name, optimizer, warmup_steps)
     reducer = BucketedGradAllReduce(model) if world > 1 else None
@@ -256,10 +258,9 @@ def train(
                 gc.freeze()
             if step % log_every_n_steps == 0:
                 loss_float = float(loss.detach().cpu())
-                ClassificationTraining.check_finite(loss_float)
-                acc1, acc5 = accuracy(out.detach(), cur_batch["labels"].long(), topk=(1, 5))
+                module.check_finite(loss_float)
                 now = time.perf_counter()
-                m = {"train/loss": loss_float, "train/acc1": acc1, "train/acc5": acc5,
+                m = {"train/loss": loss_float, **module.train_metrics(out.detach(), cur_batch),
                      "train/iter_time": (now - t_iter) / log_every_n_steps, "lr": optimizer.param_groups[0]["lr"]}
                 t_iter = now
                 history.append({"global_step": step, **m})
@@ -276,7 +277,7 @@ def train(
                     logger.info(f"step {step}: " + " ".join(f"{k}={v:.4g}" for k, v in vm.items()))
                     os.makedirs(os.path.dirname(last_ckpt), exist_ok=True)
                     save_checkpoint(last_ckpt, model, optimizer, scheduler, step, epoch, best)
-                    score = vm.get(monitor_metric, vm["val/acc1"])
+                    score = vm.get(monitor_metric, vm[module.monitor])
                     if score > best:
                         best = score
                         save_checkpoint(os.path.join(save_path, run_name, "best.ckpt"), model, optimizer, scheduler, step, epoch, best)

@@ -226,6 +226,40 @@ def test_baseline_config0_cpu_plumbing(tmp_path):
     assert res2["global_step"] == 6
 
 
+def test_segmentation_cpu_plumbing(tmp_path):
+    """co3d_3d/train.py with train.training_module = SegmentationTraining: Res16UNet on per-voxel labels, CPU oracle
+    backend; and the confusion-matrix metrics against a hand-computed case (reference utils fast_hist / per_class_iu)."""
+    from nerf_downstream_amd.co3d_3d.src.modules.segmentation_training import confusion, iou_metrics
+    from nerf_downstream_amd.co3d_3d.train import train
+    from oracle import me_cpu as OME
+
+    pred = torch.tensor([0, 0, 1, 1, 2, 2, 0, 1])
+    label = torch.tensor([0, 1, 1, 1, 2, 0, 255, -1])  # the last two are ignored (outside 0..n-1)
+    h = confusion(pred, label, 3)
+    assert h.tolist() == [[1, 0, 1], [1, 2, 0], [0, 0, 1]]
+    miou, macc, oa = iou_metrics(h)
+    assert abs(miou - 100 * (1 / 3 + 2 / 3 + 1 / 2) / 3) < 1e-6 and abs(macc - 100 * (1 / 2 + 2 / 3 + 1) / 3) < 1e-6
+    assert abs(oa - 100 * 4 / 6) < 1e-6
+    assert iou_metrics(confusion(pred[:4], label[:4], 5))[0] == pytest.approx(100 * (1 / 2 + 2 / 3) / 2)  # absent classes do not count
+
+    gin.parse_config_files_and_bindings(
+        [f"{CFG}/co3d_cls.gin", f"{CFG}/synthetic_seg.gin", f"{CFG}/res16unet.gin"],
+        ["train.gpus=0", "train.max_steps=3", "train.val_every_n_steps=3", "train.log_every_n_steps=1", "train.batch_size=2",
+         "train.val_batch_size=2", "SparseVoxelSegDataset.grid=16", "SparseVoxelSegDataset.num_samples=8", "train.lr=0.01"],
+    )
+    res = train(save_path=str(tmp_path), resume_training=False, run_name="s", run_name_postfix=None, ME=OME)
+    assert res["global_step"] == 3
+    logged = [x for x in res["history"] if "train/loss" in x]
+    assert len(logged) == 3 and all(np.isfinite(x["train/loss"]) and 0 <= x["train/mIoU"] <= 100 for x in logged)
+    assert 0 < logged[0]["train/ignore_ratio"] < 20
+    val = [x for x in res["history"] if "val/mIoU" in x]
+    assert len(val) == 1 and 0.0 <= val[0]["val/mIoU"] <= 100.0 and np.isfinite(val[0]["val/loss"])
+    assert (tmp_path / "s" / "best.ckpt").exists()
+    with pytest.raises(ValueError, match="training_module"):
+        gin.bind_parameter("train.training_module", "PruningTraining")
+        train(save_path=str(tmp_path), resume_training=False, run_name="s", run_name_postfix=None, ME=OME)
+
+
 def test_gin_configurable_injection_rules():
     @gin.configurable
     def f(a, b=2, c=3):
