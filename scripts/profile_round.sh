@@ -12,7 +12,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
   rocprofv3 --pmc $pass -d $out/pmc_$name -o pmc --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/pmc_$name.log 2>&1 || exit 1
   echo "pass $name done"
 done
-python scripts/trace_summary.py $out/trace 13 60 > $out/trace_summary.txt
+python scripts/trace_summary.py $out/trace 0 60 > $out/trace_summary.txt
 python scripts/stream_busy.py $out/trace > $out/stream_busy.txt
 python scripts/pmc_summary.py $out/pmc.json $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_SQ_VALU_MFMA_BUSY_CYCLES > $out/pmc_summary.txt
 head -30 $out/stream_busy.txt; head -12 $out/pmc_summary.txt

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-queue busy time, union busy time and per-category kernel time per step from a rocprofv3
-kernel trace of bench.py (steps are delimited by the stem forward kernel)."""
+kernel trace of bench.py (training steps are delimited by the stem weight-gradient kernel, the last
+kernel of every backward pass; the forward-only phase that follows the timed region is left out)."""
 import collections, csv, glob, sys
 
 d = sys.argv[1]
@@ -9,7 +10,7 @@ rows = list(csv.DictReader(open(f)))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-marks = [r["s"] for r in rows if "gather_gemm2" in r["Kernel_Name"] and int(r["Grid_Size_X"]) // 256 > 6000]
+marks = [r["s"] for r in rows if "wgrad_stream_kernel" in r["Kernel_Name"]]
 n = min(8, len(marks) - 1)
 t0, t1 = marks[-1 - n], marks[-1]
 seg = [r for r in rows if t0 <= r["s"] < t1]

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 --kernel-trace CSV: per (kernel, grid) time per step."""
+"""Summarise a rocprofv3 --kernel-trace CSV: per (kernel, grid) time per step.
+usage: trace_summary.py <dir> <steps | 0 = count bench.py training steps> [top]"""
 import collections
 import csv
 import glob
@@ -8,6 +9,10 @@ import sys
 d, steps = sys.argv[1], int(sys.argv[2])
 f = (glob.glob(f"{d}/*/*kernel_trace.csv") + glob.glob(f"{d}/*kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
+ends = [int(r["End_Timestamp"]) for r in rows if "wgrad_stream_kernel" in r["Kernel_Name"]]
+if ends and steps == 0:  # bench.py trace: count the training steps and drop the forward-only phase after them
+    steps = len(ends)
+    rows = [r for r in rows if int(r["Start_Timestamp"]) <= max(ends)]
 agg = collections.defaultdict(list)
 for r in rows:
     name = r["Kernel_Name"].split("(")[0][:46]
