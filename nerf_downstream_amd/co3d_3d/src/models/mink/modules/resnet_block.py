@@ -43,14 +43,14 @@ class BasicBlock(nn.Module):
 
         cur = torch.cuda.current_stream(x.F.device)
         br = Fn.branch_stream(x.F.device, home=cur)
-        br.wait_stream(cur)
+        Fn.stream_wait(br, cur)
         Fn.skew(br)
         with torch.cuda.stream(br):
             shortcut = self.downsample(x)
         x.F.record_stream(br)
 
         def join():
-            cur.wait_stream(br)
+            Fn.stream_wait(cur, br)
             shortcut.F.record_stream(cur)
 
         return shortcut, join

@@ -34,13 +34,16 @@ def _bytes(nbytes, device):
 _SCRATCH = {}
 
 
-def _scratch(nbytes, device, slot):
-    stream = _stream()
+def _scratch(nbytes, device, slot, on=None):
+    """`on`: the torch stream the buffer will be used on when that is not the current one."""
+    stream = _stream() if on is None else on.cuda_stream
     key = (device.index, stream, slot)
     buf = _SCRATCH.get(key)
     nbytes = max(int(nbytes), 256)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=device)
+        if on is not None:  # allocated under the current stream, used on `on`: a later free must wait for that stream
+            buf.record_stream(on)
         _SCRATCH[key] = buf
     return buf
 
@@ -79,21 +82,32 @@ def kernel_timings():
 
 
 class _timed:
-    def __init__(self, tag, **meta):
-        self.tag, self.meta = tag, meta
+    def __init__(self, tag, stream=None, **meta):
+        self.tag, self.meta, self.stream = tag, meta, stream
 
     def __enter__(self):
         self.on = _TIMING is not None and (_TIMING_ONLY is None or _TIMING_ONLY == self.tag)
         if self.on:
             self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.s.record()
+            self.s.record(self.stream)  # None = the current stream; else the stream the kernel is launched on
 
     def __exit__(self, *exc):
         if self.on:
-            self.e.record()
+            self.e.record(self.stream)
             ent = _TIMING.setdefault(self.tag, {"events": [], "meta": self.meta})
             ent["events"].append((self.s, self.e))
             ent["meta"] = self.meta
+
+
+class _NoTimer:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_TIMER = _NoTimer()
 
 
 # ------------------------------------------------------------------------- convolution
@@ -109,11 +123,15 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, ro
     cin = x.shape[1]
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
     n_rows = n_out if row_perm is None else row_perm.numel()
-    ksplit = _FORCE_KSPLIT or int(L.mink_conv_plan_ksplit(n_rows, K, cout, int(row_perm is not None)))
+    ksplit = _FORCE_KSPLIT or _plan_ksplit(L, n_rows, K, cout, int(row_perm is not None))
     ws = _scratch(4 * ksplit * n_out * cout, x.device, "splitk") if ksplit > 1 else None
-    tag = f"{'dgrad' if w_transposed else 'fwd'}[{n_out}x{K}:{cin}->{cout}]"
     partial = None
-    with _timed(tag, kind="gather_gemm", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr, ksplit=ksplit):
+    if _TIMING is None:
+        timer = _NO_TIMER
+    else:
+        timer = _timed(f"{'dgrad' if w_transposed else 'fwd'}[{n_out}x{K}:{cin}->{cout}]", kind="gather_gemm", n_in=x.shape[0],
+                       n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr, ksplit=ksplit)
+    with timer:
         if stats and not w_transposed and row_perm is None and n_out > 0:
             partial = torch.empty(512, 2, cout, dtype=torch.float64, device=x.device)
             sws = _scratch(L.mink_conv_stats_workspace_bytes(n_out, cout), x.device, "convstats")
@@ -136,22 +154,61 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, ro
     return (y, partial) if stats else y
 
 
-def conv_wgrad(x, dy, nbr, kernel_shape, out=None):
+def conv_wgrad(x, dy, nbr, kernel_shape, out=None, on=None):
     """dW[k] = X[nbr[:, k]]^T dY.  `out`: write into this contiguous fp32 tensor (a slice of a
-    data-parallel reducer's flat gradient buffer) instead of a fresh one."""
+    data-parallel reducer's flat gradient buffer) instead of a fresh one.  `on`: launch on this torch
+    stream instead of the current one (the caller orders it and records the buffers it reads; a fresh
+    result tensor is recorded here) -- cheaper than switching the current stream around the call."""
     L = lib()
     n_out, K = nbr.shape
     cin, cout = x.shape[1], dy.shape[1]
-    dw = out if out is not None else torch.empty(kernel_shape, dtype=torch.float32, device=x.device)
-    ws = _scratch(L.mink_conv_wgrad_workspace_bytes(n_out, K, cin, cout), x.device, "wgrad")
-    with _timed(f"wgrad[{n_out}x{K}:{cin}->{cout}]", kind="wgrad", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr):
+    if out is not None:
+        dw = out
+    else:
+        dw = torch.empty(kernel_shape, dtype=torch.float32, device=x.device)
+        if on is not None:
+            dw.record_stream(on)
+    ws = _scratch(_wgrad_ws_bytes(L, n_out, K, cin, cout), x.device, "wgrad", on)
+    raw = _stream() if on is None else on.cuda_stream
+    if _TIMING is None:
         check(
             L.mink_conv_wgrad(
                 x.data_ptr(), x.shape[0], x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K,
-                dw.data_ptr(), ws.data_ptr(), _stream(),
+                dw.data_ptr(), ws.data_ptr(), raw,
+            )
+        )
+        return dw
+    with _timed(f"wgrad[{n_out}x{K}:{cin}->{cout}]", stream=on, kind="wgrad", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr):
+        check(
+            L.mink_conv_wgrad(
+                x.data_ptr(), x.shape[0], x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K,
+                dw.data_ptr(), ws.data_ptr(), raw,
             )
         )
     return dw
+
+
+_PLAN_CACHE = {}
+
+
+def _wgrad_ws_bytes(L, n_out, K, cin, cout):
+    key = ("wws", n_out, K, cin, cout)
+    v = _PLAN_CACHE.get(key)
+    if v is None:
+        if len(_PLAN_CACHE) > 4096:
+            _PLAN_CACHE.clear()
+        v = _PLAN_CACHE[key] = int(L.mink_conv_wgrad_workspace_bytes(n_out, K, cin, cout))
+    return v
+
+
+def _plan_ksplit(L, n_rows, K, cout, classes):
+    key = ("ks", n_rows, K, cout, classes)
+    v = _PLAN_CACHE.get(key)
+    if v is None:
+        if len(_PLAN_CACHE) > 4096:
+            _PLAN_CACHE.clear()
+        v = _PLAN_CACHE[key] = int(L.mink_conv_plan_ksplit(n_rows, K, cout, classes))
+    return v
 
 
 _OVERLAP_WGRAD = True  # weight gradients on a side stream, joined at the end of backward (B=16 ResNet14: 5.11 -> 4.84 ms/step)
@@ -201,6 +258,20 @@ def skew(stream):
             torch.cuda._sleep(_SKEW)
 
 
+_WAIT_EVENTS = {}
+
+
+def stream_wait(waiter, awaited):
+    """`waiter.wait_stream(awaited)` without creating a HIP event per call (9 us each on this stack, ~20 per
+    step): one cached event per awaited stream.  Re-recording it later does not disturb a wait already
+    queued -- a stream wait captures the record that precedes it."""
+    ev = _WAIT_EVENTS.get(awaited)
+    if ev is None:
+        ev = _WAIT_EVENTS[awaited] = torch.cuda.Event()
+    ev.record(awaited)
+    waiter.wait_event(ev)
+
+
 def side_stream_if_any(device):
     return _SIDE_STREAMS.get(device.index)
 
@@ -247,7 +318,7 @@ def _join_side_streams():
     if _DEFERRED["pending"]:
         _DEFERRED["pending"] = False
         for index, side in _SIDE_STREAMS.items():
-            torch.cuda.current_stream(index).wait_stream(side)
+            stream_wait(torch.cuda.current_stream(index), side)
 
 
 class ConvolutionFunction(torch.autograd.Function):
@@ -293,7 +364,7 @@ class ConvolutionFunction(torch.autograd.Function):
         side = _side_stream(gy.device) if (want_gx and want_gw and _OVERLAP_WGRAD) else None
         if side is not None:
             main = torch.cuda.current_stream()
-            side.wait_stream(main)  # gy / x are ready on the side stream
+            stream_wait(side, main)  # gy / x are ready on the side stream
             skew(side)
         if want_gx:
             # dgrad = the same gather-GEMM over the transposed map with W[k]^T (read in place)
@@ -306,10 +377,9 @@ class ConvolutionFunction(torch.autograd.Function):
             sink = _GRAD_SINK
             out = sink.view_for(w) if (sink is not None and w.shape[1] == ctx.cin) else None
             if side is not None:
-                with torch.cuda.stream(side):
-                    gw = conv_wgrad(x, gy, ctx.nbr, w.shape, out=out)
-                for t in (x, gy, ctx.nbr, gw):  # every buffer the side stream reads, and its output
-                    t.record_stream(side if t is not gw else main)
+                gw = conv_wgrad(x, gy, ctx.nbr, w.shape, out=out, on=side)  # (a fresh gw is recorded on the side stream there)
+                for t in (x, gy, ctx.nbr):  # every buffer the side stream reads
+                    t.record_stream(side)
                 if out is not None:  # written in place into the reducer's buffer: nothing for autograd to do
                     _DEFERRED["pending"] = True
                     if not _DEFERRED["callback"]:
@@ -335,7 +405,7 @@ class ConvolutionFunction(torch.autograd.Function):
                         _DEFERRED["callback"] = True
                         torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
                 else:
-                    main.wait_stream(side)
+                    stream_wait(main, side)
             else:
                 gw = conv_wgrad(x, gy, ctx.nbr, w.shape, out=out)
                 if out is not None:
