@@ -23,9 +23,14 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # one hardware queue for every stream of a rank (compute, prepare, weight-gradient + RCCL's two): the HIP default of 4
+    # makes two of them share one and serialise; read when the HIP runtime is loaded, i.e. before `import torch`
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 from nerf_downstream_amd import gin_lite as gin
 from nerf_downstream_amd.co3d_3d.src.data.data_module import DataModule

@@ -321,6 +321,23 @@ def _join_side_streams():
             stream_wait(torch.cuda.current_stream(index), side)
 
 
+def _sink_views(*params):
+    """Data parallelism: the slices of the reducer's flat buffer to write these parameters' gradients into --
+    all of them or none (then autograd accumulates as usual).  Saves one accumulate launch per parameter."""
+    sink = _GRAD_SINK
+    if sink is None:
+        return None
+    views = []
+    for p in params:
+        v = sink.view_for(p)
+        if v is None:
+            for q in params[: len(views)]:  # hand back what was claimed
+                sink.release(q)
+            return None
+        views.append(v)
+    return views
+
+
 class ConvolutionFunction(torch.autograd.Function):
     """MinkowskiConvolution forward/backward (reference modules/common.py:116-125; A6).
 
@@ -504,6 +521,7 @@ class BatchNormFunction(torch.autograd.Function):
             )
         ctx.save_for_backward(x, y if relu else None, mean, invstd, gamma)
         ctx.training, ctx.relu, ctx.has_res = training, relu, residual is not None
+        ctx.beta = beta  # only as the key of its gradient slot under data parallelism
         return y
 
     @staticmethod
@@ -520,8 +538,12 @@ class BatchNormFunction(torch.autograd.Function):
                     g if ctx.has_res else None, None, None)
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if ctx.has_res else None
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        views = _sink_views(gamma, ctx.beta) if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] else None
+        if views is not None:
+            dgamma, dbeta = views
+        else:
+            dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
         check(
             L.mink_bn_bwd(
@@ -529,6 +551,9 @@ class BatchNormFunction(torch.autograd.Function):
                 int(ctx.relu), gx.data_ptr(), _ptr(gres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(),
             )
         )
+        if views is not None:  # written in place into the reducer's buffer: nothing for autograd to accumulate
+            _GRAD_SINK.ready(gamma), _GRAD_SINK.ready(ctx.beta)
+            return gx, None, None, None, None, None, None, None, gres, None, None
         return gx, dgamma, dbeta, None, None, None, None, None, gres, None, None
 
 
@@ -681,6 +706,7 @@ class ConvBNReLUSumPoolFunction(torch.autograd.Function):
         )
         ctx.save_for_backward(x, w, y, mean, invstd, gamma, beta)
         ctx.nbr, ctx.in2out = nbr, in2out
+        ctx.kernel = kernel  # only as the key of its gradient slot under data parallelism
         return out
 
     @staticmethod
@@ -690,8 +716,15 @@ class ConvBNReLUSumPoolFunction(torch.autograd.Function):
         gy = _f32c(gy)
         n, C = y.shape
         dev = y.device
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad
+        pv = _sink_views(gamma, beta) if need[2] and need[3] else None  # data parallelism: write straight into the reducer's buffer
+        kv = _sink_views(ctx.kernel) if need[1] and w.shape[1] == ctx.cin else None
+        if pv is not None:
+            dgamma, dbeta = pv
+        else:
+            dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        gw = kv[0] if kv is not None else None
         ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
         check(
             L.mink_bn_relu_pool_bwd(
@@ -701,7 +734,8 @@ class ConvBNReLUSumPoolFunction(torch.autograd.Function):
         )
         nbr = ctx.nbr
         K = nbr.shape[1]
-        gw = torch.empty(w.shape, dtype=torch.float32, device=dev)
+        if gw is None:
+            gw = torch.empty(w.shape, dtype=torch.float32, device=dev)
         wws = _scratch(L.mink_conv_wgrad_workspace_bytes(n, K, x.shape[1], C), dev, "wgrad")
         with _timed(f"wgrad[{n}x{K}:{x.shape[1]}->{C}]", kind="wgrad", n_in=x.shape[0], n_out=n, K=K, cin=x.shape[1], cout=C, nbr=nbr):
             check(
@@ -711,7 +745,13 @@ class ConvBNReLUSumPoolFunction(torch.autograd.Function):
                     dgamma.data_ptr(), dbeta.data_ptr(), nbr.data_ptr(), n, K, gw.data_ptr(), wws.data_ptr(), _stream(),
                 )
             )
-        if gw.shape[1] != ctx.cin:
+        if pv is not None:
+            _GRAD_SINK.ready(gamma), _GRAD_SINK.ready(beta)
+            dgamma = dbeta = None
+        if kv is not None:
+            _GRAD_SINK.ready(ctx.kernel)
+            gw = None
+        elif gw.shape[1] != ctx.cin:
             gw = gw[:, : ctx.cin].contiguous()
         return None, gw, dgamma, dbeta, None, None, None, None, None, None, None
 

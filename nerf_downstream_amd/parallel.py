@@ -13,7 +13,8 @@ per-rank BatchNorm statistics, mean of gradients across ranks once per step.  He
 * a post-accumulate-grad hook counts ready parameters per bucket and launches the bucket's
   `all_reduce(async_op=True)` as soon as it is complete -- RCCL runs it on its own HIP stream,
   overlapped with the remaining backward kernels;
-* `finish()` waits for all buckets and scales by 1/world (mean), before the optimizer step.
+* `finish()` waits for all buckets (RCCL averages inside the collective; with gloo the sum is scaled by
+  1/world here), before the optimizer step.
 """
 import os
 
@@ -22,8 +23,11 @@ import torch.distributed as dist
 
 
 class BucketedGradAllReduce:
-    def __init__(self, module, bucket_bytes=8 << 20, process_group=None):
+    def __init__(self, module, bucket_bytes=8 << 20, process_group=None, force=False):
+        """`force`: run the whole machinery (hooks, gradient sink, collectives) in a one-rank group too -- for measuring
+        its overhead on a single GPU (bench.py BENCH_FORCE_REDUCER=1)."""
         self.group = process_group
+        self.force = bool(force)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if self.world > 1 and dist.get_backend(process_group) == "gloo":
             # gloo (CPU rehearsals / tests) stalls on 32 MiB device tensors; RCCL wants them large
@@ -50,7 +54,7 @@ class BucketedGradAllReduce:
         self._work = []
         self._hooks = []
         self._home = None  # the stream the step runs on (captured in zero_grad)
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             if dev.type == "cuda":
@@ -60,9 +64,17 @@ class BucketedGradAllReduce:
                     Fn.set_wgrad_overlap(False)
                     Fn.set_branch_fork(False)
                 else:
+                    # the shortcut-branch stream stays off under data parallelism: with the process group's streams
+                    # in the picture it gains nothing (4.85 ms/step either way with six hardware queues) and, given
+                    # eight or more queues, costs a factor (8.3 ms; scripts/hostprof_dp.py)
+                    Fn.set_branch_fork(False)
                     # convolution weight gradients are written straight into the flat buffer by the
-                    # weight-gradient stream (no per-layer accumulate + join on the compute stream)
+                    # weight-gradient stream (no per-layer accumulate + join on the compute stream), batch-norm
+                    # scale / shift gradients by their backward kernel (no accumulate launch per parameter)
                     Fn.set_grad_sink(self)
+        # RCCL averages inside the collective; gloo (CPU tests, rehearsals) sums and finish() scales
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._written = set()  # parameters whose gradient was written in place this step
         self._counted = set()  # parameters already counted towards their bucket this step
 
@@ -70,7 +82,7 @@ class BucketedGradAllReduce:
     def view_for(self, p):
         """The slice of the flat buffer to write the gradient of `p` into -- once per step (a second
         gradient of the same parameter in one step must ADD, which autograd's accumulate does)."""
-        if self.world == 1 or p not in self._bucket_of or p in self._written or p.grad is None:
+        if (self.world == 1 and not self.force) or p not in self._bucket_of or p in self._written or p.grad is None:
             return None
         g = p.grad
         lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
@@ -78,6 +90,10 @@ class BucketedGradAllReduce:
             return None  # somebody replaced .grad: fall back to autograd
         self._written.add(p)
         return g
+
+    def release(self, p):
+        """Undo a `view_for(p)` whose slice will not be written after all."""
+        self._written.discard(p)
 
     def ready(self, p):
         self._on_grad(p)
@@ -96,13 +112,15 @@ class BucketedGradAllReduce:
             cur = torch.cuda.current_stream(dev)
             side = Fn.side_stream_if_any(dev)
             launch_from = side if side is not None else cur
+            seen = {launch_from}
             for st in [self._home, cur] + Fn.compute_streams(dev):
-                if st is not None and st != launch_from:
-                    launch_from.wait_stream(st)
+                if st is not None and st not in seen:
+                    seen.add(st)
+                    Fn.stream_wait(launch_from, st)
             with torch.cuda.stream(launch_from):
-                self._work.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._work.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
             return
-        self._work.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._work.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
 
     def _on_grad(self, p):
         if p in self._counted:  # a gradient written in place is reported by the kernel launcher AND (on
@@ -120,7 +138,8 @@ class BucketedGradAllReduce:
             from .minkowski import functional as Fn
 
             for st in Fn.compute_streams(self.flat.device):  # last step's collectives / writes on the side streams
-                self._home.wait_stream(st)
+                if st != self._home:
+                    Fn.stream_wait(self._home, st)
         self.flat.zero_()
         self._written.clear()
         self._counted.clear()
@@ -130,7 +149,7 @@ class BucketedGradAllReduce:
     def finish(self):
         """Wait for the outstanding collectives (launching any bucket whose parameters did not
         all receive a gradient this step), then turn the sum into the mean."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         for b in range(len(self.buckets)):
             if not self._launched[b]:
@@ -138,4 +157,5 @@ class BucketedGradAllReduce:
         for w in self._work:
             w.wait()
         self._work.clear()
-        self.flat.mul_(1.0 / self.world)
+        if not self._avg:
+            self.flat.mul_(1.0 / self.world)
