@@ -229,12 +229,14 @@ def set_wgrad_overlap(on=True):
 
 
 _GRAD_SINK = None  # a data-parallel reducer that owns the gradient memory (see set_grad_sink)
+_FLUSH_ROWS = 32768  # a convolution backward over at least this many rows keeps the GPU busy for >100 us
 
 
 def set_grad_sink(sink):
     """`sink.view_for(param)` -> the tensor the weight gradient of `param` is to be WRITTEN into (or
     None: hand the gradient to autograd as usual); `sink.ready(param)` is called once that write
-    has been queued.  This lets a bucketed all-reduce keep the weight-gradient side stream: without
+    has been queued, `sink.release(param)` if it will not be after all, `sink.flush()` where the host has
+    time to spare (a large layer's kernels have just been queued).  This lets a bucketed all-reduce keep the weight-gradient side stream: without
     it every gradient would have to be accumulated into the reducer's buffer on the compute stream,
     i.e. joined layer by layer."""
     global _GRAD_SINK
@@ -403,6 +405,8 @@ class ConvolutionFunction(torch.autograd.Function):
                         _DEFERRED["callback"] = True
                         torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
                     sink.ready(w)
+                    if gy.shape[0] >= _FLUSH_ROWS:  # the GPU now has long kernels queued: the host has time to launch collectives
+                        sink.flush()
                     return gx, None, None, None, None
                 # Nothing reads gw before backward ends when autograd merely installs it as
                 # w.grad: then the join is deferred to the end-of-backward callback and the
@@ -745,6 +749,8 @@ class ConvBNReLUSumPoolFunction(torch.autograd.Function):
                     dgamma.data_ptr(), dbeta.data_ptr(), nbr.data_ptr(), n, K, gw.data_ptr(), wws.data_ptr(), _stream(),
                 )
             )
+        if _GRAD_SINK is not None and hasattr(_GRAD_SINK, "flush"):
+            _GRAD_SINK.flush()  # the stem's weight gradient (0.9 ms) is queued: everything completed so far goes out beside it
         if pv is not None:
             _GRAD_SINK.ready(gamma), _GRAD_SINK.ready(beta)
             dgamma = dbeta = None

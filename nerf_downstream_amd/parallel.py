@@ -33,16 +33,23 @@ class BucketedGradAllReduce:
             # gloo (CPU rehearsals / tests) stalls on 32 MiB device tensors; RCCL wants them large
             bucket_bytes = min(bucket_bytes, 8 << 20)
         params = [p for p in module.parameters() if p.requires_grad][::-1]
-        total = sum(p.numel() for p in params)
+        # every slice starts on a 256-byte boundary: the fused optimizer kernel only takes its 16-byte path when
+        # all the pointers of a tensor are aligned (unaligned views cost it 3x: 149 us against 50 per step)
+        ALIGN = 64
+        total = sum(-(-p.numel() // ALIGN) * ALIGN for p in params)
         dev = params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.buckets = []  # (start, end, n_params)
         self._bucket_of = {}
         off, bstart, bcount = 0, 0, 0
+        self._views = {}  # id(param) -> its .grad view (identity-checked in view_for)
+        self._params = params  # keeps the ids alive
         for p in params:
             p.grad = self.flat[off : off + p.numel()].view_as(p)
-            self._bucket_of[p] = len(self.buckets)
-            off += p.numel()
+            self._views[id(p)] = p.grad
+            self._bucket_of[id(p)] = len(self.buckets)  # keyed by id: Tensor.__hash__ is a Python-level call (~1 us) and
+            # the per-step path would make half a dozen of them per parameter
+            off += -(-p.numel() // ALIGN) * ALIGN
             bcount += 1
             if (off - bstart) * 4 >= bucket_bytes:
                 self.buckets.append((bstart, off, bcount))
@@ -72,9 +79,13 @@ class BucketedGradAllReduce:
                     # weight-gradient stream (no per-layer accumulate + join on the compute stream), batch-norm
                     # scale / shift gradients by their backward kernel (no accumulate launch per parameter)
                     Fn.set_grad_sink(self)
+                    self.defer = os.environ.get("MINK_DP_DEFER_LAUNCH", "1") != "0"
         # RCCL averages inside the collective; gloo (CPU tests, rehearsals) sums and finish() scales
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._active = self.world > 1 or self.force
+        self.defer = False  # set with the gradient sink: complete buckets wait for flush() / finish()
+        self._pending = []
         self._written = set()  # parameters whose gradient was written in place this step
         self._counted = set()  # parameters already counted towards their bucket this step
 
@@ -82,18 +93,20 @@ class BucketedGradAllReduce:
     def view_for(self, p):
         """The slice of the flat buffer to write the gradient of `p` into -- once per step (a second
         gradient of the same parameter in one step must ADD, which autograd's accumulate does)."""
-        if (self.world == 1 and not self.force) or p not in self._bucket_of or p in self._written or p.grad is None:
-            return None
-        g = p.grad
-        lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
-        if not (g.is_contiguous() and lo <= g.data_ptr() < hi):
-            return None  # somebody replaced .grad: fall back to autograd
-        self._written.add(p)
+        k = id(p)
+        g = self._views.get(k)
+        if g is None or not self._active or k in self._written or p.grad is not g:
+            return None  # not ours / second gradient this step / somebody replaced .grad: fall back to autograd
+        self._written.add(k)
         return g
+
+    def gradients(self):
+        """The parameter gradients in buffer order (reverse registration order) without the alignment padding."""
+        return torch.cat([p.grad.flatten() for p in self._params])
 
     def release(self, p):
         """Undo a `view_for(p)` whose slice will not be written after all."""
-        self._written.discard(p)
+        self._written.discard(id(p))
 
     def ready(self, p):
         self._on_grad(p)
@@ -123,13 +136,27 @@ class BucketedGradAllReduce:
         self._work.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
 
     def _on_grad(self, p):
-        if p in self._counted:  # a gradient written in place is reported by the kernel launcher AND (on
+        k = id(p)
+        if k in self._counted:  # a gradient written in place is reported by the kernel launcher AND (on
             return              # some torch versions) by the post-accumulate hook of the undefined grad
-        self._counted.add(p)
-        b = self._bucket_of[p]
+        self._counted.add(k)
+        b = self._bucket_of[k]
         self._ready[b] += 1
         if self._ready[b] == self.buckets[b][2] and not self._launched[b]:
-            self._launch(b)
+            if self.defer:
+                self._pending.append(b)
+            else:
+                self._launch(b)
+
+    def flush(self):
+        """Launch the collectives of the buckets completed so far.  With `defer` (gradient-sink mode) a complete
+        bucket is not launched from inside the backward of the small deep layers -- there the host is what the
+        GPU waits for, and a launch costs it 60 us -- but at the first point where the GPU has a long kernel
+        queued (the convolution backward calls this after queuing the kernels of a large layer)."""
+        pending, self._pending = self._pending, []
+        for b in pending:
+            if not self._launched[b]:
+                self._launch(b)
 
     def zero_grad(self):
         """Gradients accumulate into the flat buffer; clear it with one memset per step."""
@@ -143,6 +170,7 @@ class BucketedGradAllReduce:
         self.flat.zero_()
         self._written.clear()
         self._counted.clear()
+        self._pending.clear()
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
 
@@ -151,6 +179,7 @@ class BucketedGradAllReduce:
         all receive a gradient this step), then turn the sum into the mean."""
         if self.world == 1 and not self.force:
             return
+        self.flush()
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)

@@ -89,11 +89,15 @@ def test_flat_buffer_layout_single_process():
     m = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Linear(8, 2))
     red = BucketedGradAllReduce(m, bucket_bytes=64)
     params = list(m.parameters())
-    assert red.flat.numel() == sum(p.numel() for p in params)
+    # every slice starts on a 256-byte boundary (the fused optimizer kernel needs aligned pointers for its 16-byte path)
+    assert red.flat.numel() == sum(-(-p.numel() // 64) * 64 for p in params) == 4 * 64
+    assert all((p.grad.data_ptr() - red.flat.data_ptr()) % 256 == 0 for p in params)
     # reverse registration order: the last layer's gradients (ready first in backward) come first
     assert params[-1].grad.data_ptr() == red.flat.data_ptr()
     m(torch.randn(3, 4)).sum().backward()
     red.finish()  # world 1: no-op
-    assert torch.equal(params[0].grad.flatten(), red.flat[-params[0].numel():])
+    assert torch.equal(params[0].grad.flatten(), red.flat[3 * 64 : 3 * 64 + params[0].numel()])
+    assert torch.equal(red.gradients(), torch.cat([p.grad.flatten() for p in params[::-1]]))
+    assert float(red.flat.abs().sum()) == float(red.gradients().abs().sum())  # the padding stays zero
     red.zero_grad()
     assert float(red.flat.abs().sum()) == 0.0

@@ -152,7 +152,7 @@ def _dp_worker(rank, world, port, out):
     launched = all(red._launched)
     red.finish()
     torch.cuda.synchronize()
-    torch.save({"g": red.flat.cpu(), "launched": launched}, f"{out}/r{rank}.pt")
+    torch.save({"g": red.gradients().cpu(), "launched": launched}, f"{out}/r{rank}.pt")
     # single-rank reference gradients of this rank's batch (fresh model, same seed)
     torch.manual_seed(3)
     m2 = get_model("ResNet14", 28, 5).to(dev)
