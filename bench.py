@@ -143,8 +143,8 @@ def roofline_from_timings(timings):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="scenes per GPU (co3d_cls.gin: train.batch_size = 16)")
     ap.add_argument("--model", default="ResNet14")
     ap.add_argument("--grid", type=int, default=128)
