@@ -8,7 +8,7 @@
 namespace mink {
 
 constexpr int EB = 256;
-constexpr int kRedBlocks = 512;  // workgroups of the column reductions (2 per CU)
+constexpr int kRedBlocks = 2048;  // workgroups of the column reductions (8 per CU: the passes are latency-bound)
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
