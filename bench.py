@@ -52,34 +52,61 @@ def make_batches(n_batches, batch, rank, num_classes, grid, cin):
     return out
 
 
-def cpu_baseline(model_name, cin, num_classes, grid, state_dict, seconds_budget=25.0):
-    """Times the CPU oracle (oracle/me_cpu.py + oracle/mink_maps.c: sequential hash insert, per
-    offset gather -> SGEMM -> scatter-add, torch BatchNorm1d) on a bounded sample: full
-    fwd+bwd steps of 2-scene batches (BASELINE config #0) until ~seconds_budget is spent."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(model_name, cin, num_classes, grid, state_dict, seconds_budget=24.0):
+    """Times the CPU oracle (oracle/me_cpu.py + oracle/mink_maps.c: sequential hash insert, OpenMP kernel-map
+    search, per offset gather -> SGEMM -> scatter-add, torch BatchNorm1d) on a bounded sample: full fwd+bwd steps
+    of 2-scene batches (BASELINE config #0), once with every host core and once with OMP_NUM_THREADS=12 (the
+    reference's own job script, sbatch.sh:34), ~seconds_budget/2 each.  `value` is the all-cores figure."""
     from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from oracle import maps as omaps
     from oracle import me_cpu as OME
 
     ref = get_model(model_name, cin, num_classes, ME=OME)
     ref.load_state_dict(state_dict)
-    batches = make_batches(1, 2, 977, num_classes, grid, cin)
-    vox, t_total, steps = 0, 0.0, 0
-    while t_total < seconds_budget and steps < 8:
-        b = batches[0]
-        t0 = time.perf_counter()
-        out = ref(ref.process_input(b))
-        loss = F.cross_entropy(out, b["labels"].long())
-        loss.backward()
-        t_total += time.perf_counter() - t0
-        vox += b["coordinates"].shape[0]
-        steps += 1
-        ref.zero_grad(set_to_none=True)
+    b = make_batches(1, 2, 977, num_classes, grid, cin)[0]
+    nproc = os.cpu_count() or 1
+    all_threads = torch.get_num_threads()
+
+    def run(threads, budget):
+        torch.set_num_threads(threads)
+        omaps.set_threads(threads)
+        vox, t_total, steps = 0, 0.0, 0
+        while t_total < budget and steps < 8:
+            t0 = time.perf_counter()
+            out = ref(ref.process_input(b))
+            loss = F.cross_entropy(out, b["labels"].long())
+            loss.backward()
+            t_total += time.perf_counter() - t0
+            vox += b["coordinates"].shape[0]
+            steps += 1
+            ref.zero_grad(set_to_none=True)
+        return vox / t_total, steps, t_total
+
+    v_all, steps_all, t_all = run(all_threads, seconds_budget / 2)
+    v_12, steps_12, t_12 = run(min(12, nproc), seconds_budget / 2)
+    torch.set_num_threads(all_threads)
+    omaps.set_threads(all_threads)
     return {
-        "value": vox / t_total,
+        "value": v_all,
         "unit": "voxels/s",
-        "cores": torch.get_num_threads(),
+        "cores": all_threads,
         "kind": "port",
-        "sample": f"{steps} fwd+bwd steps of {model_name} on 2-scene batches ({vox // max(steps,1)} voxels/step), "
-        f"CPU restatement of the ME CPU algorithm (ME binary unavailable), {t_total:.1f} s",
+        "sample": f"{steps_all} fwd+bwd steps of {model_name} on 2-scene batches ({b['coordinates'].shape[0]} voxels/step), "
+        f"CPU restatement of the ME CPU algorithm (ME binary unavailable), {t_all:.1f} s",
+        "cpu_model": _cpu_model(),
+        "nproc": nproc,
+        "omp12": {"value": v_12, "cores": min(12, nproc), "steps": steps_12, "seconds": round(t_12, 1),
+                  "note": "OMP_NUM_THREADS=12 as in the reference's job script (sbatch.sh:34)"},
     }
 
 
@@ -152,6 +179,8 @@ def main():
     ap.add_argument("--num-classes", type=int, default=51)
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="matrix-core arithmetic of conv forward/dgrad (fp32 = exact, the headline; bf16 = BASELINE config #3)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch plumbing only (CPU test): rendezvous over gloo, one all-reduce, print ranks_seen; no compute, no number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -161,11 +190,35 @@ def main():
         faulthandler.enable()  # also on a GPU fault (SIGABRT): which launch was the host at
         faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU as a CHILD job and hand its exit code back
+        # (nothing in this process has touched the GPU yet; a process that has must never exec another program).  The
+        # ranks inherit stdout, so rank 0's JSON line is this command's JSON line.  Same launch as the reference's
+        # Trainer(accelerator="gpu", devices=gpus, strategy=DDP) (co3d_3d/train.py:174-186) and as co3d_3d/train.py here.
+        import subprocess
+
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29537"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
+    if args.dry_run:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "ranks_seen": dist.get_world_size() if world > 1 else 1,
+                              "rank_sum": t.item()}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     # rehearsal hooks (single-GPU box): BENCH_DEVICE pins every rank to one card and
     # BENCH_DIST_BACKEND=gloo replaces RCCL, so the N>1 code path can be exercised without a node
     dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
@@ -182,6 +235,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    collective_desc = "none (one rank)"
+    if dist.is_initialized():
+        collective_desc = f"{dist.get_backend()} all-reduce of gradients, bucketed, overlapped with backward"
+        if dist.get_backend() == "nccl":  # on ROCm the "nccl" backend IS RCCL
+            collective_desc += " (RCCL %s)" % ".".join(str(v) for v in torch.cuda.nccl.version())
 
     from nerf_downstream_amd import _lib
     from nerf_downstream_amd.co3d_3d.src.models import get_model
@@ -235,13 +294,6 @@ def main():
 
     # warm-up: every conv kernel is event-timed to find the dominant one; the timed region then
     # instruments only that kernel (one event pair per step) so the measurement is not perturbed.
-    # One-time initialisation that is not steady-state work is kept out of the W warm-up steps when W is small:
-    # lazy loading of every kernel's code object, growth of the caching allocator's pools for both batch shapes,
-    # the coordinate-map plan compiled from the first forward's trace (used from the third step on).  An even
-    # number, so the two alternating batches stay aligned with the step index.
-    priming = 0 if args.warmup >= 6 else 6
-    for i in range(priming):
-        step(i)
     if not args.no_kernel_timing:
         Fn.enable_kernel_timing(True)
     for i in range(args.warmup):
@@ -264,7 +316,6 @@ def main():
             # the kernel with the longest typical launch (median: the first launches of a process run long)
             med = {t: sorted(s.elapsed_time(e) for s, e in v["events"])[len(v["events"]) // 2] for t, v in warm.items() if v["events"]}
             dominant = max(med, key=med.get)
-            conv_share = tot[dominant] / sum(tot.values())
         Fn.enable_kernel_timing(dominant is not None, only=dominant)
     # The warmed-up model / optimizer / map plans are permanent: move them out of the cyclic
     # collector's reach so its periodic full collections stop re-traversing them (measured: 0.45 ms
@@ -315,13 +366,13 @@ def main():
                 "global_batch": args.batch * world,
                 "voxels_per_step_per_gpu": vox_per_step[0],
                 "parallelism": f"dp{world}",
-                "untimed_priming_steps_before_warmup": priming,
+                "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+                "collective": collective_desc,
                 "final_loss": loss_val,
             },
         }
         if timings:
             res["roofline"] = roofline_from_timings(timings)
-            res["roofline"]["share_of_conv_kernel_time_in_warmup"] = conv_share
         if world == 1:
             # forward only (north_star: "fraction of HBM roofline on the sparse-conv forward"): the network
             # forward on an already prepared batch, training-mode batch norm, no autograd graph

@@ -311,6 +311,14 @@ int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32
  * mode 2: y = a + b. */
 int mink_eltwise(const float *a, const float *b, int64_t count, int32_t mode, float *y, void *stream);
 
+/* Pointwise activations beyond ReLU -- ME.MinkowskiLeakyReLU / ELU / CELU / SELU / GELU / PReLU, which the reference's
+ * layer factory lists at import time (co3d_3d/src/models/mink/modules/common.py:36-43) and MinkowskiFunctional mirrors
+ * (:56-71).  kind: 1 leaky-ReLU (alpha = negative slope), 2 ELU(alpha), 3 CELU(alpha), 4 SELU, 5 GELU (erf form),
+ * 6 PReLU (`slope`: C per-channel weights, or one shared weight when C == 1; channels are the fastest axis).
+ * gy == NULL: out = f(x) over `count` elements; otherwise out = gy * f'(x). */
+int mink_activation(const float *x, const float *gy, const float *slope, int32_t C, int64_t count, int32_t kind,
+                    float alpha, float *out, void *stream);
+
 /* ------------------------------------------------------------------ dataset front-end
  * PeRFception-CO3D `data.npz` batch on the device (reference co3d.py:160-166 de-quantisation,
  * :196-205 links -> coordinates and feature selection): `links[n]` flat indices x*ry*rz + y*rz + z,

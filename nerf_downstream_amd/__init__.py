@@ -15,4 +15,6 @@ def install_as_minkowski_engine():
     from . import minkowski
 
     sys.modules.setdefault("MinkowskiEngine", minkowski)
+    for sub in ("MinkowskiFunctional", "MinkowskiOps", "utils"):  # `import MinkowskiEngine.MinkowskiFunctional as MEF`
+        sys.modules.setdefault("MinkowskiEngine." + sub, getattr(minkowski, sub))
     return minkowski

@@ -81,6 +81,7 @@ SIGNATURES = {
     "mink_bn_relu_pool_fwd": (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
     "mink_bn_relu_pool_bwd": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mink_eltwise": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
+    "mink_activation": (ctypes.c_int, [_p, _p, _p, _i32, _i64, _i32, _f32, _p, _p]),
 }
 
 

@@ -99,6 +99,25 @@ class Co3DDatasetBase(Dataset):
                                    "labels": np.array([self.CLASS_LABELS.index(label)]),
                                    "feature_names": tuple(self.features)})
 
+    def sample_lengths(self):
+        """Voxel count of every scene, read from the `links` array header inside each data.npz (no array data is
+        loaded): what the length-aware data-parallel sampler balances (data_module.py).  None if a scene is missing."""
+        import zipfile
+
+        if getattr(self, "_lengths", None) is None:
+            out = np.zeros(len(self.files), dtype=np.int64)
+            for i, (_, inst_id) in enumerate(self.files):
+                path = os.path.join(self.data_root, f"plenoxel_co3d_{inst_id}", "data.npz")
+                try:
+                    with zipfile.ZipFile(path) as z, z.open("links.npy") as f:
+                        version = np.lib.format.read_magic(f)
+                        shape = (np.lib.format.read_array_header_1_0 if version == (1, 0) else np.lib.format.read_array_header_2_0)(f)[0]
+                    out[i] = int(shape[0])
+                except (OSError, KeyError, ValueError):
+                    return None
+            self._lengths = out
+        return self._lengths
+
     def _with_program(self, sample):
         if self.transformations is not None:  # drawn here (DataLoader worker), applied on the GPU
             params, stream = self.transformations.sample()

@@ -3,12 +3,56 @@
 Per-rank batch = `batch_size` (reference semantics: the DataLoader is built with
 batch_size=self.batch_size and Lightning adds a DistributedSampler), so the global batch is
 batch_size x world."""
+import numpy as np
 import torch
-from torch.utils.data import DataLoader
+from torch.utils.data import DataLoader, Sampler
 from torch.utils.data.distributed import DistributedSampler
 
 from .datasets import get_dataset
 from .utils import collate_mink
+
+
+class LengthBalancedDistributedSampler(Sampler):
+    """DistributedSampler with length-aware placement (variable voxel counts per scene are the main
+    data-parallel scaling hazard -- every step waits for the rank with the heaviest batch).
+
+    Each global step still consumes the SAME set of `world x batch` samples a `DistributedSampler` with this seed would
+    hand out (consecutive chunks of the epoch's permutation), so the averaged gradient of a step is unchanged; only
+    which rank gets which scene differs: within a chunk, scenes are dealt longest first to the rank with the
+    smallest voxel total that still has a free slot (LPT), which bounds a step's imbalance by one scene instead of
+    letting it grow with the batch size.  Every rank computes the same assignment from the shared seed."""
+
+    def __init__(self, lengths, batch_size, world_size, rank, seed=0):
+        self.lengths = np.asarray(lengths, dtype=np.int64)
+        self.batch_size, self.world, self.rank, self.seed, self.epoch = int(batch_size), int(world_size), int(rank), int(seed), 0
+        self.chunk = self.batch_size * self.world
+        self.num_chunks = len(self.lengths) // self.chunk  # drop_last, like the training loader
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return self.num_chunks * self.batch_size
+
+    @staticmethod
+    def assign(lengths, world, batch_size):
+        """LPT with a slot limit: positions of `lengths` (one chunk) per rank, each list in dealing order."""
+        order = np.argsort(-np.asarray(lengths, dtype=np.int64), kind="stable")
+        load, slots = [0] * world, [[] for _ in range(world)]
+        for i in order:
+            r = min((q for q in range(world) if len(slots[q]) < batch_size), key=lambda q: (load[q], q))
+            slots[r].append(int(i))
+            load[r] += int(lengths[i])
+        return slots
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.seed + self.epoch)
+        perm = torch.randperm(len(self.lengths), generator=g).numpy()
+        for c in range(self.num_chunks):
+            idx = perm[c * self.chunk : (c + 1) * self.chunk]
+            mine = self.assign(self.lengths[idx], self.world, self.batch_size)[self.rank]
+            yield from (int(idx[j]) for j in mine)
 
 
 class DataModule:
@@ -25,7 +69,11 @@ class DataModule:
     def _loader(self, ds, batch_size, workers, shuffle):
         sampler = None
         if self.world_size > 1:
-            sampler = DistributedSampler(ds, self.world_size, self.rank, shuffle=shuffle, seed=self.seed, drop_last=shuffle)
+            lengths = ds.sample_lengths() if shuffle and hasattr(ds, "sample_lengths") else None
+            if lengths is not None and len(lengths) >= batch_size * self.world_size:
+                sampler = LengthBalancedDistributedSampler(lengths, batch_size, self.world_size, self.rank, seed=self.seed)
+            else:
+                sampler = DistributedSampler(ds, self.world_size, self.rank, shuffle=shuffle, seed=self.seed, drop_last=shuffle)
         g = torch.Generator()
         g.manual_seed(self.seed)
         return DataLoader(ds, batch_size=batch_size, num_workers=workers, collate_fn=self.collate_fn,

@@ -26,7 +26,11 @@ def _class_sh_mean(label, num_classes):
     return rng.normal(0.0, 0.6, 27).astype(np.float32)
 
 
-def make_scene(index, split=0, num_classes=51, grid=128, box_for_odd=False):
+def make_scene(index, split=0, num_classes=51, grid=128, box_for_odd=False, class_sep=1.0, scene_sigma=0.0):
+    """`class_sep` scales the class-dependent SH mean and `scene_sigma` adds a per-scene offset N(0, scene_sigma^2) to
+    it (one draw per scene and SH channel, from a generator of its own so the other draws do not move): with a small
+    separation and a comparable scene offset the classes overlap and top-1 cannot saturate -- the fixed-split parity
+    test (tests/test_gpu_parity_full.py) needs an accuracy that can actually differ between two implementations."""
     rng = np.random.default_rng(1_000_003 * split + index)
     label = index % num_classes
     g = np.arange(grid, dtype=np.float32)
@@ -46,14 +50,17 @@ def make_scene(index, split=0, num_classes=51, grid=128, box_for_odd=False):
     xyz = np.stack(np.nonzero(occ), 1).astype(np.float32)  # sorted by (x,y,z) like `links`
     n = xyz.shape[0]
     density = rng.lognormal(0.0, 1.0, (n, 1)).astype(np.float32)
-    sh = (_class_sh_mean(label, num_classes) + rng.normal(0.0, 0.5, (n, 27))).astype(np.float32)
+    mean = _class_sh_mean(label, num_classes) * np.float32(class_sep)
+    if scene_sigma:
+        mean = mean + np.random.default_rng(5_000_011 * (split + 1) + index).normal(0.0, scene_sigma, 27).astype(np.float32)
+    sh = (mean + rng.normal(0.0, 0.5, (n, 27))).astype(np.float32)
     return xyz, density, sh, label
 
 
 @gin.configurable
 class SparseVoxelDataset(Dataset):
     def __init__(self, phase="train", num_samples=512, num_classes=51, grid=128, features=("density", "sh"),
-                 box_for_odd=False, train_transformations=()):
+                 box_for_odd=False, train_transformations=(), class_sep=1.0, scene_sigma=0.0):
         """`train_transformations`: names of data/transforms.py classes, drawn per scene for the training split
         and applied on the GPU (like Co3DDatasetBase)."""
         from . import transforms
@@ -64,12 +71,14 @@ class SparseVoxelDataset(Dataset):
         self.num_samples = num_samples if self.split == 0 else max(1, num_samples // 4)
         self.num_classes, self.grid, self.features, self.box_for_odd = num_classes, grid, list(features), box_for_odd
         self.NUM_CLASSES = num_classes
+        self.class_sep, self.scene_sigma = float(class_sep), float(scene_sigma)
 
     def __len__(self):
         return self.num_samples
 
     def __getitem__(self, index):
-        xyz, density, sh, label = make_scene(index, self.split, self.num_classes, self.grid, self.box_for_odd)
+        xyz, density, sh, label = make_scene(index, self.split, self.num_classes, self.grid, self.box_for_odd,
+                                             self.class_sep, self.scene_sigma)
         coordinates = torch.from_numpy(xyz)
         # per-point mean over (x,y,z), as the reference does (co3d.py:211)
         xyzs = coordinates - coordinates.mean(dim=1, keepdim=True)

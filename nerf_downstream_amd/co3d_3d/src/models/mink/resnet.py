@@ -8,7 +8,7 @@ co3d_3d/src/models/mink/resnet.py:25-192).  Topology, tensor strides and paramet
 
 State-dict keys: conv1.kernel, bn1.bn.*, layer{i}.{j}.{conv1,conv2}.kernel,
 layer{i}.{j}.{norm1,norm2}.bn.*, layer{i}.0.downsample.{0.kernel,1.bn.*}, final.{kernel,bias}.
-Bottleneck variants (ResNet50/101) are out of scope (not in BASELINE configs)."""
+ResNet50/101 use the Bottleneck block (conv1/conv3 1x1x1, conv2 3x3x3 carrying the stride; expansion 4)."""
 import torch
 import torch.nn as nn
 
@@ -74,8 +74,10 @@ class ResNetBase(MinkowskiBaseModel):
         return nn.Sequential(*seq)
 
     def forward(self, x):
-        if self.training and self._norms:
-            torch._foreach_add_([m.bn.num_batches_tracked for m in self._norms], 1)
+        if self.training and self._norms:  # (a norm the user has put in eval() keeps its count, as torch's does)
+            counters = [m.bn.num_batches_tracked for m in self._norms if m.bn.training and m.bn.track_running_stats]
+            if counters:
+                torch._foreach_add_(counters, 1)
         if self._fused:  # bn1 -> relu -> pool in one pass over the finest-level activation; its
             # statistics come out of the stem convolution's epilogue (no extra pass over 825 k x 64)
             # -- and, in training, conv1 + bn1 + relu + pool are one autograd node (the input needs no

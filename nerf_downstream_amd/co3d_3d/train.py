@@ -46,18 +46,32 @@ logger = logging.getLogger(__name__)
 
 
 class CSVLogger:
-    def __init__(self, save_path, run_name):
+    """metrics.csv of the run: one line appended per log call (the file is rewritten only when a new metric name
+    widens the header); an existing file -- a run being resumed -- is continued, not overwritten."""
+
+    def __init__(self, save_path, run_name, resume=False):
         self.dir = os.path.join(save_path, run_name)
         os.makedirs(self.dir, exist_ok=True)
         self.path = os.path.join(self.dir, "metrics.csv")
-        self.rows = []
+        self.rows, self.keys = [], []
+        if resume and os.path.exists(self.path):
+            with open(self.path, newline="") as f:
+                rd = csv.DictReader(f)
+                self.keys = list(rd.fieldnames or [])
+                self.rows = [{k: v for k, v in r.items() if v != ""} for r in rd]
+        elif os.path.exists(self.path):
+            os.remove(self.path)
 
     def log_dict(self, metrics, step):
         row = {"global_step": step, **{k: (float(v) if hasattr(v, "__float__") else v) for k, v in metrics.items()}}
         self.rows.append(row)
-        keys = sorted({k for r in self.rows for k in r})
+        if self.keys and all(k in self.keys for k in row):
+            with open(self.path, "a", newline="") as f:
+                csv.DictWriter(f, fieldnames=self.keys).writerow(row)
+            return
+        self.keys = sorted(set(self.keys) | set(row))
         with open(self.path, "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=keys)
+            w = csv.DictWriter(f, fieldnames=self.keys)
             w.writeheader()
             w.writerows(self.rows)
 
@@ -75,7 +89,7 @@ def _dist_env():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def save_checkpoint(path, model, optimizer, scheduler, step, epoch, best):
+def save_checkpoint(path, model, optimizer, scheduler, step, epoch, best, batch_in_epoch=0):
     torch.save(
         {
             "state_dict": {"model." + k: v for k, v in model.state_dict().items()},  # Lightning key layout
@@ -83,6 +97,7 @@ def save_checkpoint(path, model, optimizer, scheduler, step, epoch, best):
             "lr_schedulers": [scheduler.state_dict()] if scheduler is not None else [],
             "global_step": step,
             "epoch": epoch,
+            "batch_in_epoch": batch_in_epoch,  # batches of `epoch` already consumed: a resumed run skips them
             "best": best,
         },
         path,
@@ -201,12 +216,12 @@ def train(
     optimizer = get_optimizer(optimizer_name, model.parameters(), lr=lr, weight_decay=weight_decay)
     scheduler = get_scheduler(scheduler_name, optimizer, warmup_steps)
     reducer = BucketedGradAllReduce(model) if world > 1 else None
-    csv_logger = CSVLogger(save_path, run_name) if rank == 0 and "csv" in loggers else None
+    csv_logger = CSVLogger(save_path, run_name, resume=resume_training) if rank == 0 and "csv" in loggers else None
     for name in loggers:
         if name != "csv" and rank == 0:
             logger.warning(f"logger {name!r} is not available here; only 'csv' is written")
 
-    step, epoch, best = 0, 0, -float("inf")
+    step, epoch, best, skip_batches = 0, 0, -float("inf"), 0
     last_ckpt = os.path.join(save_path, run_name, "last.ckpt")
     if resume_training or load_weights:
         path = checkpoint_path or last_ckpt
@@ -214,6 +229,7 @@ def train(
                              scheduler if resume_training else None, weights_only=not resume_training and not load_optimizers)
         if resume_training:
             step, epoch, best = ck["global_step"], ck["epoch"], ck.get("best", best)
+            skip_batches = int(ck.get("batch_in_epoch", 0))
         logger.info(f"loaded {path} (step {step})")
 
     train_loader, val_loader = data.train_dataloader(), data.val_dataloader()
@@ -226,6 +242,12 @@ def train(
         if hasattr(train_loader.sampler, "set_epoch"):
             train_loader.sampler.set_epoch(epoch)
         it = iter(train_loader)
+        batch_in_epoch = 0
+        for _ in range(skip_batches):  # resumed inside this epoch: these batches were trained on before the checkpoint
+            if next(it, None) is None:
+                break
+            batch_in_epoch += 1
+        skip_batches = 0
         batch = next(it, None)
         if batch is not None:
             batch = _to_device(batch, device)
@@ -254,6 +276,7 @@ def train(
             if scheduler is not None:
                 scheduler.step()
             step += 1
+            batch_in_epoch += 1
             if step == 3:
                 # the warmed-up model / optimizer / coordinate plans are permanent: keep the cyclic collector's
                 # periodic full collections from re-traversing them (0.4 ms per step on average at ~5 ms steps)
@@ -281,11 +304,12 @@ def train(
                 if rank == 0:
                     logger.info(f"step {step}: " + " ".join(f"{k}={v:.4g}" for k, v in vm.items()))
                     os.makedirs(os.path.dirname(last_ckpt), exist_ok=True)
-                    save_checkpoint(last_ckpt, model, optimizer, scheduler, step, epoch, best)
+                    save_checkpoint(last_ckpt, model, optimizer, scheduler, step, epoch, best, batch_in_epoch)
                     score = vm.get(monitor_metric, vm[module.monitor])
                     if score > best:
                         best = score
-                        save_checkpoint(os.path.join(save_path, run_name, "best.ckpt"), model, optimizer, scheduler, step, epoch, best)
+                        save_checkpoint(os.path.join(save_path, run_name, "best.ckpt"), model, optimizer, scheduler, step, epoch, best,
+                                        batch_in_epoch)
             if step >= total_steps:
                 done = True
                 break

@@ -266,6 +266,43 @@ __global__ __launch_bounds__(EB) void eltwise_kernel(const float *__restrict__ a
   }
 }
 
+// Pointwise activations of the ME module surface beyond ReLU (reference modules/common.py:36-43 lists them at import):
+// forward (gy == nullptr): out = f(x); backward: out = gy * f'(x).  `slope`: per-channel PReLU weights (C entries,
+// or one shared entry when C == 1); channels are the fastest axis of the [rows, C] feature matrix.
+enum { ACT_LEAKY = 1, ACT_ELU = 2, ACT_CELU = 3, ACT_SELU = 4, ACT_GELU = 5, ACT_PRELU = 6 };
+
+template <bool BWD>
+__device__ __forceinline__ float act_eval(int kind, float x, float alpha) {
+  constexpr float kSeluAlpha = 1.6732632423543772f, kSeluScale = 1.0507009873554805f;
+  switch (kind) {
+    case ACT_LEAKY:
+    case ACT_PRELU:
+      return BWD ? (x > 0.f ? 1.f : alpha) : (x > 0.f ? x : alpha * x);
+    case ACT_ELU:
+      return BWD ? (x > 0.f ? 1.f : alpha * expf(x)) : (x > 0.f ? x : alpha * (expf(x) - 1.f));
+    case ACT_CELU:
+      return BWD ? (x > 0.f ? 1.f : expf(x / alpha)) : (x > 0.f ? x : alpha * (expf(x / alpha) - 1.f));
+    case ACT_SELU:
+      return BWD ? kSeluScale * (x > 0.f ? 1.f : kSeluAlpha * expf(x))
+                 : kSeluScale * (x > 0.f ? x : kSeluAlpha * (expf(x) - 1.f));
+    default: {  // ACT_GELU, exact (erf) form
+      const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+      return BWD ? cdf + x * 0.3989422804014327f * expf(-0.5f * x * x) : x * cdf;
+    }
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(EB) void activation_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                        const float *__restrict__ slope, int C, int64_t count, int kind,
+                                                        float alpha, float *__restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < count; i += (int64_t)gridDim.x * EB) {
+    const float a = slope ? slope[C > 1 ? (int)(i % C) : 0] : alpha;
+    const float v = act_eval<BWD>(kind, x[i], a);
+    out[i] = BWD ? gy[i] * v : v;
+  }
+}
+
 // ------------------------------------------------ fused bn + relu + sum-pool (stem tail)
 // y[o] = sum_{i child of o} relu((x[i]-mean)*invstd*gamma+beta): the normalised [N,C] tensor of
 // the finest level (the largest activation of the network) is never written to HBM.
@@ -623,6 +660,21 @@ int mink_eltwise(const float *a, const float *b, int64_t count, int32_t mode, fl
   REQ_A16(a, "eltwise");
   REQ_A16(y, "eltwise");
   eltwise_kernel<<<dim3(ew_grid(count >> 2)), EB, 0, (hipStream_t)stream>>>(a, b, count, mode, y);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_activation(const float *x, const float *gy, const float *slope, int32_t C, int64_t count, int32_t kind, float alpha,
+                    float *out, void *stream) {
+  MINK_REQUIRE(count >= 0 && kind >= ACT_LEAKY && kind <= ACT_PRELU && C >= 1, "activation: bad arguments (kind %d)", kind);
+  MINK_REQUIRE(kind != ACT_PRELU || slope, "activation: PReLU needs its slope vector");
+  MINK_REQUIRE(kind != ACT_CELU || alpha != 0.f, "activation: CELU alpha must be non-zero");
+  if (count == 0) return MINK_OK;
+  MINK_REQUIRE(x && out, "activation: NULL pointer");
+  const float *sl = kind == ACT_PRELU ? slope : nullptr;
+  const dim3 grid(ew_grid(count));
+  if (gy) activation_kernel<true><<<grid, EB, 0, (hipStream_t)stream>>>(x, gy, sl, C, count, kind, alpha, out);
+  else activation_kernel<false><<<grid, EB, 0, (hipStream_t)stream>>>(x, nullptr, sl, C, count, kind, alpha, out);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

@@ -229,7 +229,11 @@ def set_wgrad_overlap(on=True):
 
 
 _GRAD_SINK = None  # a data-parallel reducer that owns the gradient memory (see set_grad_sink)
-_FLUSH_ROWS = 32768  # a convolution backward over at least this many rows keeps the GPU busy for >100 us
+# Where a deferred bucket collective may be launched: behind the backward of a convolution with at most this many
+# weights per offset -- the wide-and-shallow layers, whose kernels keep the GPU busy for >100 us.  A static property
+# of the layer on purpose: every rank then issues its collectives at the same points of the backward pass (a
+# row-count rule would depend on each rank's batch and could interleave them differently with SyncBatchNorm's).
+_FLUSH_MAX_WEIGHTS = 128 * 128
 
 
 def set_grad_sink(sink):
@@ -244,7 +248,7 @@ def set_grad_sink(sink):
     return old
 
 
-_DEFERRED = {"pending": False, "callback": False}
+_DEFERRED = {"pending": False, "task": -1}  # task: the autograd graph task the end-of-backward join is queued for
 _HOME_STREAMS = {}  # device index -> the stream the network itself runs on (noted where a branch forks off)
 _BRANCH_STREAMS = {}
 
@@ -316,11 +320,27 @@ def branch_stream(device, home=None):
 def _join_side_streams():
     """End-of-backward callback: the compute stream waits for the weight gradients still running
     on the side stream, so everything after backward() (optimizer, clipping, ...) is ordered."""
-    _DEFERRED["callback"] = False
+    _DEFERRED["task"] = -1
+    join_side_streams()
+
+
+def join_side_streams():
+    """Make the current stream wait for weight gradients still in flight on the side stream (no-op when none are)."""
     if _DEFERRED["pending"]:
         _DEFERRED["pending"] = False
         for index, side in _SIDE_STREAMS.items():
             stream_wait(torch.cuda.current_stream(index), side)
+
+
+def _defer_join():
+    """Queue the end-of-backward join once per backward pass.  Keyed by the autograd graph task: a backward that
+    raised drops its queued callbacks, and a flag that merely said "already queued" would then stay set for the
+    rest of the process -- every later optimizer step would read weight gradients the side stream is still writing."""
+    _DEFERRED["pending"] = True
+    task = torch._C._current_graph_task_id()
+    if _DEFERRED["task"] != task or task < 0:
+        _DEFERRED["task"] = task
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
 
 
 def _sink_views(*params):
@@ -400,12 +420,9 @@ class ConvolutionFunction(torch.autograd.Function):
                 for t in (x, gy, ctx.nbr):  # every buffer the side stream reads
                     t.record_stream(side)
                 if out is not None:  # written in place into the reducer's buffer: nothing for autograd to do
-                    _DEFERRED["pending"] = True
-                    if not _DEFERRED["callback"]:
-                        _DEFERRED["callback"] = True
-                        torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+                    _defer_join()
                     sink.ready(w)
-                    if gy.shape[0] >= _FLUSH_ROWS:  # the GPU now has long kernels queued: the host has time to launch collectives
+                    if w.shape[-1] * w.shape[-2] <= _FLUSH_MAX_WEIGHTS:  # long kernels are queued: the host has time to launch collectives
                         sink.flush()
                     return gx, None, None, None, None
                 # Nothing reads gw before backward ends when autograd merely installs it as
@@ -421,10 +438,7 @@ class ConvolutionFunction(torch.autograd.Function):
                     gw.record_stream(home)  # a branch's gradient is consumed by the network's own stream later
                 if w.grad is None and not getattr(w, "_post_accumulate_grad_hooks", None) and \
                         not w._backward_hooks and gw.shape[1] == ctx.cin and not torch.is_grad_enabled():
-                    _DEFERRED["pending"] = True
-                    if not _DEFERRED["callback"]:
-                        _DEFERRED["callback"] = True
-                        torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+                    _defer_join()
                 else:
                     stream_wait(main, side)
             else:
@@ -785,6 +799,38 @@ class ReLUFunction(torch.autograd.Function):
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
         return _eltwise(_f32c(gy), y, 1)
+
+
+ACT_KINDS = {"leaky_relu": 1, "elu": 2, "celu": 3, "selu": 4, "gelu": 5, "prelu": 6}
+
+
+class ActivationFunction(torch.autograd.Function):
+    """Pointwise activations beyond ReLU (ME.MinkowskiLeakyReLU / ELU / CELU / SELU / GELU / PReLU; the reference's layer
+    factory lists them at import, modules/common.py:36-43): out = f(x), backward gy * f'(x), one HIP pass each.  The
+    PReLU weight gradient (a column sum of gy * min(x, 0)) is a torch reduction."""
+
+    @staticmethod
+    def forward(ctx, x, kind, alpha, slope):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        C = 1 if slope is None or slope.numel() == 1 else x.shape[1]
+        check(lib().mink_activation(x.data_ptr(), None, _ptr(slope), C, x.numel(), ACT_KINDS[kind], float(alpha), y.data_ptr(), _stream()))
+        ctx.save_for_backward(x, slope)
+        ctx.kind, ctx.alpha, ctx.C = kind, float(alpha), C
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, slope = ctx.saved_tensors
+        gy = _f32c(gy)
+        gx = torch.empty_like(x)
+        check(lib().mink_activation(x.data_ptr(), gy.data_ptr(), _ptr(slope), ctx.C, x.numel(), ACT_KINDS[ctx.kind], ctx.alpha,
+                                    gx.data_ptr(), _stream()))
+        gslope = None
+        if slope is not None and ctx.needs_input_grad[3]:
+            t = gy * x.clamp(max=0)
+            gslope = t.sum().reshape(1) if slope.numel() == 1 else t.sum(0)
+        return gx, None, None, gslope
 
 
 class AddFunction(torch.autograd.Function):

@@ -72,7 +72,10 @@ class MinkowskiConvolution(nn.Module):
                 perm = m.class_perm(in_key) if transposed and self.stride == 2 else None
                 return nbr, nbr_t, perm
 
-            out = Fn.ConvolutionFunction.apply(input.F, self.kernel, table_fn, self.stride == 1, holder)
+            # stride 1 and an odd (centred) kernel: the transposed table is the table itself with the offsets
+            # flipped; an even kernel (offsets {0,1}) has no such symmetry and takes the explicit transposed table
+            same_map = self.stride == 1 and self.kernel_size % 2 == 1
+            out = Fn.ConvolutionFunction.apply(input.F, self.kernel, table_fn, same_map, holder)
         if self.bias is not None:
             out = out + self.bias
         res = SparseTensor(out, out_key, m)
@@ -140,6 +143,16 @@ def cat(*tensors):
                         tensors[0].coordinate_manager)
 
 
+def _bn_momentum(bn):
+    """The running-statistics update factor of `nn.BatchNorm1d`: `momentum`, or -- for momentum=None, the cumulative
+    moving average -- 1 / num_batches_tracked (read after this step's increment; one host read-back, rare config)."""
+    if bn.momentum is not None:
+        return bn.momentum
+    if bn.num_batches_tracked is None:
+        return 0.0
+    return 1.0 / max(float(bn.num_batches_tracked), 1.0)
+
+
 class MinkowskiBatchNorm(nn.Module):
     """ME.MinkowskiBatchNorm: an `nn.BatchNorm1d` (attribute `bn`, so state-dict keys are
     `*.bn.weight` ... and the reference init loop resnet.py:101-105 finds it) applied to F.
@@ -164,7 +177,7 @@ class MinkowskiBatchNorm(nn.Module):
         beta = bn.bias if bn.affine else torch.zeros(bn.num_features, device=input.F.device)
         out = Fn.BatchNormFunction.apply(
             input.F, gamma, beta, bn.running_mean, bn.running_var, training,
-            bn.momentum if bn.momentum is not None else 0.1, bn.eps,
+            _bn_momentum(bn), bn.eps,
             residual.F if residual is not None else None, bool(relu),
             getattr(input, "_bn_partial", None) if training else None)
         return SparseTensor(out, input.coordinate_map_key, input.coordinate_manager)
@@ -191,7 +204,7 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
         if residual is not None:
             input._check(residual)
         out = Fn.SyncBatchNormFunction.apply(
-            input.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum if bn.momentum is not None else 0.1,
+            input.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, _bn_momentum(bn),
             bn.eps, residual.F if residual is not None else None, bool(relu), self.process_group)
         return SparseTensor(out, input.coordinate_map_key, input.coordinate_manager)
 
@@ -220,6 +233,97 @@ class MinkowskiReLU(nn.Module):
 
     def forward(self, input):
         return SparseTensor(Fn.ReLUFunction.apply(input.F), input.coordinate_map_key, input.coordinate_manager)
+
+
+class _Activation(nn.Module):
+    """Pointwise activation on the feature matrix; subclasses name the ME class (modules/common.py:36-51 looks the
+    classes up by `__name__`) and take torch's constructor arguments (`ARG` = the name of the shape parameter)."""
+
+    KIND, ALPHA, ARG = None, 0.0, None
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.alpha = self.ALPHA
+        if self.ARG is not None:
+            self.alpha = float(args[0] if args else kwargs.get(self.ARG, self.ALPHA))
+
+    def forward(self, input):
+        out = Fn.ActivationFunction.apply(input.F, self.KIND, self.alpha, None)
+        return SparseTensor(out, input.coordinate_map_key, input.coordinate_manager)
+
+
+class MinkowskiLeakyReLU(_Activation):
+    KIND, ALPHA, ARG = "leaky_relu", 0.01, "negative_slope"
+
+
+class MinkowskiELU(_Activation):
+    KIND, ALPHA, ARG = "elu", 1.0, "alpha"
+
+
+class MinkowskiCELU(_Activation):
+    KIND, ALPHA, ARG = "celu", 1.0, "alpha"
+
+
+class MinkowskiSELU(_Activation):
+    KIND = "selu"
+
+
+class MinkowskiGELU(_Activation):
+    KIND = "gelu"
+
+
+class MinkowskiPReLU(nn.Module):
+    """ME.MinkowskiPReLU = torch.nn.PReLU on F: `weight` [num_parameters] initialised to `init`."""
+
+    def __init__(self, num_parameters=1, init=0.25):
+        super().__init__()
+        self.weight = nn.Parameter(torch.full((num_parameters,), float(init)))
+
+    def forward(self, input):
+        out = Fn.ActivationFunction.apply(input.F, "prelu", 0.0, self.weight)
+        return SparseTensor(out, input.coordinate_map_key, input.coordinate_manager)
+
+
+class MinkowskiInstanceNorm(nn.Module):
+    """ME.MinkowskiInstanceNorm(num_features) (reference modules/common.py:25-26): every batch sample's voxels are
+    normalised per channel by that sample's own mean / biased variance (eps 1e-6), then scaled and shifted by
+    `weight` (ones) / `bias` (zeros).  The rows of one sample are contiguous, so each sample is one batch-norm pass
+    (training-mode statistics, no running buffers) over its row range."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.num_features, self.eps = num_features, 1e-6
+        self.weight = nn.Parameter(torch.ones(1, num_features))
+        self.bias = nn.Parameter(torch.zeros(1, num_features))
+
+    def forward(self, input):
+        m = input.coordinate_manager
+        boff = m.batch_offsets(input.coordinate_map_key).tolist()
+        F, g, b = input.F, self.weight.reshape(-1), self.bias.reshape(-1)
+        parts = [Fn.BatchNormFunction.apply(F[s:e], g, b, None, None, True, 0.0, self.eps, None, False, None)
+                 for s, e in zip(boff[:-1], boff[1:]) if e > s]
+        return SparseTensor(torch.cat(parts, 0), input.coordinate_map_key, m)
+
+
+class MinkowskiLinear(nn.Module):
+    """ME.MinkowskiLinear: torch.nn.Linear on the feature matrix (same parameter names through `.linear`)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+
+    def forward(self, input):
+        return SparseTensor(self.linear(input.F), input.coordinate_map_key, input.coordinate_manager)
+
+
+class MinkowskiDropout(nn.Module):
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__()
+        self.p = p
+
+    def forward(self, input):
+        return SparseTensor(nn.functional.dropout(input.F, self.p, self.training), input.coordinate_map_key,
+                            input.coordinate_manager)
 
 
 class MinkowskiSumPooling(nn.Module):
@@ -254,7 +358,7 @@ class MinkowskiSumPooling(nn.Module):
             if training and bn.track_running_stats and not norm.counted_by_parent:
                 bn.num_batches_tracked += 1
             out = Fn.BNReLUSumPoolFunction.apply(input.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, training,
-                                                 bn.momentum if bn.momentum is not None else 0.1, bn.eps, nbr, i2o,
+                                                 _bn_momentum(bn), bn.eps, nbr, i2o,
                                                  getattr(input, "_bn_partial", None) if training else None)
         else:
             if norm is not None:
@@ -283,7 +387,7 @@ class MinkowskiSumPooling(nn.Module):
             bn.num_batches_tracked += 1
         out = Fn.ConvBNReLUSumPoolFunction.apply(
             input.F, conv.kernel, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-            bn.momentum if bn.momentum is not None else 0.1, bn.eps, nbr, nbr_pool, i2o)
+            _bn_momentum(bn), bn.eps, nbr, nbr_pool, i2o)
         return SparseTensor(out, out_key, m)
 
 

@@ -99,6 +99,10 @@ class TensorField:
         if kwargs.get("_manager") is not None:  # a slice(): shares the manager of the field it came from
             self._F, self._C, self._manager, self._plan, self._ready = features, coordinates, kwargs["_manager"], None, None
             return
+        qm = kwargs.get("quantization_mode")
+        if qm is not None and getattr(qm, "name", str(qm)) != "UNWEIGHTED_AVERAGE":
+            raise NotImplementedError(f"TensorField(quantization_mode={qm}): only UNWEIGHTED_AVERAGE (the ME default the "
+                                      "reference relies on) is implemented")
         if not coordinates.is_cuda:
             raise RuntimeError("nerf_downstream_amd.minkowski runs on the GPU only: move the batch to cuda first")
         self._F, self._C = features, coordinates

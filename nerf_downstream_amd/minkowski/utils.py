@@ -117,3 +117,14 @@ def augment_batch(coords, feats, scene_offsets, params, streams, seed, raw_cols,
         return out_c, out_f, (count, ev)
     k = int(kept.item())
     return out_c[:k], out_f[:k]
+
+
+def kaiming_normal_(tensor, a=0, mode="fan_in", nonlinearity="leaky_relu"):
+    """ME.utils.kaiming_normal_ for convolution kernels laid out (K, Cin, Cout): fan_in = K * Cin, fan_out = K * Cout."""
+    import math
+
+    k = tensor.shape[0] if tensor.dim() == 3 else 1
+    fan = k * (tensor.shape[-2] if mode == "fan_in" else tensor.shape[-1])
+    std = torch.nn.init.calculate_gain(nonlinearity, a) / math.sqrt(fan)
+    with torch.no_grad():
+        return tensor.normal_(0, std)

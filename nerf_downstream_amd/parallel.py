@@ -8,11 +8,14 @@ per-rank BatchNorm statistics, mean of gradients across ranks once per step.  He
   in REVERSE registration order so the buffer fills front-to-back as backward proceeds
   (layer4 -- 74 % of the bytes -- first);
 * the buffer is cut into buckets of >= 8 MiB (one parameter tensor is never split: layer4's two
-  3^3 kernels are 28 MB and 14 MB messages on their own, ready first; the LAST bucket, which
-  cannot overlap with anything, ends up ~4 MB);
+  3^3 kernels are 28 MB and 14 MB messages on their own, ready first); the LAST bucket, which
+  cannot overlap with anything, holds only the stem convolution + its batch norm (0.2 MB);
 * a post-accumulate-grad hook counts ready parameters per bucket and launches the bucket's
-  `all_reduce(async_op=True)` as soon as it is complete -- RCCL runs it on its own HIP stream,
-  overlapped with the remaining backward kernels;
+  `all_reduce(async_op=True)` once it is complete -- RCCL runs it on its own HIP stream, overlapped
+  with the remaining backward kernels.  On the GPU (gradient-sink mode) a complete bucket is not
+  launched from inside the backward of the small deep layers, where the host is what the GPU waits
+  for, but at the next `flush()` point: behind the backward of a wide-and-shallow layer -- a static
+  property of the layer, so every rank issues its collectives at the same points;
 * `finish()` waits for all buckets (RCCL averages inside the collective; with gloo the sum is scaled by
   1/world here), before the optimizer step.
 """
@@ -44,14 +47,29 @@ class BucketedGradAllReduce:
         off, bstart, bcount = 0, 0, 0
         self._views = {}  # id(param) -> its .grad view (identity-checked in view_for)
         self._params = params  # keeps the ids alive
-        for p in params:
+        # The network's first layer is the last to get its gradient, and nothing is left to overlap its collective
+        # with: keep that exposed message minimal.  The first registered weight tensor and the 1-D parameters that
+        # follow it (the stem convolution and its batch norm: 0.2 MB for the ResNets) get a bucket of their own, so
+        # the bucket before it (layer1) goes out beside the stem's weight-gradient kernel (0.9 ms at B=16) instead
+        # of waiting for it.
+        fwd = params[::-1]
+        n_tail = 0
+        if len(fwd) > 6 and fwd[0].dim() > 1:
+            n_tail = 1
+            while n_tail < len(fwd) and fwd[n_tail].dim() == 1:
+                n_tail += 1
+        tail_at = len(params) - n_tail if n_tail else -1
+        for i, p in enumerate(params):
+            if i == tail_at and bcount:
+                self.buckets.append((bstart, off, bcount))
+                bstart, bcount = off, 0
             p.grad = self.flat[off : off + p.numel()].view_as(p)
             self._views[id(p)] = p.grad
             self._bucket_of[id(p)] = len(self.buckets)  # keyed by id: Tensor.__hash__ is a Python-level call (~1 us) and
             # the per-step path would make half a dozen of them per parameter
             off += -(-p.numel() // ALIGN) * ALIGN
             bcount += 1
-            if (off - bstart) * 4 >= bucket_bytes:
+            if (off - bstart) * 4 >= bucket_bytes and not (0 <= tail_at <= i):
                 self.buckets.append((bstart, off, bcount))
                 bstart, bcount = off, 0
         if bcount:
@@ -61,6 +79,12 @@ class BucketedGradAllReduce:
         self._work = []
         self._hooks = []
         self._home = None  # the stream the step runs on (captured in zero_grad)
+        # `defer` (switched on together with the gradient sink below): complete buckets wait for flush() / finish()
+        # instead of being launched from inside the backward of the small deep layers
+        self.defer = False
+        self._pending = []
+        self._written = set()  # parameters whose gradient was written in place this step
+        self._counted = set()  # parameters already counted towards their bucket this step
         if self.world > 1 or self.force:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -84,10 +108,6 @@ class BucketedGradAllReduce:
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._active = self.world > 1 or self.force
-        self.defer = False  # set with the gradient sink: complete buckets wait for flush() / finish()
-        self._pending = []
-        self._written = set()  # parameters whose gradient was written in place this step
-        self._counted = set()  # parameters already counted towards their bucket this step
 
     # ---- gradient sink protocol (minkowski.functional.set_grad_sink)
     def view_for(self, p):

@@ -43,6 +43,15 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP thread count of the C restatement's kernel-map search (bench.py times it at two thread counts)."""
+    lib()  # liboracle_maps.so brings libgomp in
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
 def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 

@@ -204,12 +204,12 @@ class TensorField:
         m = self._manager
         inv = torch.from_numpy(m.field_inverse.astype(np.int64))
         nu = m.coords[1].shape[0]
-        F = self._F.float()
+        F = self._F if self._F.dtype == torch.float64 else self._F.float()  # (float64: the tests' high-precision reference run)
         if nu == F.shape[0]:
             Fs = F[torch.from_numpy(m.field_unique_index.astype(np.int64))]
         else:
-            Fs = torch.zeros(nu, F.shape[1]).index_add_(0, inv, F)
-            cnt = torch.zeros(nu).index_add_(0, inv, torch.ones(F.shape[0]))
+            Fs = torch.zeros(nu, F.shape[1], dtype=F.dtype).index_add_(0, inv, F)
+            cnt = torch.zeros(nu, dtype=F.dtype).index_add_(0, inv, torch.ones(F.shape[0], dtype=F.dtype))
             Fs = Fs / cnt[:, None]
         return SparseTensor(Fs, CoordinateMapKey(1), m)
 
@@ -272,7 +272,7 @@ class _GlobalAvgFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, batch_idx, B):
         idx = torch.from_numpy(batch_idx.astype(np.int64))
-        cnt = torch.bincount(idx, minlength=B).float()
+        cnt = torch.bincount(idx, minlength=B).to(x.dtype)
         ctx.idx, ctx.cnt = idx, cnt
         return x.new_zeros(B, x.shape[1]).index_add_(0, idx, x) / cnt[:, None]
 
@@ -367,6 +367,78 @@ class MinkowskiReLU(nn.Module):
 
     def forward(self, input):
         return SparseTensor(torch.relu(input.F), input.coordinate_map_key, input._manager)
+
+
+def _pointwise(name, fn, arg=None, default=None):
+    """ME's activation modules are torch's activations applied to F (ME MinkowskiNonlinearity.py wraps the torch modules)."""
+
+    class _Act(nn.Module):
+        def __init__(self, *args, **kw):
+            super().__init__()
+            self.value = (args[0] if args else kw.get(arg, default)) if arg else None
+
+        def forward(self, input):
+            out = fn(input.F) if arg is None else fn(input.F, self.value)
+            return SparseTensor(out, input.coordinate_map_key, input._manager)
+
+    _Act.__name__ = _Act.__qualname__ = name
+    return _Act
+
+
+MinkowskiLeakyReLU = _pointwise("MinkowskiLeakyReLU", torch.nn.functional.leaky_relu, "negative_slope", 0.01)
+MinkowskiELU = _pointwise("MinkowskiELU", torch.nn.functional.elu, "alpha", 1.0)
+MinkowskiCELU = _pointwise("MinkowskiCELU", torch.nn.functional.celu, "alpha", 1.0)
+MinkowskiSELU = _pointwise("MinkowskiSELU", torch.nn.functional.selu)
+MinkowskiGELU = _pointwise("MinkowskiGELU", torch.nn.functional.gelu)
+
+
+class MinkowskiPReLU(nn.Module):
+    def __init__(self, num_parameters=1, init=0.25):
+        super().__init__()
+        self.weight = nn.Parameter(torch.full((num_parameters,), float(init)))
+
+    def forward(self, input):
+        return SparseTensor(torch.nn.functional.prelu(input.F, self.weight), input.coordinate_map_key, input._manager)
+
+
+class MinkowskiInstanceNorm(nn.Module):
+    """ME.MinkowskiInstanceNorm: per batch sample and channel, (x - mean) / sqrt(biased var + 1e-6) * weight + bias."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.eps = 1e-6
+        self.weight = nn.Parameter(torch.ones(1, num_features))
+        self.bias = nn.Parameter(torch.zeros(1, num_features))
+
+    def forward(self, input):
+        m = input._manager
+        b = torch.from_numpy(m.coords[input.coordinate_map_key.ts][:, 0].astype(np.int64))
+        out = torch.empty_like(input.F)
+        for j in range(m.batch_size()):
+            rows = torch.nonzero(b == j).squeeze(1)
+            x = input.F[rows]
+            mu, var = x.mean(0, keepdim=True), x.var(0, unbiased=False, keepdim=True)
+            out[rows] = (x - mu) / torch.sqrt(var + self.eps) * self.weight + self.bias
+        return SparseTensor(out, input.coordinate_map_key, m)
+
+
+class _Functional:
+    """MinkowskiEngine.MinkowskiFunctional (reference modules/common.py:56-71)."""
+
+    @staticmethod
+    def _w(input, out):
+        return SparseTensor(out, input.coordinate_map_key, input._manager)
+
+    relu = staticmethod(lambda input, *a, **k: _Functional._w(input, torch.relu(input.F)))
+    leaky_relu = staticmethod(lambda input, negative_slope=0.01, **k: _Functional._w(input, torch.nn.functional.leaky_relu(input.F, negative_slope)))
+    elu = staticmethod(lambda input, alpha=1.0, **k: _Functional._w(input, torch.nn.functional.elu(input.F, alpha)))
+    celu = staticmethod(lambda input, alpha=1.0, **k: _Functional._w(input, torch.nn.functional.celu(input.F, alpha)))
+    selu = staticmethod(lambda input, **k: _Functional._w(input, torch.nn.functional.selu(input.F)))
+    gelu = staticmethod(lambda input, **k: _Functional._w(input, torch.nn.functional.gelu(input.F)))
+    prelu = staticmethod(lambda input, weight: _Functional._w(input, torch.nn.functional.prelu(input.F, weight)))
+
+
+MinkowskiFunctional = _Functional()
 
 
 class MinkowskiSumPooling(nn.Module):

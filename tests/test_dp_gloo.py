@@ -101,3 +101,77 @@ def test_flat_buffer_layout_single_process():
     assert float(red.flat.abs().sum()) == float(red.gradients().abs().sum())  # the padding stays zero
     red.zero_grad()
     assert float(red.flat.abs().sum()) == 0.0
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_one_rank_per_gpu():
+    """`python bench.py --gpus 2` with no launcher environment starts its own ranks under torch.distributed.run (as
+    a child process -- the parent never touches the GPU) and relays rank 0's JSON line.  --dry-run: rendezvous and one
+    all-reduce only (this container has no GPU); the real step runs the same way in tests/test_gpu_train.py."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res == {"dry_run": True, "n_gpus": 2, "ranks_seen": 2, "rank_sum": 3.0}
+    # asking for a rank count that the launcher environment does not provide is an error, not a silent N=1 run
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def test_length_balanced_sampler_matches_distributed_sampler_sets(tmp_path, monkeypatch):
+    """Length-aware placement across ranks: every global step draws the same sample set as DistributedSampler would
+    (same averaged gradient), but the per-rank voxel totals are balanced to within one scene."""
+    import numpy as np
+    from torch.utils.data.distributed import DistributedSampler
+
+    sys.path.insert(0, ROOT)
+    from nerf_downstream_amd.co3d_3d.src.data.data_module import LengthBalancedDistributedSampler as LB
+
+    rng = np.random.default_rng(0)
+    n, W, B = 203, 4, 6
+    lengths = rng.integers(8_000, 120_000, n)  # CO3D scenes vary by more than 10x
+    samplers = [LB(lengths, B, W, r, seed=7) for r in range(W)]
+    for s in samplers:
+        s.set_epoch(3)
+    per_rank = [list(s) for s in samplers]
+    assert all(len(p) == (n // (W * B)) * B == len(samplers[0]) for p in per_rank)
+    flat = sorted(i for p in per_rank for i in p)
+    assert len(set(flat)) == len(flat)  # disjoint across ranks
+    worst_lb, worst_plain = 0.0, 0.0
+    plain = []
+    for r in range(W):
+        ds = DistributedSampler(range(n), W, r, shuffle=True, seed=7, drop_last=True)
+        ds.set_epoch(3)
+        plain.append(list(ds))
+    for t in range(n // (W * B)):
+        got = [p[t * B : (t + 1) * B] for p in per_rank]
+        ref = [p[t * B : (t + 1) * B] for p in plain]
+        assert sorted(i for g in got for i in g) == sorted(i for g in ref for i in g)  # same global batch
+        tot = np.array([lengths[g].sum() for g in got], dtype=np.float64)
+        tot_ref = np.array([lengths[g].sum() for g in ref], dtype=np.float64)
+        assert tot.max() - tot.min() <= lengths[[i for g in got for i in g]].max()
+        worst_lb, worst_plain = max(worst_lb, tot.max() / tot.mean()), max(worst_plain, tot_ref.max() / tot_ref.mean())
+    assert worst_lb < 1.05 < worst_plain  # slowest rank: < 5 % over the mean instead of tens of percent
+
+    # the CO3D dataset reads its lengths from the npz headers
+    from nerf_downstream_amd.co3d_3d.src.data.co3d import Co3DDataset
+
+    (tmp_path / "filelist").mkdir()
+    names = []
+    for j, k in enumerate([300, 57, 1234]):
+        d = tmp_path / "data" / f"plenoxel_co3d_s{j}"
+        d.mkdir(parents=True)
+        np.savez(d / "data.npz", links=np.arange(k, dtype=np.int32), density=np.zeros((k, 1), np.float32),
+                 sh=np.zeros((k, 27), np.uint8), sh_min=np.float32(0), sh_scale=np.float32(1))
+        names.append(f"cup s{j}")
+    (tmp_path / "filelist" / "train.txt").write_text("\n".join(names) + "\n")
+    monkeypatch.chdir(tmp_path)
+    assert Co3DDataset(phase="train", data_root=str(tmp_path / "data")).sample_lengths().tolist() == [300, 57, 1234]

@@ -149,10 +149,13 @@ def _dp_worker(rank, world, port, out):
     labels = torch.tensor([rank, 3 - rank], device=dev)
     red.zero_grad()
     F.cross_entropy(m(m.process_input({"coordinates": coords.to(dev), "features": feats.to(dev)})), labels).backward()
-    launched = all(red._launched)
+    # gradient-sink mode defers complete buckets to the flush points of the backward pass: by its end everything but
+    # the stem's own little bucket (complete only with the last kernel of backward) must be on its way
+    launched = all(red._launched[:-1]) and red.defer and len(red.buckets) >= 3
+    tail_bytes = 4 * (red.buckets[-1][1] - red.buckets[-1][0])
     red.finish()
     torch.cuda.synchronize()
-    torch.save({"g": red.gradients().cpu(), "launched": launched}, f"{out}/r{rank}.pt")
+    torch.save({"g": red.gradients().cpu(), "launched": launched, "tail_bytes": tail_bytes}, f"{out}/r{rank}.pt")
     # single-rank reference gradients of this rank's batch (fresh model, same seed)
     torch.manual_seed(3)
     m2 = get_model("ResNet14", 28, 5).to(dev)
@@ -177,7 +180,8 @@ def _dp_worker(rank, world, port, out):
 def test_data_parallel_two_ranks_on_card(tmp_path):
     mp.spawn(_dp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    assert r0["launched"] and r1["launched"]  # buckets were reduced from the backward hooks
+    assert r0["launched"] and r1["launched"]  # buckets were reduced from inside the backward pass (deferred launches on)
+    assert r0["tail_bytes"] < (1 << 20)  # the bucket nothing can overlap with is the stem alone
     assert torch.equal(r0["g"], r1["g"])
     ref = 0.5 * (torch.load(tmp_path / "local0.pt") + torch.load(tmp_path / "local1.pt"))
     assert torch.allclose(r0["g"], ref, atol=1e-5 * float(ref.abs().max()), rtol=1e-4)
@@ -333,3 +337,24 @@ def test_segmentation_and_augmented_training_runs(tmp_path):
     logged = [x for x in res["history"] if "train/loss" in x]
     assert res["global_step"] == 8 and len(logged) == 8 and all(np.isfinite(x["train/loss"]) for x in logged)
     gin.clear_config()
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_self_launched(tmp_path):
+    """`python bench.py --gpus 2` as the driver would type it (no launcher): bench.py starts its own two ranks under
+    torch.distributed.run and rank 0's JSON line comes back.  Rehearsal transport: gloo, both ranks on this one card
+    (BENCH_DEVICE=0) -- the RCCL transport itself needs a node with two GPUs."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(BENCH_DIST_BACKEND="gloo", BENCH_DEVICE="0", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "2",
+           "--grid", "32", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["config"]["ranks_seen"] == 2 and res["config"]["parallelism"] == "dp2"
+    assert res["scaling"] == "weak" and res["steps"] == 3 and res["warmup"] == 2 and res["value"] > 0
+    assert res["config"]["global_batch"] == 4 and "gloo" in res["config"]["collective"]
+    assert np.isfinite(res["config"]["final_loss"])

@@ -1,4 +1,6 @@
 """Pins oracle/mink_maps.c (C restatement) against brute-force numpy/python sets."""
+import os
+
 import numpy as np
 import pytest
 
@@ -86,3 +88,21 @@ def test_kernel_map(oracle_maps, ksize, stride):
         for k in range(27):
             v = nbr[:, k] >= 0
             assert np.array_equal(nbr[nbr[v, k], 26 - k], np.nonzero(v)[0])
+
+
+def test_c_restatement_is_clean_under_asan_ubsan(tmp_path):
+    """oracle/mink_maps.c built with -fsanitize=address,undefined (CPU build only: GPU sanitizers are not available
+    on this pool) and driven over duplicates, negatives, range corners, out-of-range rows and empty inputs."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "orc_san"
+    cc = ["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fopenmp", "-std=c99", "-Wall",
+          "-Werror", "-o", str(exe), os.path.join(root, "oracle", "mink_maps.c"), os.path.join(root, "oracle", "sanitize_driver.c"), "-lm"]
+    subprocess.check_call(cc)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="4"))
+    assert r.returncode == 0 and "sanitize_driver ok" in r.stdout, r.stdout + r.stderr

@@ -220,10 +220,19 @@ def test_baseline_config0_cpu_plumbing(tmp_path):
     assert ckpt.exists() and (tmp_path / "t" / "metrics.csv").exists()
     sd = torch.load(ckpt, weights_only=False)
     assert all(k.startswith("model.") for k in sd["state_dict"]) and sd["global_step"] == 4
-    # resume continues from the stored step
+    assert sd["batch_in_epoch"] == 4 and sd["epoch"] == 0  # position inside the epoch: a resumed run skips those batches
+    import csv
+
+    rows_before = list(csv.DictReader(open(tmp_path / "t" / "metrics.csv")))
+    assert len(rows_before) == 5  # 4 training rows + 1 validation row
+    # resume continues from the stored step, keeps the metrics history and does not replay consumed samples
     gin.bind_parameter("train.max_steps", 6)
     res2 = train(save_path=str(tmp_path), resume_training=True, run_name="t", run_name_postfix=None, ME=OME)
     assert res2["global_step"] == 6
+    rows_after = list(csv.DictReader(open(tmp_path / "t" / "metrics.csv")))
+    assert len(rows_after) == 5 + 3 and [r["global_step"] for r in rows_after[:5]] == [r["global_step"] for r in rows_before]
+    sd2 = torch.load(ckpt, weights_only=False)  # the 4-batch epoch 0 was skipped as already consumed: 2 batches into epoch 1
+    assert (sd2["epoch"], sd2["batch_in_epoch"]) == (1, 2)
 
 
 def test_segmentation_cpu_plumbing(tmp_path):
