@@ -131,39 +131,49 @@ def pmc_traffic(tag, meta):
     return best
 
 
-def roofline_from_timings(timings):
+def _conv_bytes(meta, pairs):
+    """Algorithmic bytes of one convolution launch: 4 (N_in Cin + N_out Cout + K Cin Cout) + 8 P."""
+    n_in = meta["n_in"] if meta["n_in"] is not None and meta["n_in"] >= 0 else meta["n_out"]
+    return 4.0 * (n_in * meta["cin"] + meta["n_out"] * meta["cout"] + meta["K"] * meta["cin"] * meta["cout"]) + 8.0 * pairs
+
+
+def roofline_from_timings(timings, pair_table):
     """Dominant conv kernel of the timed region: achieved = algorithmic FLOPs per launch
     (2 * pairs * Cin * Cout, pairs = valid neighbour-table entries) / mean HIP-event duration."""
-    best = None
-    for tag, ent in timings.items():
-        ms = [s.elapsed_time(e) for s, e in ent["events"]]
-        if not ms:
+    groups = {}
+    for tag, ent in timings.items():  # the two alternating batches give two tags (different row counts) of one kernel
+        m = ent["meta"]
+        key = (m["kind"], m["K"], m["cin"], m["cout"])
+        g = groups.setdefault(key, {"ms": [], "flops": 0.0, "bytes": 0.0, "pairs": 0, "tags": [], "meta": m})
+        pairs = m["pairs"] if m["pairs"] is not None else pair_table.get(tag)
+        if pairs is None or not ent["ms"]:
             continue
-        tot = sum(ms)
-        if best is None or tot > best[1]:
-            best = (tag, tot, ms, ent["meta"])
-    if best is None:
+        g["ms"] += ent["ms"]
+        g["flops"] += 2.0 * pairs * m["cin"] * m["cout"] * len(ent["ms"])
+        g["bytes"] += _conv_bytes(m, pairs) * len(ent["ms"])
+        g["pairs"] = max(g["pairs"], pairs)
+        g["tags"].append(tag)
+    groups = {k: g for k, g in groups.items() if g["ms"]}
+    if not groups:
         return None
-    tag, tot, ms, meta = best
-    pairs = int((meta["nbr"] >= 0).sum().item())
-    flops = 2.0 * pairs * meta["cin"] * meta["cout"]
-    nbytes = 4.0 * (meta["n_in"] * meta["cin"] + meta["n_out"] * meta["cout"] + meta["K"] * meta["cin"] * meta["cout"]) + 8.0 * pairs
-    avg_ms = tot / len(ms)
-    achieved = flops / (avg_ms * 1e-3) / 1e12
+    g = max(groups.values(), key=lambda g: sum(g["ms"]))
+    n, tot = len(g["ms"]), sum(g["ms"])
+    avg_ms = tot / n
+    achieved = g["flops"] / (tot * 1e-3) / 1e12
     return {
         "bound": "mfma",
-        "kernel": tag,
+        "kernel": g["tags"][0],
         "achieved": achieved,
         "peak": MFMA_F32_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-        "traffic": pmc_traffic(tag, meta),
+        "traffic": pmc_traffic(g["tags"][0], g["meta"]),
         "avg_ms": avg_ms,
-        "launches": len(ms),
-        "flops_per_launch": flops,
-        "algorithmic_bytes_per_launch": nbytes,
-        "hbm_frac_at_algorithmic_bytes": nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "pairs": pairs,
+        "launches": n,
+        "flops_per_launch": g["flops"] / n,
+        "algorithmic_bytes_per_launch": g["bytes"] / n,
+        "hbm_frac_at_algorithmic_bytes": g["bytes"] / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "pairs": g["pairs"],
     }
 
 
@@ -299,22 +309,23 @@ def main():
     for i in range(args.warmup):
         step(i)
     dominant = None
-    layer_table = []
+    layer_table, pair_table = [], {}
     if not args.no_kernel_timing:
-        torch.cuda.synchronize()
-        warm = Fn.kernel_timings()
-        tot = {t: sum(s.elapsed_time(e) for s, e in v["events"]) for t, v in warm.items()}
+        warm = Fn.kernel_timings()  # (synchronises on the recorded events)
         for t, v in warm.items():  # (N_in, N_out, P, Cin, Cout) per layer so the roofline can be recomputed
             m = v["meta"]
-            pairs = int((m["nbr"] >= 0).sum().item())
+            if m["pairs"] is None or not v["ms"]:
+                continue
+            pair_table[t] = m["pairs"]
             layer_table.append({
-                "op": t, "n_in": m["n_in"], "n_out": m["n_out"], "pairs": pairs, "cin": m["cin"], "cout": m["cout"],
-                "avg_ms": round(tot[t] / max(1, len(v["events"])), 4), "gflop": round(2e-9 * pairs * m["cin"] * m["cout"], 3),
-                "algorithmic_mb": round((4.0 * (m["n_in"] * m["cin"] + m["n_out"] * m["cout"] + m["K"] * m["cin"] * m["cout"]) + 8.0 * pairs) / 1e6, 2),
+                "op": t, "n_in": m["n_in"], "n_out": m["n_out"], "pairs": m["pairs"], "cin": m["cin"],
+                "cout": m["cout"], "avg_ms": round(sum(v["ms"]) / len(v["ms"]), 4),
+                "gflop": round(2e-9 * m["pairs"] * m["cin"] * m["cout"], 3),
+                "algorithmic_mb": round(_conv_bytes(m, m["pairs"]) / 1e6, 2),
             })
-        if tot:
+        if warm:
             # the kernel with the longest typical launch (median: the first launches of a process run long)
-            med = {t: sorted(s.elapsed_time(e) for s, e in v["events"])[len(v["events"]) // 2] for t, v in warm.items() if v["events"]}
+            med = {t: sorted(v["ms"])[len(v["ms"]) // 2] for t, v in warm.items() if v["ms"]}
             dominant = max(med, key=med.get)
         Fn.enable_kernel_timing(dominant is not None, only=dominant)
     # The warmed-up model / optimizer / map plans are permanent: move them out of the cyclic
@@ -331,7 +342,7 @@ def main():
         loss = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    timings = Fn.kernel_timings()
+    timings = Fn.kernel_timings() if not args.no_kernel_timing else {}
     Fn.enable_kernel_timing(False)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -372,7 +383,7 @@ def main():
             },
         }
         if timings:
-            res["roofline"] = roofline_from_timings(timings)
+            res["roofline"] = roofline_from_timings(timings, pair_table)
         if world == 1:
             # forward only (north_star: "fraction of HBM roofline on the sparse-conv forward"): the network
             # forward on an already prepared batch, training-mode batch norm, no autograd graph

@@ -383,6 +383,94 @@ int mink_augment_scenes(const void *coords, int32_t coords_are_int32, const floa
                         const uint32_t *streams, uint64_t seed, const int32_t *raw_cols, float *out_coords,
                         float *out_feats, int64_t ldo, int32_t *n_kept, void *workspace, void *stream);
 
+/* ------------------------------------------------------------------ whole residual blocks
+ * One call = the complete launch sequence of one stage of the reference network, so the host pays one FFI call per
+ * block instead of one per kernel (a Mink-ResNet14 step is ~300 launches; issued one by one from a Python autograd
+ * graph the host, not the GPU, was the bottleneck).  Same kernels, same order, same results as the per-operator
+ * entry points above -- these functions only sequence them:
+ *
+ *   mink_stem_forward/backward   conv1 -> bn1 -> relu -> SumPooling(2,2)            (models/mink/resnet.py:58-64,163-166)
+ *   mink_block_forward/backward  BasicBlock: conv1-norm1-relu-conv2-norm2 (+downsample(x) or x) -relu
+ *                                                                                   (modules/resnet_block.py:53-69)
+ *
+ * Three streams take part (any two may be the same stream): `compute` runs the chain, `branch` runs the shortcut
+ * (1x1x1 strided convolution + norm) beside it, `wgrad` runs the weight gradients beside the data-gradient chain.
+ * Cross-stream ordering inside a call uses events owned by the library; on return everything the NEXT call on
+ * `compute` needs is ordered on `compute`, EXCEPT the weight gradients (dw of every convolution), which are complete
+ * on `wgrad` -- the caller joins `wgrad` once, at the end of the backward pass.  Buffers must stay alive until then.
+ * Batch norm runs in training mode (batch statistics; running statistics updated in place when given). */
+typedef struct {
+  const float *w;        /* [K][cin][cout] */
+  float *dw;             /* backward: weight gradient [K][cin][cout] (written, not accumulated) */
+  const int32_t *nbr;    /* [n_out][K] neighbour table in -> out */
+  const int32_t *nbr_t;  /* backward, stride > 1: transposed table [n_in][K]; NULL for stride 1 (the flipped table) */
+  const int32_t *perm;   /* backward, stride > 1: parity-class row order of the input map (mink_class_partition) */
+  int64_t n_perm;        /* rows of `perm` (0 without one) */
+  int32_t K, cin, cout, stride;
+} MinkConvLayer;
+
+typedef struct {
+  const float *gamma, *beta;          /* [C] */
+  float *running_mean, *running_var;  /* [C] or both NULL */
+  float *dgamma, *dbeta;              /* backward: [C] (written) */
+  float *mean, *invstd;               /* [C] batch statistics: written by forward, read by backward */
+  float momentum, eps;
+} MinkNormLayer;
+
+typedef struct {
+  void *compute, *branch, *wgrad;     /* hipStream_t */
+  void *ws_compute, *ws_branch, *ws_wgrad; /* scratch per stream, 256-byte aligned */
+  int64_t ws_bytes;                   /* size of EACH scratch buffer (>= mink_block_workspace_bytes) */
+} MinkExec;
+
+typedef struct {
+  MinkConvLayer conv;   /* 3^3, stride 1, no bias; cin a multiple of 4 */
+  MinkNormLayer norm;
+  const int32_t *nbr_pool;  /* [n_pool][8] children table of the 2^3 sum pooling */
+  const int32_t *in2out;    /* [n] row -> pooled row */
+  int64_t n, n_pool;
+  const float *x;  /* [n][cin] */
+  float *y;        /* [n][cout] convolution output (kept for backward) */
+  float *out;      /* [n_pool][cout] */
+  const float *g_out;  /* backward: gradient of `out` */
+} MinkStem;
+
+typedef struct {
+  MinkConvLayer conv1, conv2, down;   /* down.w == NULL: identity shortcut (then n_in == n_out, cin == cout) */
+  MinkNormLayer norm1, norm2, normd;
+  int64_t n_in, n_out;
+  const float *x;   /* [n_in][cin] */
+  float *y1, *h1, *y2, *yd, *sd, *out;  /* [n_out][planes] each: conv1 out, relu(norm1), conv2 out, shortcut conv out,
+                                           normalised shortcut, block output (yd, sd unused without a down path) */
+  /* backward */
+  const float *g_out;  /* [n_out][planes] */
+  float *g_x;          /* [n_in][cin], or NULL when the block input needs no gradient */
+  float *g_tmp;        /* scratch for the intermediate gradients: mink_block_grad_scratch_floats() floats */
+} MinkBasicBlock;
+
+int64_t mink_block_workspace_bytes(int64_t n_in, int64_t n_out, int32_t cin, int32_t cout);
+int64_t mink_block_grad_scratch_floats(int64_t n_in, int64_t n_out, int32_t cin, int32_t cout, int32_t has_down);
+/* 1 when mink_stem_forward/backward accept this stem (else compose it from the per-operator calls) */
+int mink_stem_supported(int64_t n, int32_t cin, int32_t cout, int32_t K);
+int mink_stem_forward(const MinkStem *s, const MinkExec *ex);
+int mink_stem_backward(const MinkStem *s, const MinkExec *ex);
+int mink_block_forward(const MinkBasicBlock *b, const MinkExec *ex);
+int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex);
+
+/* ------------------------------------------------------------------ kernel timing (measurement only)
+ * bench.py reports the roofline of the dominant convolution kernel from HIP events recorded on the stream each
+ * kernel is launched on.  mode 0: off; 1: every convolution launch; 2: only launches matching (kind, K, cin, cout).
+ * kind: 0 forward, 1 data gradient, 2 weight gradient.  mink_conv_timing_fetch synchronises the recorded events,
+ * writes up to `max` entries and clears the list; returns the number written (or the number pending if out == NULL). */
+typedef struct {
+  int32_t kind, K, cin, cout;
+  int64_t n_in, n_out;
+  const int32_t *nbr;
+  float ms;
+} MinkTimingEntry;
+int mink_conv_timing(int32_t mode, int32_t kind, int32_t K, int32_t cin, int32_t cout);
+int64_t mink_conv_timing_fetch(MinkTimingEntry *out, int64_t max);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,49 @@ class KernelMapDesc(ctypes.Structure):
                 ("n_in", _i64), ("nbr", _p), ("nbr_t", _p), ("K", _i32), ("offsets", _i32 * 81)]
 
 
+class ConvLayer(ctypes.Structure):
+    """MinkConvLayer of include/mink_hip.h"""
+
+    _fields_ = [("w", _p), ("dw", _p), ("nbr", _p), ("nbr_t", _p), ("perm", _p), ("n_perm", _i64), ("K", _i32), ("cin", _i32),
+                ("cout", _i32), ("stride", _i32)]
+
+
+class NormLayer(ctypes.Structure):
+    """MinkNormLayer"""
+
+    _fields_ = [("gamma", _p), ("beta", _p), ("running_mean", _p), ("running_var", _p), ("dgamma", _p), ("dbeta", _p),
+                ("mean", _p), ("invstd", _p), ("momentum", _f32), ("eps", _f32)]
+
+
+class Exec(ctypes.Structure):
+    """MinkExec"""
+
+    _fields_ = [("compute", _p), ("branch", _p), ("wgrad", _p), ("ws_compute", _p), ("ws_branch", _p), ("ws_wgrad", _p),
+                ("ws_bytes", _i64)]
+
+
+class Stem(ctypes.Structure):
+    """MinkStem"""
+
+    _fields_ = [("conv", ConvLayer), ("norm", NormLayer), ("nbr_pool", _p), ("in2out", _p), ("n", _i64), ("n_pool", _i64),
+                ("x", _p), ("y", _p), ("out", _p), ("g_out", _p)]
+
+
+class BasicBlock(ctypes.Structure):
+    """MinkBasicBlock"""
+
+    _fields_ = [("conv1", ConvLayer), ("conv2", ConvLayer), ("down", ConvLayer), ("norm1", NormLayer), ("norm2", NormLayer),
+                ("normd", NormLayer), ("n_in", _i64), ("n_out", _i64), ("x", _p), ("y1", _p), ("h1", _p), ("y2", _p),
+                ("yd", _p), ("sd", _p), ("out", _p), ("g_out", _p), ("g_x", _p), ("g_tmp", _p)]
+
+
+class TimingEntry(ctypes.Structure):
+    """MinkTimingEntry"""
+
+    _fields_ = [("kind", _i32), ("K", _i32), ("cin", _i32), ("cout", _i32), ("n_in", _i64), ("n_out", _i64), ("nbr", _p),
+                ("ms", _f32)]
+
+
 # name -> (restype, argtypes); mirrors include/mink_hip.h one to one
 SIGNATURES = {
     "mink_last_error": (ctypes.c_char_p, []),
@@ -82,6 +125,15 @@ SIGNATURES = {
     "mink_bn_relu_pool_bwd": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "mink_eltwise": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
     "mink_activation": (ctypes.c_int, [_p, _p, _p, _i32, _i64, _i32, _f32, _p, _p]),
+    "mink_block_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
+    "mink_block_grad_scratch_floats": (_i64, [_i64, _i64, _i32, _i32, _i32]),
+    "mink_stem_supported": (ctypes.c_int, [_i64, _i32, _i32, _i32]),
+    "mink_stem_forward": (ctypes.c_int, [_p, _p]),
+    "mink_stem_backward": (ctypes.c_int, [_p, _p]),
+    "mink_block_forward": (ctypes.c_int, [_p, _p]),
+    "mink_block_backward": (ctypes.c_int, [_p, _p]),
+    "mink_conv_timing": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
+    "mink_conv_timing_fetch": (_i64, [_p, _i64]),
 }
 
 

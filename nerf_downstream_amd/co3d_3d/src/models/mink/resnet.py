@@ -9,12 +9,24 @@ co3d_3d/src/models/mink/resnet.py:25-192).  Topology, tensor strides and paramet
 State-dict keys: conv1.kernel, bn1.bn.*, layer{i}.{j}.{conv1,conv2}.kernel,
 layer{i}.{j}.{norm1,norm2}.bn.*, layer{i}.0.downsample.{0.kernel,1.bn.*}, final.{kernel,bias}.
 ResNet50/101 use the Bottleneck block (conv1/conv3 1x1x1, conv2 3x3x3 carrying the stride; expansion 4)."""
+import os
+
 import torch
 import torch.nn as nn
 
 from .base_model import MinkowskiBaseModel
 from .modules.common import conv, get_norm
 from .modules.resnet_block import BasicBlock, Bottleneck
+
+
+class _Presparsed:
+    """A field whose `.sparse()` has already been taken (forward() looked at it to choose its path)."""
+
+    def __init__(self, st):
+        self._st = st
+
+    def sparse(self):
+        return self._st
 
 
 class GlobalAvgPool(nn.Module):
@@ -49,6 +61,8 @@ class ResNetBase(MinkowskiBaseModel):
         self.final = conv(self.PLANES[3] * self.BLOCK.expansion, out_channel, kernel_size=1, bias=True, D=D, ME=ME)
         self.weight_initialization()
         self._norms = []
+        self._trunk_plan = None  # native trunk description (minkowski/trunk.py), built on first use; False = not applicable
+        self._native_trunk = os.environ.get("MINK_NATIVE_TRUNK", "1") != "0"
         if self._fused:  # HIP backend: one foreach launch bumps every BN step counter
             self._norms = [m for m in self.modules() if isinstance(m, ME.MinkowskiBatchNorm)]
             for m in self._norms:
@@ -78,6 +92,22 @@ class ResNetBase(MinkowskiBaseModel):
             counters = [m.bn.num_batches_tracked for m in self._norms if m.bn.training and m.bn.track_running_stats]
             if counters:
                 torch._foreach_add_(counters, 1)
+        if self._fused and self._native_trunk:
+            # HIP backend: stem + residual stages as ONE autograd node whose forward / backward make one native call per
+            # stage (minkowski/trunk.py) -- the same kernels as the module-by-module path below, without ~20 us of
+            # Python per launch.  Anything the native sequencer does not cover (eval-mode norms, Bottleneck blocks,
+            # an input that needs a gradient) takes the module path.
+            from nerf_downstream_amd.minkowski import trunk
+
+            if self._trunk_plan is None:
+                self._trunk_plan = trunk.plan_for(self) or False
+            xs = x.sparse()
+            if self._trunk_plan and trunk.usable(self, self._trunk_plan, xs):
+                fork = getattr(self.layer1[0], "_fork", False) and trunk.Fn.branch_fork_enabled()
+                feats = trunk.TrunkFunction.apply(xs.F, self._trunk_plan, xs.coordinate_manager, fork, *self._trunk_plan["params"])
+                out = self._ME.SparseTensor(feats, trunk.out_key_of(self._trunk_plan), xs.coordinate_manager)
+                return self.final(self.glob_avg(out)).F
+            x = _Presparsed(xs)
         if self._fused:  # bn1 -> relu -> pool in one pass over the finest-level activation; its
             # statistics come out of the stem convolution's epilogue (no extra pass over 825 k x 64)
             # -- and, in training, conv1 + bn1 + relu + pool are one autograd node (the input needs no

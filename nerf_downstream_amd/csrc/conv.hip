@@ -6,9 +6,10 @@
 // Both are implicit GEMMs over the neighbour table, accumulated in registers by
 // v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD), with no atomics: every output
 // element has exactly one owner, so results are bitwise reproducible run to run.
-#include <type_traits>
-
 #include <algorithm>
+#include <mutex>
+#include <type_traits>
+#include <vector>
 
 #include "common.h"
 
@@ -1185,6 +1186,45 @@ static void launch_wgrad(const WgradParams &p, dim3 grid, hipStream_t st) {
 
 using namespace mink;
 
+// ---- kernel timing registry (measurement only; see mink_conv_timing in the header)
+namespace {
+struct TimedLaunch {
+  MinkTimingEntry e;
+  hipEvent_t a, b;
+};
+std::mutex g_time_mu;
+std::vector<TimedLaunch> g_timed;
+std::vector<hipEvent_t> g_event_pool;
+int g_time_mode = 0, g_time_kind = 0, g_time_K = 0, g_time_cin = 0, g_time_cout = 0;
+
+struct ScopedTimer {  // records an event pair around the launches of one convolution call, on the launch stream
+  bool on = false;
+  TimedLaunch t;
+  hipStream_t st;
+  ScopedTimer(int kind, int64_t n_in, int64_t n_out, int K, int cin, int cout, const int32_t *nbr, hipStream_t stream) : st(stream) {
+    if (g_time_mode == 0) return;
+    if (g_time_mode == 2 && !(kind == g_time_kind && K == g_time_K && cin == g_time_cin && cout == g_time_cout)) return;
+    std::lock_guard<std::mutex> lk(g_time_mu);
+    for (hipEvent_t *ev : {&t.a, &t.b}) {
+      if (!g_event_pool.empty()) {
+        *ev = g_event_pool.back();
+        g_event_pool.pop_back();
+      } else if (hipEventCreate(ev) != hipSuccess) {
+        return;
+      }
+    }
+    t.e = MinkTimingEntry{kind, K, cin, cout, n_in, n_out, nbr, 0.f};
+    on = hipEventRecord(t.a, st) == hipSuccess;
+  }
+  ~ScopedTimer() {
+    if (!on) return;
+    (void)hipEventRecord(t.b, st);
+    std::lock_guard<std::mutex> lk(g_time_mu);
+    g_timed.push_back(t);
+  }
+};
+}  // namespace
+
 static int g_stagger = 0;
 static int g_pipeline = 1;
 static int g_flat = 1;
@@ -1200,6 +1240,31 @@ int mink_conv_set_stagger(int units) {
   g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
   g_wgrad_force = (units >> 12) & 0xFFFF;  // bits 12-15: force G (1, 3, 9), bits 16-27: force the row split count
   return old;
+}
+
+int mink_conv_timing(int32_t mode, int32_t kind, int32_t K, int32_t cin, int32_t cout) {
+  MINK_REQUIRE(mode >= 0 && mode <= 2, "conv_timing: mode %d", mode);
+  const int old = g_time_mode;
+  g_time_mode = mode, g_time_kind = kind, g_time_K = K, g_time_cin = cin, g_time_cout = cout;
+  return old;
+}
+
+int64_t mink_conv_timing_fetch(MinkTimingEntry *out, int64_t max) {
+  std::lock_guard<std::mutex> lk(g_time_mu);
+  if (!out) return (int64_t)g_timed.size();
+  int64_t n = 0;
+  for (TimedLaunch &t : g_timed) {
+    if (n < max) {
+      float ms = -1.f;
+      if (hipEventSynchronize(t.b) == hipSuccess) (void)hipEventElapsedTime(&ms, t.a, t.b);
+      t.e.ms = ms;
+      out[n++] = t.e;
+    }
+    g_event_pool.push_back(t.a);
+    g_event_pool.push_back(t.b);
+  }
+  g_timed.clear();
+  return n;
 }
 
 int mink_conv_set_math(int mode) {
@@ -1255,6 +1320,7 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   MINK_REQUIRE(ksplit == 1 || workspace, "gather_gemm: split-K needs a workspace");
   if (!row_perm) n_virtual = n_out;
   MINK_REQUIRE(n_virtual >= n_out, "gather_gemm: the row permutation must cover every output row");
+  ScopedTimer timer(w_transposed ? 1 : 0, /*n_in (rows of x) is not known here*/ -1, n_out, K, cin, cout, nbr, (hipStream_t)stream);
   GemmParams p;
   p.row_perm = row_perm, p.n_virtual = n_virtual;
   p.stagger = g_stagger;
@@ -1365,6 +1431,7 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
     return MINK_OK;
   }
   MINK_REQUIRE(x && dy && nbr, "wgrad: NULL pointer");
+  ScopedTimer timer(2, n_in, n_out, K, cin, cout, nbr, st);
   const WgradPlan pl = wgrad_plan(n_out, K, cin, cout);
   MINK_REQUIRE(pl.nsplit == 1 || workspace, "wgrad: needs a workspace");
   WgradParams p;

@@ -1,0 +1,261 @@
+// Whole residual blocks as one host call (include/mink_hip.h, "whole residual blocks").
+//
+// Nothing here launches a kernel of its own: each function sequences the per-operator entry points of this
+// library (mink_conv_* / mink_bn_* / mink_eltwise) over up to three HIP streams, with the cross-stream
+// dependencies expressed through a small pool of library-owned events.  The point is the HOST: a Mink-ResNet14
+// training step is ~300 launches; issued from a Python autograd graph one operator at a time they cost ~20 us
+// each (4 ms per step, as much as the GPU needs for the step); issued from here they cost the ~3.5 us of
+// hipLaunchKernel.
+#include "common.h"
+
+namespace mink {
+namespace {
+
+struct Scratch {  // bump allocator over one stream's scratch buffer
+  char *base;
+  int64_t bytes, off = 0;
+  Scratch(void *p, int64_t n) : base((char *)p), bytes(n) {}
+  void *take(int64_t n) {
+    n = align_up(n > 0 ? n : 1, 256);
+    if (!base || off + n > bytes) return nullptr;
+    void *p = base + off;
+    off += n;
+    return p;
+  }
+};
+
+constexpr int kEvents = 8;
+hipEvent_t g_ev[kEvents];
+bool g_ev_ready = false;
+
+int ensure_events() {
+  if (g_ev_ready) return MINK_OK;
+  for (int i = 0; i < kEvents; ++i) MINK_HIP(hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming));
+  g_ev_ready = true;
+  return MINK_OK;
+}
+
+// `waiter` continues only after everything queued on `producer` so far (no-op for one and the same stream)
+int order_after(hipStream_t waiter, hipStream_t producer, int slot) {
+  if (waiter == producer) return MINK_OK;
+  MINK_HIP(hipEventRecord(g_ev[slot], producer));
+  MINK_HIP(hipStreamWaitEvent(waiter, g_ev[slot], 0));
+  return MINK_OK;
+}
+
+#define TRY(expr)        \
+  do {                   \
+    int rc_ = (expr);    \
+    if (rc_) return rc_; \
+  } while (0)
+
+// y = conv(x) and the batch statistics of y (from the convolution's own epilogue when the launch shape allows)
+int conv_stats(const MinkConvLayer &c, const MinkNormLayer &nm, const float *x, int64_t n_out, float *y, void *ws_base,
+               int64_t ws_bytes, hipStream_t st) {
+  Scratch ws(ws_base, ws_bytes);
+  const int ksplit = mink_conv_plan_ksplit(n_out, c.K, c.cout, 0);
+  float *slabs = ksplit > 1 ? (float *)ws.take(4ll * ksplit * n_out * c.cout) : nullptr;
+  void *stats_ws = ws.take(mink_conv_stats_workspace_bytes(n_out, c.cout));
+  double *partial = (double *)ws.take(512ll * 2 * c.cout * sizeof(double));
+  MINK_REQUIRE((ksplit == 1 || slabs) && stats_ws && partial, "block: scratch too small for a %lld x %d convolution",
+               (long long)n_out, c.cout);
+  int32_t rows = 0;
+  TRY(mink_conv_gather_gemm_stats(x, c.cin, c.cin, c.w, c.nbr, n_out, c.K, y, c.cout, c.cout, nullptr, ksplit, slabs,
+                                  partial, &rows, stats_ws, st));
+  const float mom = nm.running_mean ? nm.momentum : 0.f;
+  if (rows > 0)
+    return mink_bn_stats_from_partials(partial, rows, n_out, c.cout, nm.eps, mom, nm.mean, nm.invstd, nm.running_mean,
+                                       nm.running_var, st);
+  void *bn_ws = ws.take(mink_bn_workspace_bytes(n_out, c.cout));
+  MINK_REQUIRE(bn_ws, "block: scratch too small for batch-norm statistics");
+  return mink_bn_stats(y, n_out, c.cout, nm.eps, mom, nm.mean, nm.invstd, nm.running_mean, nm.running_var, bn_ws, st);
+}
+
+struct Lane {  // a stream and what is left of its scratch buffer
+  hipStream_t st;
+  void *ws;
+  int64_t bytes;
+  Lane after(int64_t used) const { return Lane{st, (char *)ws + align_up(used, 256), bytes - align_up(used, 256)}; }
+};
+
+// gy (complete on data.st) -> dW on weight.st, dX (optional) on data.st
+int conv_backward(const MinkConvLayer &c, const float *x, int64_t n_in, int64_t n_out, const float *gy, float *gx, Lane data,
+                  Lane weight, int ev_slot) {
+  TRY(order_after(weight.st, data.st, ev_slot));
+  {
+    Scratch ws(weight.ws, weight.bytes);
+    const int64_t need = mink_conv_wgrad_workspace_bytes(n_out, c.K, c.cin, c.cout);
+    void *slabs = need > 0 ? ws.take(need) : nullptr;
+    MINK_REQUIRE(need == 0 || slabs, "block: weight-gradient scratch too small");
+    TRY(mink_conv_wgrad(x, n_in, c.cin, c.cin, gy, c.cout, c.cout, c.nbr, n_out, c.K, c.dw, slabs, weight.st));
+  }
+  if (!gx) return MINK_OK;
+  Scratch ws(data.ws, data.bytes);
+  if (c.stride == 1) {  // centred odd kernel: the transposed table is the table with the offsets flipped
+    const int ksplit = mink_conv_plan_ksplit(n_out, c.K, c.cin, 0);
+    float *slabs = ksplit > 1 ? (float *)ws.take(4ll * ksplit * n_out * c.cin) : nullptr;
+    MINK_REQUIRE(ksplit == 1 || slabs, "block: data-gradient scratch too small");
+    return mink_conv_gather_gemm(gy, c.cout, c.cout, c.w, 1, 1, c.nbr, n_out, c.K, nullptr, 0, gx, c.cin, c.cin, nullptr,
+                                 ksplit, slabs, data.st);
+  }
+  MINK_REQUIRE(c.nbr_t, "block: a strided convolution needs its transposed table for the data gradient");
+  const int64_t rows = c.perm ? c.n_perm : n_in;
+  const int ksplit = mink_conv_plan_ksplit(rows, c.K, c.cin, c.perm ? 1 : 0);
+  float *slabs = ksplit > 1 ? (float *)ws.take(4ll * ksplit * n_in * c.cin) : nullptr;
+  MINK_REQUIRE(ksplit == 1 || slabs, "block: data-gradient scratch too small");
+  return mink_conv_gather_gemm(gy, c.cout, c.cout, c.w, 1, 0, c.nbr_t, n_in, c.K, c.perm, c.perm ? c.n_perm : 0, gx, c.cin,
+                               c.cin, nullptr, ksplit, slabs, data.st);
+}
+
+int check_conv(const MinkConvLayer &c, const char *what, bool backward) {
+  MINK_REQUIRE(c.w && c.nbr && c.K >= 1 && c.K <= 27 && c.cin >= 4 && c.cout >= 4 && (c.cin & 3) == 0 && (c.cout & 3) == 0,
+               "%s: bad convolution layer (K=%d, %d -> %d)", what, c.K, c.cin, c.cout);
+  MINK_REQUIRE(!backward || c.dw, "%s: NULL weight-gradient buffer", what);
+  return MINK_OK;
+}
+
+int check_norm(const MinkNormLayer &n, const char *what, bool backward) {
+  MINK_REQUIRE(n.gamma && n.beta && n.mean && n.invstd && (n.running_mean == nullptr) == (n.running_var == nullptr),
+               "%s: bad batch-norm layer", what);
+  MINK_REQUIRE(!backward || (n.dgamma && n.dbeta), "%s: NULL batch-norm gradient buffer", what);
+  return MINK_OK;
+}
+
+}  // namespace
+}  // namespace mink
+
+using namespace mink;
+
+extern "C" {
+
+int64_t mink_block_workspace_bytes(int64_t n_in, int64_t n_out, int32_t cin, int32_t cout) {
+  // generous upper bound of what any single operator of the block carves from one stream's scratch:
+  // split-K slabs (the planner keeps them under 128 MiB) + statistics partials + weight-gradient slabs
+  const int64_t rows = n_in > n_out ? n_in : n_out;
+  const int64_t cmax = cin > cout ? cin : cout;
+  int64_t b = (160ll << 20);
+  b += mink_conv_stats_workspace_bytes(rows, cmax) + 512ll * 2 * cmax * 8 + mink_bn_workspace_bytes(rows, cmax);
+  int64_t wg = 0;
+  for (int k : {1, 27}) {
+    wg = std::max<int64_t>(wg, mink_conv_wgrad_workspace_bytes(n_out, k, cin, cout));
+    wg = std::max<int64_t>(wg, mink_conv_wgrad_workspace_bytes(n_out, k, cout, cout));
+  }
+  return align_up(b + wg + 4096, 256);
+}
+
+int64_t mink_block_grad_scratch_floats(int64_t n_in, int64_t n_out, int32_t cin, int32_t cout, int32_t has_down) {
+  // g_y2, g_res, g_h1, g_y1 [n_out][cout]; g_xa [n_in][cin]; with a down path: g_yd [n_out][cout], g_xb [n_in][cin]
+  return (4 + (has_down ? 1 : 0)) * n_out * cout + (1 + (has_down ? 1 : 0)) * n_in * cin + 64;
+}
+
+int mink_stem_supported(int64_t n, int32_t cin, int32_t cout, int32_t K) {
+  return n > 0 && (cin & 3) == 0 && (cout & 3) == 0 && mink_conv_wgrad_bn_relu_pool_supported(n, cin, cin, n, K, cout);
+}
+
+int mink_stem_forward(const MinkStem *s, const MinkExec *ex) {
+  MINK_REQUIRE(s && ex, "stem_forward: NULL descriptor");
+  TRY(check_conv(s->conv, "stem_forward", false));
+  TRY(check_norm(s->norm, "stem_forward", false));
+  MINK_REQUIRE(s->x && s->y && s->out && s->nbr_pool && s->n >= 1 && s->n_pool >= 1, "stem_forward: bad arguments");
+  hipStream_t st = (hipStream_t)ex->compute;
+  TRY(conv_stats(s->conv, s->norm, s->x, s->n, s->y, ex->ws_compute, ex->ws_bytes, st));
+  return mink_bn_relu_pool_fwd(s->y, s->conv.cout, s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta, s->nbr_pool,
+                               s->n_pool, 8, s->out, st);
+}
+
+int mink_stem_backward(const MinkStem *s, const MinkExec *ex) {
+  MINK_REQUIRE(s && ex, "stem_backward: NULL descriptor");
+  TRY(check_conv(s->conv, "stem_backward", true));
+  TRY(check_norm(s->norm, "stem_backward", true));
+  MINK_REQUIRE(s->x && s->y && s->g_out && s->in2out && s->n >= 1 && s->n_pool >= 1, "stem_backward: bad arguments");
+  hipStream_t st = (hipStream_t)ex->compute;
+  Scratch ws(ex->ws_compute, ex->ws_bytes);
+  void *bn_ws = ws.take(mink_bn_workspace_bytes(s->n, s->conv.cout));
+  const int64_t need = mink_conv_wgrad_workspace_bytes(s->n, s->conv.K, s->conv.cin, s->conv.cout);
+  void *slabs = need > 0 ? ws.take(need) : nullptr;
+  MINK_REQUIRE(bn_ws && (need == 0 || slabs), "stem_backward: scratch too small");
+  TRY(mink_bn_relu_pool_bwd(s->g_out, s->y, s->n, s->conv.cout, s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta,
+                            s->in2out, nullptr, s->norm.dgamma, s->norm.dbeta, bn_ws, st));
+  // the gradient w.r.t. the convolution output is recomputed inside the weight-gradient kernel's operand load
+  return mink_conv_wgrad_bn_relu_pool(s->x, s->n, s->conv.cin, s->conv.cin, s->y, s->conv.cout, s->g_out, s->n_pool, s->in2out,
+                                      s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta, s->norm.dgamma,
+                                      s->norm.dbeta, s->conv.nbr, s->n, s->conv.K, s->conv.dw, slabs, st);
+}
+
+int mink_block_forward(const MinkBasicBlock *b, const MinkExec *ex) {
+  MINK_REQUIRE(b && ex, "block_forward: NULL descriptor");
+  TRY(check_conv(b->conv1, "block_forward conv1", false));
+  TRY(check_conv(b->conv2, "block_forward conv2", false));
+  TRY(check_norm(b->norm1, "block_forward norm1", false));
+  TRY(check_norm(b->norm2, "block_forward norm2", false));
+  const bool down = b->down.w != nullptr;
+  const int C = b->conv1.cout;
+  MINK_REQUIRE(b->x && b->y1 && b->h1 && b->y2 && b->out && b->n_in >= 1 && b->n_out >= 1 && b->conv2.cin == C &&
+                   b->conv2.cout == C,
+               "block_forward: bad arguments");
+  MINK_REQUIRE(down || (b->n_in == b->n_out && b->conv1.cin == C), "block_forward: an identity shortcut needs equal shapes");
+  TRY(ensure_events());
+  hipStream_t st = (hipStream_t)ex->compute, br = (hipStream_t)ex->branch;
+  const float *shortcut = b->x;
+  if (down) {  // shortcut branch: 1x1x1 strided convolution + norm beside conv1 / norm1 / conv2
+    TRY(check_conv(b->down, "block_forward downsample", false));
+    TRY(check_norm(b->normd, "block_forward downsample norm", false));
+    MINK_REQUIRE(b->yd && b->sd && b->down.cout == C && b->down.cin == b->conv1.cin, "block_forward: bad downsample path");
+    TRY(order_after(br, st, 0));  // x is ready
+    TRY(conv_stats(b->down, b->normd, b->x, b->n_out, b->yd, br == st ? ex->ws_compute : ex->ws_branch, ex->ws_bytes, br));
+    TRY(mink_bn_apply(b->yd, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, b->normd.beta, nullptr, 0, b->sd, br));
+    shortcut = b->sd;
+  }
+  TRY(conv_stats(b->conv1, b->norm1, b->x, b->n_out, b->y1, ex->ws_compute, ex->ws_bytes, st));
+  TRY(mink_bn_apply(b->y1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, b->norm1.beta, nullptr, 1, b->h1, st));
+  TRY(conv_stats(b->conv2, b->norm2, b->h1, b->n_out, b->y2, ex->ws_compute, ex->ws_bytes, st));
+  if (down) TRY(order_after(st, br, 1));
+  return mink_bn_apply(b->y2, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, b->norm2.beta, shortcut, 1, b->out, st);
+}
+
+int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
+  MINK_REQUIRE(b && ex, "block_backward: NULL descriptor");
+  TRY(check_conv(b->conv1, "block_backward conv1", true));
+  TRY(check_conv(b->conv2, "block_backward conv2", true));
+  TRY(check_norm(b->norm1, "block_backward norm1", true));
+  TRY(check_norm(b->norm2, "block_backward norm2", true));
+  const bool down = b->down.w != nullptr;
+  const int C = b->conv1.cout, cin = b->conv1.cin;
+  MINK_REQUIRE(b->x && b->y1 && b->h1 && b->y2 && b->out && b->g_out && b->g_tmp && b->n_in >= 1 && b->n_out >= 1,
+               "block_backward: bad arguments");
+  TRY(ensure_events());
+  hipStream_t st = (hipStream_t)ex->compute, br = (hipStream_t)ex->branch, wst = (hipStream_t)ex->wgrad;
+  const Lane compute{st, ex->ws_compute, ex->ws_bytes};
+  const Lane branch{br, br == st ? ex->ws_compute : ex->ws_branch, ex->ws_bytes};
+  const Lane weight{wst, wst == st ? ex->ws_compute : ex->ws_wgrad, ex->ws_bytes};
+  const int64_t no = b->n_out * C, ni = b->n_in * cin;
+  float *g_y2 = b->g_tmp, *g_res = g_y2 + no, *g_h1 = g_res + no, *g_y1 = g_h1 + no, *g_xa = g_y1 + no;
+  float *g_yd = g_xa + ni, *g_xb = g_yd + no;
+  const int64_t bn_bytes = mink_bn_workspace_bytes(b->n_out, C);
+  MINK_REQUIRE(ex->ws_compute && ex->ws_bytes > bn_bytes + 256, "block_backward: scratch too small");
+  const bool want_gx = b->g_x != nullptr;
+  // out = relu(norm2(y2) + shortcut)
+  TRY(mink_bn_bwd(b->g_out, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, 1, g_y2, g_res,
+                  b->norm2.dgamma, b->norm2.dbeta, compute.ws, st));
+  if (down) {  // shortcut branch beside the main one
+    TRY(check_conv(b->down, "block_backward downsample", true));
+    TRY(check_norm(b->normd, "block_backward downsample norm", true));
+    MINK_REQUIRE(b->yd && branch.ws, "block_backward: bad downsample path");
+    TRY(order_after(br, st, 2));  // g_res is ready
+    // (on one stream the branch shares the compute scratch: its batch-norm partials sit behind the main chain's)
+    const Lane bl = br == st ? branch.after(bn_bytes) : branch;
+    TRY(mink_bn_bwd(g_res, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
+                    b->normd.dgamma, b->normd.dbeta, bl.ws, br));
+    TRY(conv_backward(b->down, b->x, b->n_in, b->n_out, g_yd, want_gx ? g_xb : nullptr, bl.after(bn_bytes), weight, 3));
+  }
+  const Lane rest = compute.after(2 * bn_bytes);
+  TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, 4));
+  TRY(mink_bn_bwd(g_h1, b->y1, b->h1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr,
+                  b->norm1.dgamma, b->norm1.dbeta, compute.ws, st));
+  TRY(conv_backward(b->conv1, b->x, b->n_in, b->n_out, g_y1, want_gx ? g_xa : nullptr, rest, weight, 5));
+  if (!want_gx) return MINK_OK;
+  if (down) TRY(order_after(st, br, 6));
+  return mink_eltwise(g_xa, down ? g_xb : g_res, ni, 2, b->g_x, st);
+}
+
+}  // extern "C"

@@ -64,50 +64,81 @@ def set_conv_math(mode="fp32"):
 
 
 # ---------------------------------------------------------------------- kernel timing
-# bench.py measures the dominant kernel live with HIP events recorded on the launch stream.
-# HIP event records are not free on this stack (each one is a barrier packet that drains the
-# queue), so the timed region instruments ONE kernel tag only; the warm-up instruments all.
-_TIMING = None  # None = off; else {tag: {"events": [(start, end)], "meta": {...}}}
-_TIMING_ONLY = None  # restrict event recording to this tag
+# bench.py measures the dominant kernel live with HIP events recorded on the launch stream.  The events are recorded
+# inside the native library around each convolution call (mink_conv_timing), so the module-by-module path and the
+# native trunk are instrumented alike.  HIP event records are not free on this stack (each one is a barrier packet),
+# so the timed region instruments ONE kernel tag only; the warm-up instruments all.
+_TIMING_MODE = 0     # 0 off, 1 every convolution launch, 2 only `_TIMING_ONLY`
+_TIMING_ONLY = None
+_TIMING_TABLES = {}  # warm-up (mode 1): data_ptr -> neighbour table, kept until the entries are fetched (pair counts)
+_TIMING_PAIRS = {}   # tag -> {n_out: valid entries of its table}
+_KINDS = ("fwd", "dgrad", "wgrad")
+
+
+def _parse_tag(tag):
+    import re
+
+    kind, n_out, K, cin, cout = re.fullmatch(r"(\w+)\[(\d+)x(\d+):(\d+)->(\d+)\]", tag).groups()
+    return _KINDS.index(kind), int(n_out), int(K), int(cin), int(cout)
 
 
 def enable_kernel_timing(on=True, only=None):
-    global _TIMING, _TIMING_ONLY
-    _TIMING = {} if on else None
-    _TIMING_ONLY = only
+    """`only`: a tag "kind[n_out x K:cin->cout]" -- every launch of that kind / K / cin / cout is timed."""
+    global _TIMING_MODE, _TIMING_ONLY
+    L = lib()
+    n = L.mink_conv_timing_fetch(None, 0)
+    if n:  # drop entries nobody asked for
+        from .._lib import TimingEntry
+
+        L.mink_conv_timing_fetch((TimingEntry * n)(), n)
+    _TIMING_TABLES.clear()
+    if not on:
+        _TIMING_MODE, _TIMING_ONLY = 0, None
+        L.mink_conv_timing(0, 0, 0, 0, 0)
+    elif only is None:
+        _TIMING_MODE, _TIMING_ONLY = 1, None
+        L.mink_conv_timing(1, 0, 0, 0, 0)
+    else:
+        kind, _, K, cin, cout = _parse_tag(only)
+        _TIMING_MODE, _TIMING_ONLY = 2, only
+        L.mink_conv_timing(2, kind, K, cin, cout)
+
+
+def note_table(*tables):
+    """Warm-up instrumentation: keep the neighbour tables of timed launches alive so their pair counts can be read."""
+    if _TIMING_MODE == 1:
+        for t in tables:
+            if t is not None:
+                _TIMING_TABLES[t.data_ptr()] = t
 
 
 def kernel_timings():
-    return _TIMING
+    """{tag: {"ms": [per-launch milliseconds], "meta": {kind, n_in, n_out, K, cin, cout, pairs (per launch)}}} of the
+    launches timed since the last call (synchronises on their events)."""
+    from .._lib import TimingEntry
 
-
-class _timed:
-    def __init__(self, tag, stream=None, **meta):
-        self.tag, self.meta, self.stream = tag, meta, stream
-
-    def __enter__(self):
-        self.on = _TIMING is not None and (_TIMING_ONLY is None or _TIMING_ONLY == self.tag)
-        if self.on:
-            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.s.record(self.stream)  # None = the current stream; else the stream the kernel is launched on
-
-    def __exit__(self, *exc):
-        if self.on:
-            self.e.record(self.stream)
-            ent = _TIMING.setdefault(self.tag, {"events": [], "meta": self.meta})
-            ent["events"].append((self.s, self.e))
-            ent["meta"] = self.meta
-
-
-class _NoTimer:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *exc):
-        return False
-
-
-_NO_TIMER = _NoTimer()
+    L = lib()
+    n = L.mink_conv_timing_fetch(None, 0)
+    out = {}
+    if n == 0:
+        return out
+    buf = (TimingEntry * n)()
+    n = L.mink_conv_timing_fetch(buf, n)
+    for e in buf[:n]:
+        tag = f"{_KINDS[e.kind]}[{e.n_out}x{e.K}:{e.cin}->{e.cout}]"
+        pairs = _TIMING_PAIRS.setdefault(tag, {})
+        t = _TIMING_TABLES.get(e.nbr)
+        if t is not None and e.n_out not in pairs:
+            # (the row count of the gathered operand is not an argument of a forward / data-gradient call: every row of
+            # it is referenced by the table of the layers timed here, so it is the largest index + 1)
+            pairs[e.n_out] = (int((t >= 0).sum().item()), e.n_in if e.n_in >= 0 else int(t.max().item()) + 1)
+        pr, n_in = pairs.get(e.n_out, (None, e.n_in))
+        ent = out.setdefault(tag, {"ms": [], "meta": {"kind": _KINDS[e.kind], "n_in": n_in, "n_out": e.n_out, "K": e.K,
+                                                      "cin": e.cin, "cout": e.cout, "pairs": pr}})
+        if e.ms >= 0:
+            ent["ms"].append(e.ms)
+    _TIMING_TABLES.clear()
+    return out
 
 
 # ------------------------------------------------------------------------- convolution
@@ -126,31 +157,26 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, ro
     ksplit = _FORCE_KSPLIT or _plan_ksplit(L, n_rows, K, cout, int(row_perm is not None))
     ws = _scratch(4 * ksplit * n_out * cout, x.device, "splitk") if ksplit > 1 else None
     partial = None
-    if _TIMING is None:
-        timer = _NO_TIMER
+    note_table(nbr)
+    if stats and not w_transposed and row_perm is None and n_out > 0:
+        partial = torch.empty(512, 2, cout, dtype=torch.float64, device=x.device)
+        sws = _scratch(L.mink_conv_stats_workspace_bytes(n_out, cout), x.device, "convstats")
+        rows = ctypes.c_int32(0)
+        check(
+            L.mink_conv_gather_gemm_stats(
+                x.data_ptr(), x.stride(0), cin, w.data_ptr(), nbr.data_ptr(), n_out, K, y.data_ptr(), cout, cout,
+                _ptr(bias), ksplit, _ptr(ws), partial.data_ptr(), ctypes.addressof(rows), sws.data_ptr(), _stream(),
+            )
+        )
+        partial = partial[: rows.value] if rows.value > 0 else None
     else:
-        timer = _timed(f"{'dgrad' if w_transposed else 'fwd'}[{n_out}x{K}:{cin}->{cout}]", kind="gather_gemm", n_in=x.shape[0],
-                       n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr, ksplit=ksplit)
-    with timer:
-        if stats and not w_transposed and row_perm is None and n_out > 0:
-            partial = torch.empty(512, 2, cout, dtype=torch.float64, device=x.device)
-            sws = _scratch(L.mink_conv_stats_workspace_bytes(n_out, cout), x.device, "convstats")
-            rows = ctypes.c_int32(0)
-            check(
-                L.mink_conv_gather_gemm_stats(
-                    x.data_ptr(), x.stride(0), cin, w.data_ptr(), nbr.data_ptr(), n_out, K, y.data_ptr(), cout, cout,
-                    _ptr(bias), ksplit, _ptr(ws), partial.data_ptr(), ctypes.addressof(rows), sws.data_ptr(), _stream(),
-                )
+        check(
+            L.mink_conv_gather_gemm(
+                x.data_ptr(), x.stride(0), cin, w.data_ptr(), int(w_transposed), int(flip_k), nbr.data_ptr(), n_out, K,
+                _ptr(row_perm), 0 if row_perm is None else row_perm.numel(),
+                y.data_ptr(), cout, cout, _ptr(bias), ksplit, _ptr(ws), _stream(),
             )
-            partial = partial[: rows.value] if rows.value > 0 else None
-        else:
-            check(
-                L.mink_conv_gather_gemm(
-                    x.data_ptr(), x.stride(0), cin, w.data_ptr(), int(w_transposed), int(flip_k), nbr.data_ptr(), n_out, K,
-                    _ptr(row_perm), 0 if row_perm is None else row_perm.numel(),
-                    y.data_ptr(), cout, cout, _ptr(bias), ksplit, _ptr(ws), _stream(),
-                )
-            )
+        )
     return (y, partial) if stats else y
 
 
@@ -170,21 +196,13 @@ def conv_wgrad(x, dy, nbr, kernel_shape, out=None, on=None):
             dw.record_stream(on)
     ws = _scratch(_wgrad_ws_bytes(L, n_out, K, cin, cout), x.device, "wgrad", on)
     raw = _stream() if on is None else on.cuda_stream
-    if _TIMING is None:
-        check(
-            L.mink_conv_wgrad(
-                x.data_ptr(), x.shape[0], x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K,
-                dw.data_ptr(), ws.data_ptr(), raw,
-            )
+    note_table(nbr)
+    check(
+        L.mink_conv_wgrad(
+            x.data_ptr(), x.shape[0], x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K,
+            dw.data_ptr(), ws.data_ptr(), raw,
         )
-        return dw
-    with _timed(f"wgrad[{n_out}x{K}:{cin}->{cout}]", stream=on, kind="wgrad", n_in=x.shape[0], n_out=n_out, K=K, cin=cin, cout=cout, nbr=nbr):
-        check(
-            L.mink_conv_wgrad(
-                x.data_ptr(), x.shape[0], x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K,
-                dw.data_ptr(), ws.data_ptr(), raw,
-            )
-        )
+    )
     return dw
 
 
@@ -324,12 +342,17 @@ def _join_side_streams():
     join_side_streams()
 
 
+_AFTER_JOIN = []  # callables run once the compute stream is ordered after the side stream (release of kept-alive buffers)
+
+
 def join_side_streams():
     """Make the current stream wait for weight gradients still in flight on the side stream (no-op when none are)."""
     if _DEFERRED["pending"]:
         _DEFERRED["pending"] = False
         for index, side in _SIDE_STREAMS.items():
             stream_wait(torch.cuda.current_stream(index), side)
+    for fn in _AFTER_JOIN:
+        fn()
 
 
 def _defer_join():
@@ -755,14 +778,14 @@ class ConvBNReLUSumPoolFunction(torch.autograd.Function):
         if gw is None:
             gw = torch.empty(w.shape, dtype=torch.float32, device=dev)
         wws = _scratch(L.mink_conv_wgrad_workspace_bytes(n, K, x.shape[1], C), dev, "wgrad")
-        with _timed(f"wgrad[{n}x{K}:{x.shape[1]}->{C}]", kind="wgrad", n_in=x.shape[0], n_out=n, K=K, cin=x.shape[1], cout=C, nbr=nbr):
-            check(
-                L.mink_conv_wgrad_bn_relu_pool(
-                    x.data_ptr(), x.shape[0], x.stride(0), x.shape[1], y.data_ptr(), C, gy.data_ptr(), gy.shape[0],
-                    ctx.in2out.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                    dgamma.data_ptr(), dbeta.data_ptr(), nbr.data_ptr(), n, K, gw.data_ptr(), wws.data_ptr(), _stream(),
-                )
+        note_table(nbr)
+        check(
+            L.mink_conv_wgrad_bn_relu_pool(
+                x.data_ptr(), x.shape[0], x.stride(0), x.shape[1], y.data_ptr(), C, gy.data_ptr(), gy.shape[0],
+                ctx.in2out.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                dgamma.data_ptr(), dbeta.data_ptr(), nbr.data_ptr(), n, K, gw.data_ptr(), wws.data_ptr(), _stream(),
             )
+        )
         if _GRAD_SINK is not None and hasattr(_GRAD_SINK, "flush"):
             _GRAD_SINK.flush()  # the stem's weight gradient (0.9 ms) is queued: everything completed so far goes out beside it
         if pv is not None:

@@ -1,15 +1,19 @@
-"""Host-side timeline of one pipelined training step (run on the GPU box)."""
+"""Host-side timeline of one pipelined training step (run on the GPU box): how long the HOST needs to queue each
+phase, against the wall time of the step.  usage: python scripts/hostprof.py [batch] [native_trunk 0/1]"""
 import collections, cProfile, io, os, pstats, sys, time
 sys.path.insert(0, os.getcwd())
 import torch, torch.nn.functional as F
 from bench import make_batches
 from nerf_downstream_amd.co3d_3d.src.models import get_model
 
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = get_model("ResNet14", 28, 51).to(dev)
+if len(sys.argv) > 2:
+    model._native_trunk = sys.argv[2] != "0"
 opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=True)
-batches = make_batches(2, 16, 0, 51, 128, 28)
+batches = make_batches(2, B, 0, 51, 128, 28)
 batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
 T = collections.defaultdict(float)
 state = {"tf": model.process_input(batches[0])}
@@ -26,17 +30,19 @@ def step(i, rec=False):
     if rec:
         T["launch_next"] += ta - t0; T["forward"] += t1 - ta; T["backward"] += t2 - t1; T["finish_next"] += t3 - t2; T["opt"] += t4 - t3
 
-for i in range(6): step(i)
+for i in range(8): step(i)
+import gc; gc.collect(); gc.freeze()
 torch.cuda.synchronize()
+N = 40
+# (a) host only: the GPU is left to fall behind, then drained
 t0 = time.perf_counter()
-N = 20
-for i in range(6, 6 + N): step(i, True)
+for i in range(8, 8 + N): step(i, True)
 th = time.perf_counter() - t0
 torch.cuda.synchronize()
 tt = time.perf_counter() - t0
-print("host ms/step", {k: round(v / N * 1e3, 3) for k, v in T.items()}, "host total", round(th / N * 1e3, 3), "wall", round(tt / N * 1e3, 3))
+print(f"B={B} native_trunk={model._native_trunk} host ms/step", {k: round(v / N * 1e3, 3) for k, v in T.items()}, "host total", round(th / N * 1e3, 3), "wall", round(tt / N * 1e3, 3))
 pr = cProfile.Profile(); pr.enable()
-for i in range(26, 36): step(i)
+for i in range(48, 58): step(i)
 torch.cuda.synchronize()
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:5000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22); print(s.getvalue()[:4500])

@@ -24,8 +24,8 @@ def _models(name, cin, ncls):
     ("ResNet14", 28, 32, (11, 12, 13), True),
     ("ResNet14", 28, 32, (11, 12, 13), False),
     ("ResNet34", 27, 32, (11, 12, 13, 14, 15), True),
-    ("ResNet50", 28, 32, (11, 12, 13, 14, 15), True),   # Bottleneck blocks
-    ("ResNet50", 28, 32, (11, 12, 13, 14, 15), False),  # 5 scenes: BN over the 3 rows of a 3-scene batch at ts=32 amplifies rounding
+    ("ResNet50", 28, 48, (11, 12, 13, 14), True),   # Bottleneck blocks; 48^3 scenes: at 32^3 the batch norms of
+    ("ResNet50", 28, 48, (11, 12, 13, 14), False),  # layer4 (2048 channels) see ~1 row per scene and amplify rounding 100x
 ])
 def test_resnet_matches_oracle(oracle_maps, name, cin, grid, seeds, fused):
     """Logits within the north_star tolerance (1e-3, fp32), then the gradients of every parameter.
@@ -152,3 +152,43 @@ def test_wgrad_side_stream_is_bitwise_identical(oracle_maps):
         a, b = grads(False, passes), grads(True, passes)
         for k in a:
             assert torch.equal(a[k], b[k]), (passes, k)
+
+
+@pytest.mark.parametrize("name,cin,seeds", [("ResNet14", 28, (41, 42, 43)), ("ResNet18", 27, (44, 45)), ("ResNet34", 28, (46, 47))])
+def test_native_trunk_is_bitwise_the_module_path(oracle_maps, name, cin, seeds):
+    """The native trunk (one call per stage, minkowski/trunk.py) sequences the same kernels as the module-by-module
+    path: logits, every parameter gradient and every batch-norm buffer must be equal bit for bit -- with the shortcut
+    branch and the weight gradients on their own streams, and on a single stream.  ResNet18/34 add identity-shortcut
+    blocks; 27 input channels add the zero-padded column."""
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    coords, feats = batch_scenes(list(seeds), grid=32, cin=cin)
+    batch = {"coordinates": coords.cuda(), "features": feats.cuda()}
+    labels = (torch.arange(len(seeds)) * 7 + 1).cuda() % 51
+
+    def run(native, overlap):
+        hip, _ = _models(name, cin, 51)
+        hip._native_trunk = native
+        old = Fn.set_wgrad_overlap(overlap)
+        try:
+            outs = []
+            for _ in range(2):  # second pass: the map plan of the first is replayed ahead (prepared manager -> forked shortcut)
+                hip.zero_grad(set_to_none=True)
+                out = hip(hip.process_input(batch))
+                F.cross_entropy(out, labels).backward()
+                outs.append(out.detach().clone())
+            torch.cuda.synchronize()
+        finally:
+            Fn.set_wgrad_overlap(old)
+        used = hip._trunk_plan if native else None
+        return outs, {k: p.grad.clone() for k, p in hip.named_parameters()}, {k: b.clone() for k, b in hip.named_buffers()}, used
+
+    ref_out, ref_g, ref_b, _ = run(False, False)
+    for overlap in (False, True):
+        out, g, b, plan = run(True, overlap)
+        assert plan, "the native trunk was not taken"
+        assert all(torch.equal(a, c) for a, c in zip(out, ref_out))
+        for k in ref_g:
+            assert torch.equal(g[k], ref_g[k]), (overlap, k)
+        for k in ref_b:
+            assert torch.equal(b[k], ref_b[k]), (overlap, k)
