@@ -265,8 +265,9 @@ def main():
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=dev.type == "cuda")
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=200000)
-    reducer = BucketedGradAllReduce(model, bucket_bytes=int(os.environ.get("BENCH_BUCKET_BYTES", 8 << 20)),
-                                    force=force_reducer) if world > 1 or force_reducer else None  # N=1: autograd hands gradients over without a copy
+    # one flat gradient buffer the backward kernels write into; with N > 1 ranks its buckets are all-reduced (overlapped
+    # with backward), with one rank that is all it is -- the step is the same program at every N
+    reducer = BucketedGradAllReduce(model, bucket_bytes=int(os.environ.get("BENCH_BUCKET_BYTES", 8 << 20)), force=force_reducer)
 
     batches = make_batches(2, args.batch, rank, args.num_classes, args.grid, args.in_channel)
     batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]

@@ -187,6 +187,10 @@ int mink_conv_set_math(int mode);
 /* Split-K factor the library recommends for a layer (1 for large row counts).  row_classes != 0:
  * the launch will pass a class-partitioned row_perm (stride-2 dgrad), n_out = its n_virtual. */
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_classes);
+/* flip_k: bit 0 = read the weights of offset K-1-k for offset k (data gradient of a stride-1 convolution through the
+ * forward table); bit 1 = ACCUMULATE, y[row] += result instead of y[row] = result -- for an un-split launch whose
+ * row_perm visits every output row at most once (rows it does not visit are left untouched): the data gradient of
+ * the 1x1x1 strided shortcut convolution is added into the main branch's gradient at the 1/8 of the rows it reaches. */
 int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
                           int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K,
                           const int32_t *row_perm, int64_t n_virtual, float *y, int32_t ldy,

@@ -104,7 +104,7 @@ class ResNetBase(MinkowskiBaseModel):
             xs = x.sparse()
             if self._trunk_plan and trunk.usable(self, self._trunk_plan, xs):
                 fork = getattr(self.layer1[0], "_fork", False) and trunk.Fn.branch_fork_enabled()
-                feats = trunk.TrunkFunction.apply(xs.F, self._trunk_plan, xs.coordinate_manager, fork, *self._trunk_plan["params"])
+                feats = trunk.TrunkFunction.apply(xs.F, self._trunk_plan, xs.coordinate_manager, fork, *self._trunk_plan.params)
                 out = self._ME.SparseTensor(feats, trunk.out_key_of(self._trunk_plan), xs.coordinate_manager)
                 return self.final(self.glob_avg(out)).F
             x = _Presparsed(xs)

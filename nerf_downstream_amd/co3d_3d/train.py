@@ -215,7 +215,8 @@ def train(
     module = TRAINING_MODULES[training_module](model)
     optimizer = get_optimizer(optimizer_name, model.parameters(), lr=lr, weight_decay=weight_decay)
     scheduler = get_scheduler(scheduler_name, optimizer, warmup_steps)
-    reducer = BucketedGradAllReduce(model) if world > 1 else None
+    # flat gradient buffer written by the backward kernels (HIP backend); all-reduced in buckets when world > 1
+    reducer = BucketedGradAllReduce(model) if (world > 1 or (device.type == "cuda" and ME is None)) else None
     csv_logger = CSVLogger(save_path, run_name, resume=resume_training) if rank == 0 and "csv" in loggers else None
     for name in loggers:
         if name != "csv" and rank == 0:

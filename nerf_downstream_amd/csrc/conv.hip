@@ -34,6 +34,7 @@ struct GemmParams {
   int64_t n_out;        // rows of y / of the neighbour table
   int64_t n_virtual;    // rows iterated (== n_out without a permutation)
   int ldx, cin, ldy, cout, K, flip_k, kper, stagger;
+  int accumulate;  // y += result instead of y = result (un-split launches whose rows are visited at most once)
   float *stats;  // optional [row tiles][2][cout]: per-tile column (sum, sum of squares) of y (un-split launches only)
 };
 
@@ -648,7 +649,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
   for (int r = 0; r < 16; ++r) {
     const int64_t row = s_orow[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
     if (row >= 0) {
-      const float va = acc0[r] + bias_a, vb = acc1[r] + bias_b;
+      float va = acc0[r] + bias_a, vb = acc1[r] + bias_b;
+      if (p.accumulate) {  // (uniform) scatter-accumulate: each output row belongs to at most one tile row
+        if (c_a < p.cout) va += dst[row * ldd + c_a];
+        if (c_b < p.cout) vb += dst[row * ldd + c_b];
+      }
       if (c_a < p.cout) dst[row * ldd + c_a] = va;
       if (c_b < p.cout) dst[row * ldd + c_b] = vb;
       sa += va, qa += va * va, sb += vb, qb += vb * vb;
@@ -1319,13 +1324,14 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   MINK_REQUIRE(x && w && nbr && y, "gather_gemm: NULL pointer");
   MINK_REQUIRE(ksplit == 1 || workspace, "gather_gemm: split-K needs a workspace");
   if (!row_perm) n_virtual = n_out;
-  MINK_REQUIRE(n_virtual >= n_out, "gather_gemm: the row permutation must cover every output row");
+  MINK_REQUIRE(n_virtual >= n_out || (flip_k & 2), "gather_gemm: the row permutation must cover every output row");
   ScopedTimer timer(w_transposed ? 1 : 0, /*n_in (rows of x) is not known here*/ -1, n_out, K, cin, cout, nbr, (hipStream_t)stream);
   GemmParams p;
   p.row_perm = row_perm, p.n_virtual = n_virtual;
   p.stagger = g_stagger;
   p.x = x, p.w = w, p.nbr = nbr, p.bias = bias, p.y = y, p.ws = workspace;
-  p.n_out = n_out, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K, p.flip_k = flip_k;
+  p.n_out = n_out, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K, p.flip_k = flip_k & 1;
+  p.accumulate = (flip_k >> 1) & 1;
   p.kper = (int)cdiv(K, ksplit);
   p.stats = nullptr;
   const int zs = (int)cdiv(K, p.kper);
@@ -1333,6 +1339,9 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   hipStream_t st = (hipStream_t)stream;
   const bool al = (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && (ldx & 3) == 0 && (cin & 3) == 0;
   const bool vec = al && (w_transposed ? true : (cout & 3) == 0);
+  MINK_REQUIRE(!p.accumulate || (zs == 1 && vec && g_pipeline && !stats_out),
+               "gather_gemm: accumulation needs an un-split launch of the pipelined kernel (16-byte aligned operands)");
+  flip_k &= 1;
   const bool want_stats = stats_out && stats_rows && stats_ws && !row_perm && !w_transposed;
   const bool stats_direct = want_stats && zs == 1 && vec && g_pipeline;  // conv epilogue -> per-tile partials -> stage 2
   const bool stats_split = want_stats && zs > 1 && (cout & 3) == 0 && cout <= 1024 && (ldy & 3) == 0 &&

@@ -144,8 +144,8 @@ int64_t mink_block_workspace_bytes(int64_t n_in, int64_t n_out, int32_t cin, int
 }
 
 int64_t mink_block_grad_scratch_floats(int64_t n_in, int64_t n_out, int32_t cin, int32_t cout, int32_t has_down) {
-  // g_y2, g_res, g_h1, g_y1 [n_out][cout]; g_xa [n_in][cin]; with a down path: g_yd [n_out][cout], g_xb [n_in][cin]
-  return (4 + (has_down ? 1 : 0)) * n_out * cout + (1 + (has_down ? 1 : 0)) * n_in * cin + 64;
+  // g_y2, g_res, g_h1, g_y1 [n_out][cout]; identity shortcut: g_xa [n_in][cin]; with a down path: g_yd [n_out][cout]
+  return (4 + (has_down ? 1 : 0)) * n_out * cout + (has_down ? 0 : 1) * n_in * cin + 64;
 }
 
 int mink_stem_supported(int64_t n, int32_t cin, int32_t cout, int32_t K) {
@@ -229,15 +229,16 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
   const Lane branch{br, br == st ? ex->ws_compute : ex->ws_branch, ex->ws_bytes};
   const Lane weight{wst, wst == st ? ex->ws_compute : ex->ws_wgrad, ex->ws_bytes};
   const int64_t no = b->n_out * C, ni = b->n_in * cin;
-  float *g_y2 = b->g_tmp, *g_res = g_y2 + no, *g_h1 = g_res + no, *g_y1 = g_h1 + no, *g_xa = g_y1 + no;
-  float *g_yd = g_xa + ni, *g_xb = g_yd + no;
+  float *g_y2 = b->g_tmp, *g_res = g_y2 + no, *g_h1 = g_res + no, *g_y1 = g_h1 + no;
+  float *g_xa = g_y1 + no;  // identity shortcut only (then g_x = g_xa + g_res)
+  float *g_yd = g_y1 + no;  // down path only
   const int64_t bn_bytes = mink_bn_workspace_bytes(b->n_out, C);
-  MINK_REQUIRE(ex->ws_compute && ex->ws_bytes > bn_bytes + 256, "block_backward: scratch too small");
+  MINK_REQUIRE(ex->ws_compute && ex->ws_bytes > 2 * bn_bytes + 256, "block_backward: scratch too small");
   const bool want_gx = b->g_x != nullptr;
   // out = relu(norm2(y2) + shortcut)
   TRY(mink_bn_bwd(b->g_out, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, 1, g_y2, g_res,
                   b->norm2.dgamma, b->norm2.dbeta, compute.ws, st));
-  if (down) {  // shortcut branch beside the main one
+  if (down) {  // shortcut branch beside the main one: its norm and its weight gradient
     TRY(check_conv(b->down, "block_backward downsample", true));
     TRY(check_norm(b->normd, "block_backward downsample norm", true));
     MINK_REQUIRE(b->yd && branch.ws, "block_backward: bad downsample path");
@@ -246,16 +247,22 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
     const Lane bl = br == st ? branch.after(bn_bytes) : branch;
     TRY(mink_bn_bwd(g_res, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
                     b->normd.dgamma, b->normd.dbeta, bl.ws, br));
-    TRY(conv_backward(b->down, b->x, b->n_in, b->n_out, g_yd, want_gx ? g_xb : nullptr, bl.after(bn_bytes), weight, 3));
+    TRY(conv_backward(b->down, b->x, b->n_in, b->n_out, g_yd, nullptr, bl.after(bn_bytes), weight, 3));
   }
   const Lane rest = compute.after(2 * bn_bytes);
   TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, 4));
   TRY(mink_bn_bwd(g_h1, b->y1, b->h1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr,
                   b->norm1.dgamma, b->norm1.dbeta, compute.ws, st));
-  TRY(conv_backward(b->conv1, b->x, b->n_in, b->n_out, g_y1, want_gx ? g_xa : nullptr, rest, weight, 5));
+  TRY(conv_backward(b->conv1, b->x, b->n_in, b->n_out, g_y1, want_gx ? (down ? b->g_x : g_xa) : nullptr, rest, weight, 5));
   if (!want_gx) return MINK_OK;
-  if (down) TRY(order_after(st, br, 6));
-  return mink_eltwise(g_xa, down ? g_xb : g_res, ni, 2, b->g_x, st);
+  if (!down) return mink_eltwise(g_xa, g_res, ni, 2, b->g_x, st);
+  // The shortcut convolution (kernel volume 1, stride 2) reaches only the input voxels that sit on an output
+  // coordinate -- about one row in eight.  Its data gradient is ADDED into those rows of g_x: tile row v = output row
+  // o, written row = the input row under it (the forward table's only column), gathered operand = g_yd[o].
+  MINK_REQUIRE(b->down.K == 1 && b->down.nbr_t, "block_backward: the shortcut convolution must have kernel volume 1");
+  TRY(order_after(st, br, 6));
+  return mink_conv_gather_gemm(g_yd, C, C, b->down.w, 1, /*accumulate*/ 2, b->down.nbr_t, b->n_in, 1, b->down.nbr, b->n_out, b->g_x,
+                               cin, cin, nullptr, 1, nullptr, st);
 }
 
 }  // extern "C"

@@ -28,7 +28,11 @@ import torch.distributed as dist
 class BucketedGradAllReduce:
     def __init__(self, module, bucket_bytes=8 << 20, process_group=None, force=False):
         """`force`: run the whole machinery (hooks, gradient sink, collectives) in a one-rank group too -- for measuring
-        its overhead on a single GPU (bench.py BENCH_FORCE_REDUCER=1)."""
+        its overhead on a single GPU (bench.py BENCH_FORCE_REDUCER=1).
+
+        With one rank (and no `force`) only the flat gradient buffer is kept: the backward kernels write the
+        gradients straight into it (gradient sink), there are no hooks and no collectives -- one GPU and N GPUs run
+        the same step, the collectives being the only difference."""
         self.group = process_group
         self.force = bool(force)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -85,13 +89,17 @@ class BucketedGradAllReduce:
         self._pending = []
         self._written = set()  # parameters whose gradient was written in place this step
         self._counted = set()  # parameters already counted towards their bucket this step
-        if self.world > 1 or self.force:
+        self._collect = self.world > 1 or self.force  # buckets are all-reduced
+        if self._collect:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if self._collect or dev.type == "cuda":
             if dev.type == "cuda":
                 from .minkowski import functional as Fn
 
-                if os.environ.get("MINK_DP_MULTISTREAM", "1") == "0":  # conservative schedule: compute + prepare streams only
+                if not self._collect:
+                    Fn.set_grad_sink(self)
+                elif os.environ.get("MINK_DP_MULTISTREAM", "1") == "0":  # conservative schedule: compute + prepare streams only
                     Fn.set_wgrad_overlap(False)
                     Fn.set_branch_fork(False)
                 else:
@@ -107,7 +115,7 @@ class BucketedGradAllReduce:
         # RCCL averages inside the collective; gloo (CPU tests, rehearsals) sums and finish() scales
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        self._active = self.world > 1 or self.force
+        self._active = self._collect or dev.type == "cuda"
 
     # ---- gradient sink protocol (minkowski.functional.set_grad_sink)
     def view_for(self, p):
@@ -156,6 +164,8 @@ class BucketedGradAllReduce:
         self._work.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
 
     def _on_grad(self, p):
+        if not self._collect:
+            return
         k = id(p)
         if k in self._counted:  # a gradient written in place is reported by the kernel launcher AND (on
             return              # some torch versions) by the post-accumulate hook of the undefined grad
@@ -197,7 +207,7 @@ class BucketedGradAllReduce:
     def finish(self):
         """Wait for the outstanding collectives (launching any bucket whose parameters did not
         all receive a gradient this step), then turn the sum into the mean."""
-        if self.world == 1 and not self.force:
+        if not self._collect:
             return
         self.flush()
         for b in range(len(self.buckets)):
