@@ -126,6 +126,23 @@ typedef struct MinkKernelMapDesc {
   int32_t *nbr_t; /* may be NULL */
   int32_t K;
   int32_t offsets[81]; /* [K][3], scaled by dilation * input tensor stride */
+  /* Optional block index of the INPUT map (blk_table != NULL): neighbour look-ups go through a second, much smaller
+   * hash map keyed by the 4x4x4-cell BLOCK of a coordinate instead of through the per-voxel map.  A block entry
+   * holds the occupancy mask of its 64 cells and the start of its run in `blk_rowids`; the row of a cell is
+   * blk_rowids[base + popcount(mask below the cell)].  The 27 neighbours of a voxel fall into at most 8 blocks and
+   * neighbouring voxels share them, so a wave touches a handful of cache lines where the per-voxel map (one random
+   * 64-byte line for the key and one for the value, per probe) touched thousands: 1.5 GB of HBM traffic per stem table
+   * became the size of the table itself.  Results are identical (bit-exact tables).  Descriptors that share an input
+   * map share the buffers; exactly the first of them sets blk_build = 1 and the index is built by that call. */
+  const int32_t *in_coords; /* [n_in][4] rows of the input map */
+  int32_t in_ts;            /* its tensor stride (cells are coordinates / in_ts) */
+  int32_t blk_build;
+  uint64_t *blk_table;      /* [blk_cap][2]: block key, inverted occupancy mask */
+  int32_t *blk_base;        /* [blk_cap] */
+  int32_t *blk_slot;        /* [n_in] scratch: block slot of every input row */
+  int32_t *blk_rowids;      /* [n_in] */
+  int32_t *blk_counter;     /* one int32 of scratch */
+  int64_t blk_cap;          /* power of two >= 2 * n_in */
 } MinkKernelMapDesc;
 int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *descs, void *stream);
 

@@ -18,7 +18,9 @@ class KernelMapDesc(ctypes.Structure):
     """MinkKernelMapDesc of include/mink_hip.h"""
 
     _fields_ = [("in_table_keys", _p), ("in_table_vals", _p), ("in_cap", _i64), ("out_coords", _p), ("n_out", _i64),
-                ("n_in", _i64), ("nbr", _p), ("nbr_t", _p), ("K", _i32), ("offsets", _i32 * 81)]
+                ("n_in", _i64), ("nbr", _p), ("nbr_t", _p), ("K", _i32), ("offsets", _i32 * 81),
+                ("in_coords", _p), ("in_ts", _i32), ("blk_build", _i32), ("blk_table", _p), ("blk_base", _p), ("blk_slot", _p),
+                ("blk_rowids", _p), ("blk_counter", _p), ("blk_cap", _i64)]
 
 
 class ConvLayer(ctypes.Structure):

@@ -187,6 +187,101 @@ __global__ __launch_bounds__(kBlock) void kernel_map_kernel(const uint64_t *__re
   if (nbr_t && v >= 0) nbr_t[(int64_t)v * K + k] = (int)o;
 }
 
+// ------------------------------------------------------------------------ block index
+// Block key of a coordinate at tensor stride ts: cell = coordinate / ts (exact for map rows, floor for safety),
+// block = cell >> 2 per axis (on the biased 16-bit value, so negative coordinates floor correctly), packed like a
+// voxel key; `local` = position of the cell inside its 4x4x4 block (x fastest).
+__device__ __forceinline__ bool block_key(int b, int x, int y, int z, int ts, uint64_t &key, int &local) {
+  if (ts > 1) x = floor_to(x, ts) / ts, y = floor_to(y, ts) / ts, z = floor_to(z, ts) / ts;
+  const unsigned ux = (unsigned)(x + 32768), uy = (unsigned)(y + 32768), uz = (unsigned)(z + 32768);
+  const bool ok = ((unsigned)b <= 65534u) && ux <= 65535u && uy <= 65535u && uz <= 65535u;
+  key = ((uint64_t)(unsigned)b << 48) | ((uint64_t)(ux >> 2) << 32) | ((uint64_t)(uy >> 2) << 16) | (uint64_t)(uz >> 2);
+  local = (int)((ux & 3u) | ((uy & 3u) << 2) | ((uz & 3u) << 4));
+  return ok;
+}
+
+__global__ __launch_bounds__(kBlock) void blk_insert_kernel(const int *__restrict__ coords, int64_t n, int ts,
+                                                            unsigned long long *table, uint64_t mask,
+                                                            int *__restrict__ slot_of_row) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+  uint64_t key;
+  int local;
+  block_key(c.x, c.y, c.z, c.w, ts, key, local);  // rows of a map are always in range
+  uint64_t s = mix64(key) & mask;
+  for (;;) {
+    const unsigned long long prev = atomicCAS(&table[2 * s], (unsigned long long)kEmptyKey, (unsigned long long)key);
+    if (prev == kEmptyKey || prev == key) break;
+    s = (s + 1) & mask;
+  }
+  atomicAnd(&table[2 * s + 1], ~(1ull << local));  // the mask is kept inverted: the 0xFF fill of the table means "empty"
+  slot_of_row[i] = (int)s;
+}
+
+// One row per block (the one in its lowest occupied cell) reserves the block's run of `rowids`.  The order of the
+// runs depends on the order the leaders arrive in; the look-up result does not.
+__global__ __launch_bounds__(kBlock) void blk_leader_kernel(const int *__restrict__ coords, int64_t n, int ts,
+                                                            const unsigned long long *__restrict__ table,
+                                                            const int *__restrict__ slot_of_row, int *__restrict__ base,
+                                                            int *counter) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+  uint64_t key;
+  int local;
+  block_key(c.x, c.y, c.z, c.w, ts, key, local);
+  const int s = slot_of_row[i];
+  const unsigned long long m = ~table[2 * (int64_t)s + 1];
+  if (local == __builtin_ctzll(m)) base[s] = atomicAdd(counter, __popcll(m));
+}
+
+__global__ __launch_bounds__(kBlock) void blk_fill_kernel(const int *__restrict__ coords, int64_t n, int ts,
+                                                          const unsigned long long *__restrict__ table,
+                                                          const int *__restrict__ slot_of_row,
+                                                          const int *__restrict__ base, int *__restrict__ rowids) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+  uint64_t key;
+  int local;
+  block_key(c.x, c.y, c.z, c.w, ts, key, local);
+  const int s = slot_of_row[i];
+  const unsigned long long m = ~table[2 * (int64_t)s + 1];
+  rowids[base[s] + __popcll(m & ((1ull << local) - 1ull))] = (int)i;
+}
+
+// Same result as kernel_map_kernel, through the block index.  Thread per (output row, offset): the 27 look-ups of a
+// row sit in adjacent lanes and hit the same one to eight block entries.
+__global__ __launch_bounds__(kBlock) void kernel_map_blk_kernel(const unsigned long long *__restrict__ table,
+                                                                const int *__restrict__ base,
+                                                                const int *__restrict__ rowids, uint64_t mask, int ts,
+                                                                const int *__restrict__ out_coords, int64_t n_out, int K,
+                                                                Offsets off, int *__restrict__ nbr, int *nbr_t) {
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n_out * K) return;
+  const int64_t o = idx / K;
+  const int k = (int)(idx - o * K);
+  const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];
+  uint64_t key;
+  int local, v = -1;
+  if (block_key(c.x, c.y + off.d[3 * k], c.z + off.d[3 * k + 1], c.w + off.d[3 * k + 2], ts, key, local)) {
+    uint64_t s = mix64(key) & mask;
+    for (;;) {
+      const ulonglong2 e = reinterpret_cast<const ulonglong2 *>(table)[s];
+      if (e.x == key) {
+        const unsigned long long m = ~e.y;
+        if ((m >> local) & 1ull) v = rowids[base[s] + __popcll(m & ((1ull << local) - 1ull))];
+        break;
+      }
+      if (e.x == kEmptyKey) break;
+      s = (s + 1) & mask;
+    }
+  }
+  nbr[idx] = v;
+  if (nbr_t && v >= 0) nbr_t[(int64_t)v * K + k] = (int)o;
+}
+
 // -------------------------------------------------------------------------- rulebook
 // Pass 1: pairs per (offset, 256-row chunk); pass 2 (after the scan): fill, ordered by row.
 template <bool FILL>
@@ -504,11 +599,44 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
   MINK_REQUIRE(n >= 0 && (n == 0 || d), "kernel_map_batch: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < n; ++i) {
-    if (d[i].nbr_t && d[i].n_in > 0)
-      MINK_HIP(hipMemsetAsync(d[i].nbr_t, 0xFF, sizeof(int32_t) * d[i].n_in * d[i].K, st));
-    int rc = mink_kernel_map(d[i].in_table_keys, d[i].in_table_vals, d[i].in_cap, d[i].out_coords, d[i].n_out,
-                             d[i].offsets, d[i].K, d[i].nbr, d[i].nbr_t, stream);
-    if (rc) return rc;
+    const MinkKernelMapDesc &e = d[i];
+    if (e.nbr_t && e.n_in > 0) MINK_HIP(hipMemsetAsync(e.nbr_t, 0xFF, sizeof(int32_t) * e.n_in * e.K, st));
+    if (!e.blk_table) {  // per-voxel hash map
+      int rc = mink_kernel_map(e.in_table_keys, e.in_table_vals, e.in_cap, e.out_coords, e.n_out, e.offsets, e.K, e.nbr, e.nbr_t,
+                               stream);
+      if (rc) return rc;
+      continue;
+    }
+    MINK_REQUIRE(e.K >= 1 && e.K <= 27 && e.n_out >= 0 && e.n_in >= 0 && e.n_out * e.K < (1ll << 31) && e.in_ts >= 1,
+                 "kernel_map_batch: bad shape in descriptor %d", i);
+    MINK_REQUIRE(e.blk_cap >= 64 && (e.blk_cap & (e.blk_cap - 1)) == 0 && e.blk_cap >= 2 * e.n_in && e.blk_base && e.blk_slot &&
+                     e.blk_rowids && e.blk_counter && e.in_coords && ((uintptr_t)e.blk_table & 15) == 0,
+                 "kernel_map_batch: bad block-index buffers in descriptor %d", i);
+    if (e.blk_build) {
+      MINK_HIP(hipMemsetAsync(e.blk_table, 0xFF, sizeof(uint64_t) * 2 * e.blk_cap, st));
+      MINK_HIP(hipMemsetAsync(e.blk_counter, 0, sizeof(int32_t), st));
+      if (e.n_in > 0) {
+        const dim3 g((unsigned)cdiv(e.n_in, kBlock));
+        blk_insert_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (unsigned long long *)e.blk_table,
+                                                (uint64_t)e.blk_cap - 1, e.blk_slot);
+        MINK_CHECK_LAUNCH();
+        blk_leader_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table, e.blk_slot,
+                                                e.blk_base, e.blk_counter);
+        MINK_CHECK_LAUNCH();
+        blk_fill_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table, e.blk_slot,
+                                              e.blk_base, e.blk_rowids);
+        MINK_CHECK_LAUNCH();
+      }
+    }
+    if (e.n_out == 0) continue;
+    MINK_REQUIRE(e.out_coords && e.nbr && ((uintptr_t)e.out_coords & 15) == 0, "kernel_map_batch: NULL/misaligned pointer");
+    Offsets off;
+    memset(&off, 0, sizeof off);
+    memcpy(off.d, e.offsets, sizeof(int) * 3 * e.K);
+    kernel_map_blk_kernel<<<dim3((unsigned)cdiv(e.n_out * e.K, kBlock)), kBlock, 0, st>>>(
+        (const unsigned long long *)e.blk_table, e.blk_base, e.blk_rowids, (uint64_t)e.blk_cap - 1, e.in_ts, e.out_coords, e.n_out,
+        e.K, off, e.nbr, e.nbr_t);
+    MINK_CHECK_LAUNCH();
   }
   return MINK_OK;
 }

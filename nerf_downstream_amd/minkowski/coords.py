@@ -163,6 +163,17 @@ class CoordinateManager:
             sizes.append((self.levels[ts_out].n * K, self.levels[ts_in].n * K if transposed else 0))
         pool = torch.empty(sum(a + b for a, b in sizes) + 4, dtype=torch.int32, device=self.device)
         descs = (KernelMapDesc * len(todo))()
+        # block index of every input map that is looked up (4^3-cell blocks: see MinkKernelMapDesc): one buffer set per
+        # input tensor stride, built by the first table that uses it
+        L = lib()
+        blk, need = {}, 0
+        for ts_in in dict.fromkeys(t[0] for t in todo):
+            n_pad = (max(self.levels[ts_in].n, 1) + 1) // 2 * 2  # regions stay 16-byte aligned
+            cap = int(L.mink_table_capacity(self.levels[ts_in].n))
+            blk[ts_in] = [cap, need, True, n_pad]  # capacity, int32 offset into the index pool, still to build
+            need += 4 * cap + cap + 2 * n_pad + 4  # table (2 x int64 per slot), base, slot, rowids, counter (+pad)
+        bpool = torch.empty(need + 4, dtype=torch.int32, device=self.device)
+        bbase_ptr = bpool.data_ptr()
         off = 0
         for d, (ts_in, ts_out, ks, dil, transposed), (na, nb) in zip(descs, todo, sizes):
             lin, lout = self.levels[ts_in], self.levels[ts_out]
@@ -176,8 +187,15 @@ class CoordinateManager:
             d.nbr, d.nbr_t, d.K = nbr.data_ptr(), (nbr_t.data_ptr() if transposed else None), K
             o = kernel_offsets(ks, ts_in, dil).ravel()
             d.offsets[: o.size] = o.tolist()
+            cap, boff, build, n_pad = blk[ts_in]
+            p0 = bbase_ptr + 4 * boff
+            d.in_coords, d.in_ts, d.blk_build, d.blk_cap = lin.coords.data_ptr(), ts_in, int(build), cap
+            d.blk_table, d.blk_base = p0, p0 + 16 * cap
+            d.blk_slot, d.blk_rowids, d.blk_counter = p0 + 20 * cap, p0 + 20 * cap + 4 * n_pad, p0 + 20 * cap + 8 * n_pad
+            blk[ts_in][2] = False
             self.tables[(ts_in, ts_out, ks, dil)] = (nbr, nbr_t)
         check(lib().mink_kernel_map_batch(len(todo), ctypes.cast(descs, ctypes.c_void_p), _stream()))
+        self._blk_pool = bpool  # (scratch of the call; kept until the manager goes so no stream bookkeeping is needed)
 
     def tensors(self):
         out = [self.field_inverse, self.field_unique_index]

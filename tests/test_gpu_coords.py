@@ -150,3 +150,38 @@ def test_decode_plenoxel_batch_matches_oracle(features):
             b = net(net.process_input({"coordinates": coords, "features": feats}))
             c = net(net.process_input({"coordinates": coords.float(), "features": feats}))  # the reference's float field
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("grid,negative,dup", [(16, False, False), (24, True, True), (48, True, False), (128, False, False)])
+def test_block_index_tables_match_oracle(oracle_maps, grid, negative, dup):
+    """The batched table builder looks neighbours up through the 4^3-cell block index (MinkKernelMapDesc.blk_*) instead
+    of the per-voxel hash map: every table of a ResNet pass, transposed ones included, bit-exact against the C oracle
+    -- negative coordinates (blocks must floor, not truncate), duplicates and the full 128^3 shape included."""
+    from nerf_downstream_amd import minkowski as ME
+
+    coords = _noisy_field(9, grid, negative, dup)
+    ME_, tf = _mgr(coords)
+    m = tf.coordinate_manager
+    q = oracle_maps.quantize(coords.numpy())
+    ui, _ = oracle_maps.unique(q)
+    c_ref = {1: q[ui]}
+    keys = {1: ME.CoordinateMapKey(1)}
+    for ts in (2, 4, 8, 16):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+        c_ref[ts], _ = oracle_maps.stride_map(c_ref[ts // 2], ts)
+    ops = [("ktable", 1, 1, 3, 1, False), ("ktable", 1, 2, 2, 1, False), ("ktable", 2, 4, 3, 1, True), ("ktable", 2, 4, 1, 1, True),
+           ("ktable", 4, 4, 3, 1, False), ("ktable", 4, 8, 3, 1, True), ("ktable", 8, 8, 3, 1, False), ("ktable", 8, 16, 1, 1, True),
+           ("ktable", 16, 16, 3, 1, False), ("ktable", 2, 2, 2, 1, True)]
+    m._build_tables_batched(ops)
+    torch.cuda.synchronize()
+    assert len(m.tables) == len(ops)
+    for _, ts_in, ts_out, ks, dil, transposed in ops:
+        off = oracle_maps.kernel_offsets(ks, ts_in)
+        ref = oracle_maps.kernel_map_table(c_ref[ts_in], c_ref[ts_out], off)
+        nbr, nbr_t = m.tables[(ts_in, ts_out, ks, dil)]
+        assert np.array_equal(nbr.cpu().numpy(), ref), (ts_in, ts_out, ks)
+        if transposed:
+            ref_t = np.full((len(c_ref[ts_in]), off.shape[0]), -1, np.int32)
+            o, k = np.nonzero(ref >= 0)
+            ref_t[ref[o, k], k] = o
+            assert np.array_equal(nbr_t.cpu().numpy(), ref_t), (ts_in, ts_out, ks)
