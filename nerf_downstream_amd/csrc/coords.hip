@@ -200,6 +200,16 @@ __device__ __forceinline__ bool block_key(int b, int x, int y, int z, int ts, ui
   return ok;
 }
 
+// 32-bit multiplicative hash of a block key: the look-up kernels are instruction-bound (splitmix64 alone is ~30 VALU
+// instructions in 32-bit hardware), and a block table holds few, well-spread keys
+__device__ __forceinline__ uint64_t blk_hash(uint64_t key) {
+  unsigned h = (unsigned)key * 0x9E3779B1u ^ (unsigned)(key >> 32) * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 13;
+  return h;
+}
+
 __global__ __launch_bounds__(kBlock) void blk_insert_kernel(const int *__restrict__ coords, int64_t n, int ts,
                                                             unsigned long long *table, uint64_t mask,
                                                             int *__restrict__ slot_of_row) {
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void blk_insert_kernel(const int *__restric
   uint64_t key;
   int local;
   block_key(c.x, c.y, c.z, c.w, ts, key, local);  // rows of a map are always in range
-  uint64_t s = mix64(key) & mask;
+  uint64_t s = blk_hash(key) & mask;
   for (;;) {
     const unsigned long long prev = atomicCAS(&table[2 * s], (unsigned long long)kEmptyKey, (unsigned long long)key);
     if (prev == kEmptyKey || prev == key) break;
@@ -220,20 +230,48 @@ __global__ __launch_bounds__(kBlock) void blk_insert_kernel(const int *__restric
 }
 
 // One row per block (the one in its lowest occupied cell) reserves the block's run of `rowids`.  The order of the
-// runs depends on the order the leaders arrive in; the look-up result does not.
-__global__ __launch_bounds__(kBlock) void blk_leader_kernel(const int *__restrict__ coords, int64_t n, int ts,
-                                                            const unsigned long long *__restrict__ table,
-                                                            const int *__restrict__ slot_of_row, int *__restrict__ base,
-                                                            int *counter) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
+// runs depends on the order the workgroups arrive in; the look-up result does not.  One atomic per 1024-thread
+// workgroup: a single word takes ~90 atomics per microsecond, so 70 k block leaders -- or 13 k waves -- adding to it
+// one by one would serialise for longer than the rest of the build takes.
+constexpr int kLeaderBlock = 1024;
+__global__ __launch_bounds__(kLeaderBlock) void blk_leader_kernel(const int *__restrict__ coords, int64_t n, int ts,
+                                                                   const unsigned long long *__restrict__ table,
+                                                                   const int *__restrict__ slot_of_row,
+                                                                   int *__restrict__ base, int *counter) {
+  __shared__ int s_wave[kLeaderBlock / 64];
+  __shared__ int s_start;
+  const int64_t i0 = (int64_t)blockIdx.x * kLeaderBlock + threadIdx.x;
+  const bool live = i0 < n;
+  const int64_t i = live ? i0 : n - 1;  // (idle lanes shadow the last row and never lead: whole waves reach the shuffles)
   const int4 c = reinterpret_cast<const int4 *>(coords)[i];
   uint64_t key;
   int local;
   block_key(c.x, c.y, c.z, c.w, ts, key, local);
+  if (!live) local = -1;
   const int s = slot_of_row[i];
   const unsigned long long m = ~table[2 * (int64_t)s + 1];
-  if (local == __builtin_ctzll(m)) base[s] = atomicAdd(counter, __popcll(m));
+  const bool leader = local == __builtin_ctzll(m);
+  const int cnt = leader ? __popcll(m) : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int w = 0; w < kLeaderBlock / 64; ++w) {
+      const int t = s_wave[w];
+      s_wave[w] = run;
+      run += t;
+    }
+    s_start = run > 0 ? atomicAdd(counter, run) : 0;
+  }
+  __syncthreads();
+  if (leader) base[s] = s_start + s_wave[wave] + incl - cnt;
 }
 
 __global__ __launch_bounds__(kBlock) void blk_fill_kernel(const int *__restrict__ coords, int64_t n, int ts,
@@ -266,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void kernel_map_blk_kernel(const unsigned l
   uint64_t key;
   int local, v = -1;
   if (block_key(c.x, c.y + off.d[3 * k], c.z + off.d[3 * k + 1], c.w + off.d[3 * k + 2], ts, key, local)) {
-    uint64_t s = mix64(key) & mask;
+    uint64_t s = blk_hash(key) & mask;
     for (;;) {
       const ulonglong2 e = reinterpret_cast<const ulonglong2 *>(table)[s];
       if (e.x == key) {
@@ -280,6 +318,85 @@ __global__ __launch_bounds__(kBlock) void kernel_map_blk_kernel(const unsigned l
   }
   nbr[idx] = v;
   if (nbr_t && v >= 0) nbr_t[(int64_t)v * K + k] = (int)o;
+}
+
+// The 3^3 neighbourhood of one output row per THREAD (unit offsets in input cells: every 3x3x3 convolution of the
+// network, strided or not).  The 27 cells lie in at most 2x2x2 blocks -- A = block of (cell - 1), B = block of
+// (cell + 1) per axis -- so the thread probes eight block entries and answers all 27 look-ups from their masks with
+// bit tests and popcounts: ~20 instructions per neighbour instead of ~300 for one probe chain each.  Results are
+// staged in LDS and written as one contiguous run per workgroup.
+template <bool HAS_T>
+__global__ __launch_bounds__(kBlock) void kernel_map_blk27_kernel(const unsigned long long *__restrict__ table,
+                                                                  const int *__restrict__ base,
+                                                                  const int *__restrict__ rowids, uint64_t mask, int ts,
+                                                                  const int *__restrict__ out_coords, int64_t n_out,
+                                                                  int *__restrict__ nbr, int *nbr_t) {
+  __shared__ int s_out[kBlock * 27];
+  const int64_t o0 = (int64_t)blockIdx.x * kBlock;
+  const int64_t o = o0 + threadIdx.x;
+  const bool live = o < n_out;
+  const int4 c = reinterpret_cast<const int4 *>(out_coords)[live ? o : n_out - 1];
+  int cx = c.y, cy = c.z, cz = c.w;
+  if (ts > 1) cx = floor_to(cx, ts) / ts, cy = floor_to(cy, ts) / ts, cz = floor_to(cz, ts) / ts;
+  const int u[3] = {cx + 32768, cy + 32768, cz + 32768};  // 0..65535 for rows of a map; neighbours may step outside
+  const bool b_ok = (unsigned)c.x <= 65534u;
+  // block entries: index = ix + 2 iy + 4 iz, i = 0 -> block of (u - 1), 1 -> block of (u + 1)
+  unsigned long long M[8];
+  int B[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int nx = u[0] + ((q & 1) ? 1 : -1), ny = u[1] + ((q & 2) ? 1 : -1), nz = u[2] + ((q & 4) ? 1 : -1);
+    M[q] = 0ull, B[q] = 0;
+    if (b_ok && (unsigned)nx <= 65535u && (unsigned)ny <= 65535u && (unsigned)nz <= 65535u) {
+      const uint64_t key = ((uint64_t)(unsigned)c.x << 48) | ((uint64_t)((unsigned)nx >> 2) << 32) |
+                           ((uint64_t)((unsigned)ny >> 2) << 16) | (uint64_t)((unsigned)nz >> 2);
+      uint64_t s = blk_hash(key) & mask;
+      for (;;) {
+        const ulonglong2 e = reinterpret_cast<const ulonglong2 *>(table)[s];
+        if (e.x == key) {
+          M[q] = ~e.y, B[q] = base[s];
+          break;
+        }
+        if (e.x == kEmptyKey) break;
+        s = (s + 1) & mask;
+      }
+    }
+  }
+  // the centre cell of an axis shares block A unless it sits on the low face of its block (then it is in B)
+  const bool cB[3] = {(u[0] & 3) == 0, (u[1] & 3) == 0, (u[2] & 3) == 0};
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int d[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
+    // select the block entry: per axis bit = 1 (B) for d = +1, 0 (A) for d = -1, cB for d = 0
+    unsigned long long m;
+    int bs;
+    {
+      unsigned long long mx[4];
+      int bx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // x axis resolved: entries over (iy, iz)
+        const bool sel = d[0] > 0 || (d[0] == 0 && cB[0]);
+        mx[j] = sel ? M[2 * j + 1] : M[2 * j];
+        bx[j] = sel ? B[2 * j + 1] : B[2 * j];
+      }
+      const bool sy = d[1] > 0 || (d[1] == 0 && cB[1]);
+      const unsigned long long my0 = sy ? mx[1] : mx[0], my1 = sy ? mx[3] : mx[2];
+      const int by0 = sy ? bx[1] : bx[0], by1 = sy ? bx[3] : bx[2];
+      const bool sz = d[2] > 0 || (d[2] == 0 && cB[2]);
+      m = sz ? my1 : my0;
+      bs = sz ? by1 : by0;
+    }
+    const int local = ((u[0] + d[0]) & 3) | (((u[1] + d[1]) & 3) << 2) | (((u[2] + d[2]) & 3) << 4);
+    int v = -1;
+    if ((m >> local) & 1ull) v = rowids[bs + __popcll(m & ((1ull << local) - 1ull))];
+    if (!live) v = -1;
+    s_out[threadIdx.x * 27 + k] = v;
+    if (HAS_T && v >= 0) nbr_t[(int64_t)v * 27 + k] = (int)o;
+  }
+  __syncthreads();
+  const int64_t rows = n_out - o0 < kBlock ? n_out - o0 : kBlock;
+  const int total = (int)rows * 27;
+  for (int e = threadIdx.x; e < total; e += kBlock) nbr[o0 * 27 + e] = s_out[e];
 }
 
 // -------------------------------------------------------------------------- rulebook
@@ -620,8 +737,8 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
         blk_insert_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (unsigned long long *)e.blk_table,
                                                 (uint64_t)e.blk_cap - 1, e.blk_slot);
         MINK_CHECK_LAUNCH();
-        blk_leader_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table, e.blk_slot,
-                                                e.blk_base, e.blk_counter);
+        blk_leader_kernel<<<dim3((unsigned)cdiv(e.n_in, kLeaderBlock)), kLeaderBlock, 0, st>>>(
+            e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table, e.blk_slot, e.blk_base, e.blk_counter);
         MINK_CHECK_LAUNCH();
         blk_fill_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table, e.blk_slot,
                                               e.blk_base, e.blk_rowids);
@@ -633,6 +750,23 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
     Offsets off;
     memset(&off, 0, sizeof off);
     memcpy(off.d, e.offsets, sizeof(int) * 3 * e.K);
+    bool unit27 = e.K == 27;  // offsets == {-1,0,1}^3 * in_ts, x fastest: the 3x3x3 convolutions
+    for (int k = 0; k < 27 && unit27; ++k)
+      unit27 = off.d[3 * k] == (k % 3 - 1) * e.in_ts && off.d[3 * k + 1] == ((k / 3) % 3 - 1) * e.in_ts &&
+               off.d[3 * k + 2] == (k / 9 - 1) * e.in_ts;
+    if (unit27) {
+      const dim3 g((unsigned)cdiv(e.n_out, kBlock));
+      if (e.nbr_t)
+        kernel_map_blk27_kernel<true><<<g, kBlock, 0, st>>>((const unsigned long long *)e.blk_table, e.blk_base, e.blk_rowids,
+                                                           (uint64_t)e.blk_cap - 1, e.in_ts, e.out_coords, e.n_out, e.nbr,
+                                                           e.nbr_t);
+      else
+        kernel_map_blk27_kernel<false><<<g, kBlock, 0, st>>>((const unsigned long long *)e.blk_table, e.blk_base, e.blk_rowids,
+                                                            (uint64_t)e.blk_cap - 1, e.in_ts, e.out_coords, e.n_out, e.nbr,
+                                                            nullptr);
+      MINK_CHECK_LAUNCH();
+      continue;
+    }
     kernel_map_blk_kernel<<<dim3((unsigned)cdiv(e.n_out * e.K, kBlock)), kBlock, 0, st>>>(
         (const unsigned long long *)e.blk_table, e.blk_base, e.blk_rowids, (uint64_t)e.blk_cap - 1, e.in_ts, e.out_coords, e.n_out,
         e.K, off, e.nbr, e.nbr_t);

@@ -159,7 +159,7 @@ def _fit(ME, device, probe_steps=(), probe=None):
             probe(step, model, b, loss)
         opt.step()
         sched.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     return model, np.array(losses)
 
 
@@ -238,30 +238,18 @@ def test_fixed_split_top1_matches_oracle(oracle_maps):
     assert abs(lh[-20:].mean() - lo[-20:].mean()) < 0.1
 
 
-def test_reference_training_does_not_reproduce_itself(oracle_maps):
+def test_reference_training_does_not_reproduce_itself(oracle_maps, monkeypatch):
     """Why the fixed-split criterion above is not "identical trajectories": the CPU oracle alone, run with two thread
-    counts (only its summation order changes), leaves its own trajectory within a dozen steps."""
-    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    counts (only its summation order changes), leaves its own trajectory within a dozen steps of the same recipe."""
     from oracle import me_cpu as OME
 
-    coords, feats = batch_scenes(list(range(60, 68)), grid=32, cin=28)
-    labels = torch.arange(8) * 5 % 51
+    monkeypatch.setitem(SPLIT, "grid", 32)
+    monkeypatch.setitem(SPLIT, "steps", 30)
     traj = {}
     for threads in (8, 3):
         torch.set_num_threads(threads)
         oracle_maps.set_threads(threads)
-        torch.manual_seed(11)
-        m = get_model("ResNet14", 28, 51, ME=OME)
-        opt = torch.optim.SGD(m.parameters(), lr=0.003, momentum=0.9, weight_decay=1e-4)
-        out = []
-        for step in range(24):
-            sel = torch.randperm(coords.shape[0], generator=torch.Generator().manual_seed(step))[: coords.shape[0] * 3 // 4].sort().values
-            opt.zero_grad(set_to_none=True)
-            loss = F.cross_entropy(m(m.process_input({"coordinates": coords[sel], "features": feats[sel]})), labels)
-            loss.backward()
-            opt.step()
-            out.append(float(loss))
-        traj[threads] = np.array(out)
+        traj[threads] = _fit(OME, torch.device("cpu"))[1]
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     oracle_maps.set_threads(min(16, os.cpu_count() or 1))
     d = np.abs(traj[8] - traj[3])
