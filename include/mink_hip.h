@@ -328,6 +328,15 @@ int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32
                           const int32_t *in2out, float *dx, float *dgamma, float *dbeta,
                           void *workspace, void *stream);
 
+/* Max pooling over a neighbour table whose windows may overlap -- the 3x3 stride-2 pooling of the dense 2-D
+ * comparison network (torchvision ResNet, reference co3d_2d/src/model/models.py:18-23), also ME.MinkowskiMaxPooling.
+ * arg[n_out][C] receives the input row of each maximum; backward gathers through the transposed table nbr_t[n_in][K]
+ * (the windows containing a row), so there are no atomics. */
+int mink_pool_max_fwd(const float *x, int32_t C, const int32_t *nbr, int64_t n_out, int32_t K, float *y, int32_t *arg,
+                      void *stream);
+int mink_pool_max_bwd(const float *dy, const int32_t *arg, int32_t C, const int32_t *nbr_t, int64_t n_in, int32_t K,
+                      float *dx, void *stream);
+
 /* Elementwise: mode 0: y = max(x,0); mode 1: dx = (y>0) ? dy : 0 (a=dy,b=y);
  * mode 2: y = a + b. */
 int mink_eltwise(const float *a, const float *b, int64_t count, int32_t mode, float *y, void *stream);

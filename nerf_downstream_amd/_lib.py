@@ -112,6 +112,8 @@ SIGNATURES = {
     ),
     "mink_pool_sum_fwd": (ctypes.c_int, [_p, _i32, _i32, _p, _i64, _i32, _p, _p]),
     "mink_pool_sum_bwd": (ctypes.c_int, [_p, _i32, _p, _i64, _p, _p]),
+    "mink_pool_max_fwd": (ctypes.c_int, [_p, _i32, _p, _i64, _i32, _p, _p, _p]),
+    "mink_pool_max_bwd": (ctypes.c_int, [_p, _p, _i32, _p, _i64, _i32, _p, _p]),
     "mink_global_avg_fwd": (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p]),
     "mink_global_avg_bwd": (ctypes.c_int, [_p, _i32, _p, _i32, _i64, _p, _p]),
     "mink_segment_mean": (ctypes.c_int, [_p, _i32, _i32, _p, _p, _i64, _p, _p]),

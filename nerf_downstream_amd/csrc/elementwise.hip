@@ -391,6 +391,52 @@ __global__ __launch_bounds__(EB) void pool_sum_bwd_kernel(const float *__restric
   st4(dx + i * (int64_t)(4 * C4) + c, ld4(dy + (int64_t)in2out[i] * (4 * C4) + c));
 }
 
+// Max pooling over a neighbour table (overlapping windows allowed: the dense 2-D baseline's 3x3 stride-2 pooling).
+// arg[o][c] = input row holding the maximum (the first one in offset order, as torch's window scan picks it).
+__global__ __launch_bounds__(EB) void pool_max_fwd_kernel(const float *__restrict__ x, int C4, const int *__restrict__ nbr,
+                                                          int64_t n_out, int K, float *__restrict__ y, int *__restrict__ arg) {
+  const int64_t idx = (int64_t)blockIdx.x * EB + threadIdx.x;
+  if (idx >= n_out * C4) return;
+  const int64_t o = idx / C4;
+  const int c = (int)(idx - o * C4) * 4;
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  int4 a = make_int4(-1, -1, -1, -1);
+  for (int k = 0; k < K; ++k) {
+    const int i = nbr[o * K + k];
+    if (i >= 0) {
+      const float4 v = ld4(x + (int64_t)i * (4 * C4) + c);
+      if (v.x > m.x || a.x < 0) m.x = v.x, a.x = i;  // (a NaN never wins, like torch keeps the first element then)
+      if (v.y > m.y || a.y < 0) m.y = v.y, a.y = i;
+      if (v.z > m.z || a.z < 0) m.z = v.z, a.z = i;
+      if (v.w > m.w || a.w < 0) m.w = v.w, a.w = i;
+    }
+  }
+  st4(y + o * (int64_t)(4 * C4) + c, m);
+  *reinterpret_cast<int4 *>(arg + o * (int64_t)(4 * C4) + c) = a;
+}
+
+// dx[i][c] = sum of dy[o][c] over the windows o that contain i and chose it (gathered through the transposed table:
+// no atomics, one owner per element)
+__global__ __launch_bounds__(EB) void pool_max_bwd_kernel(const float *__restrict__ dy, const int *__restrict__ arg, int C4,
+                                                          const int *__restrict__ nbr_t, int64_t n_in, int K,
+                                                          float *__restrict__ dx) {
+  const int64_t idx = (int64_t)blockIdx.x * EB + threadIdx.x;
+  if (idx >= n_in * C4) return;
+  const int64_t i = idx / C4;
+  const int c = (int)(idx - i * C4) * 4;
+  float4 s = make_float4(0, 0, 0, 0);
+  for (int k = 0; k < K; ++k) {
+    const int o = nbr_t[i * K + k];
+    if (o >= 0) {
+      const int4 a = *reinterpret_cast<const int4 *>(arg + (int64_t)o * (4 * C4) + c);
+      const float4 g = ld4(dy + (int64_t)o * (4 * C4) + c);
+      s.x += a.x == (int)i ? g.x : 0.f, s.y += a.y == (int)i ? g.y : 0.f;
+      s.z += a.z == (int)i ? g.z : 0.f, s.w += a.w == (int)i ? g.w : 0.f;
+    }
+  }
+  st4(dx + i * (int64_t)(4 * C4) + c, s);
+}
+
 // one workgroup per (batch, 64-channel slab): 16 float4 columns x 16 row lanes
 __global__ __launch_bounds__(EB) void global_avg_fwd_kernel(const float *__restrict__ x, int C,
                                                             const int *__restrict__ boff, float *__restrict__ y) {
@@ -702,6 +748,34 @@ int mink_pool_sum_bwd(const float *dy, int32_t C, const int32_t *in2out, int64_t
   REQ_A16(dx, "pool_sum_bwd");
   pool_sum_bwd_kernel<<<dim3((unsigned)cdiv(n_in * (C >> 2), EB)), EB, 0, (hipStream_t)stream>>>(dy, C >> 2, in2out,
                                                                                                 n_in, dx);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_pool_max_fwd(const float *x, int32_t C, const int32_t *nbr, int64_t n_out, int32_t K, float *y, int32_t *arg,
+                      void *stream) {
+  REQ_C4(C, "pool_max_fwd");
+  MINK_REQUIRE(n_out >= 0 && K >= 1, "pool_max_fwd: bad shape");
+  if (n_out == 0) return MINK_OK;
+  MINK_REQUIRE(x && nbr && y && arg, "pool_max_fwd: NULL pointer");
+  REQ_A16(x, "pool_max_fwd");
+  REQ_A16(y, "pool_max_fwd");
+  REQ_A16(arg, "pool_max_fwd");
+  pool_max_fwd_kernel<<<dim3((unsigned)cdiv(n_out * (C >> 2), EB)), EB, 0, (hipStream_t)stream>>>(x, C >> 2, nbr, n_out, K, y, arg);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_pool_max_bwd(const float *dy, const int32_t *arg, int32_t C, const int32_t *nbr_t, int64_t n_in, int32_t K, float *dx,
+                      void *stream) {
+  REQ_C4(C, "pool_max_bwd");
+  MINK_REQUIRE(n_in >= 0 && K >= 1, "pool_max_bwd: bad shape");
+  if (n_in == 0) return MINK_OK;
+  MINK_REQUIRE(dy && arg && nbr_t && dx, "pool_max_bwd: NULL pointer");
+  REQ_A16(dy, "pool_max_bwd");
+  REQ_A16(dx, "pool_max_bwd");
+  REQ_A16(arg, "pool_max_bwd");
+  pool_max_bwd_kernel<<<dim3((unsigned)cdiv(n_in * (C >> 2), EB)), EB, 0, (hipStream_t)stream>>>(dy, arg, C >> 2, nbr_t, n_in, K, dx);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

@@ -889,6 +889,31 @@ class SumPoolFunction(torch.autograd.Function):
         return gx, None, None
 
 
+class MaxPoolFunction(torch.autograd.Function):
+    """Max pooling over a neighbour table (windows may overlap); `nbr_t` = the transposed table."""
+
+    @staticmethod
+    def forward(ctx, x, nbr, nbr_t):
+        x = _f32c(x)
+        n_out, K = nbr.shape
+        C = x.shape[1]
+        y = torch.empty(n_out, C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(n_out, C, dtype=torch.int32, device=x.device)
+        check(lib().mink_pool_max_fwd(x.data_ptr(), C, nbr.data_ptr(), n_out, K, y.data_ptr(), arg.data_ptr(), _stream()))
+        ctx.save_for_backward(arg, nbr_t)
+        ctx.n_in = x.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        arg, nbr_t = ctx.saved_tensors
+        gy = _f32c(gy)
+        C = gy.shape[1]
+        gx = torch.empty(ctx.n_in, C, dtype=torch.float32, device=gy.device)
+        check(lib().mink_pool_max_bwd(gy.data_ptr(), arg.data_ptr(), C, nbr_t.data_ptr(), ctx.n_in, nbr_t.shape[1], gx.data_ptr(), _stream()))
+        return gx, None, None
+
+
 class GlobalAvgPoolFunction(torch.autograd.Function):
     """MinkowskiGlobalAvgPooling (reference resnet.py:15-22,175; A10)."""
 

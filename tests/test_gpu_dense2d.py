@@ -1,0 +1,190 @@
+"""-m gpu: the dense 2-D comparison network (BASELINE config #5) -- every layer against torch's own
+dense operators in fp32 (F.conv2d / F.max_pool2d / BatchNorm2d), the whole ResNet18 against a plain-torch ResNet18 with
+the same state dict, the bf16 matrix-core mode within its stated tolerance, and the training script end to end."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rows_to_nchw(y, g):
+    return y.view(g.B, g.H, g.W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw", [(16, 32, 3, 1, 1, 20), (16, 32, 3, 2, 1, 21), (32, 64, 1, 2, 0, 14),
+                                                      (3, 64, 7, 2, 3, 40), (64, 64, 3, 2, 1, 8)])
+def test_dense_conv_matches_torch(cin, cout, k, stride, pad, hw):
+    from nerf_downstream_amd.co3d_2d.src.model import dense
+
+    torch.manual_seed(0)
+    x0 = torch.randn(3, cin, hw, hw + 3)
+    conv = dense.Conv2d(cin, cout, k, stride, pad).cuda()
+    w0 = conv.weight.detach().cpu().clone()
+    need_gx = cin != 3
+    x = x0.clone().cuda().requires_grad_(need_gx)
+    rows, grid = x.permute(0, 2, 3, 1).reshape(-1, cin), dense.Grid(3, hw, hw + 3)
+    y, og, _ = conv(rows, grid)
+    xr, wr = x0.clone().requires_grad_(need_gx), w0.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, stride=stride, padding=pad)
+    assert (og.B, og.H, og.W) == (3, yr.shape[2], yr.shape[3])
+    gy = torch.randn_like(yr)
+    (yr * gy).sum().backward()
+    (_rows_to_nchw(y, og) * gy.cuda()).sum().backward()
+    scale = float(yr.abs().max())
+    assert torch.allclose(_rows_to_nchw(y, og).detach().cpu(), yr.detach(), atol=2e-5 * max(scale, 1.0))
+    assert torch.allclose(conv.weight.grad.cpu(), wr.grad, atol=2e-4 * float(wr.grad.abs().max()))
+    if need_gx:
+        assert torch.allclose(x.grad.cpu(), xr.grad, atol=2e-5 * float(xr.grad.abs().max()) + 1e-6)
+
+
+def test_dense_maxpool_and_batchnorm_match_torch():
+    from nerf_downstream_amd.co3d_2d.src.model import dense
+
+    torch.manual_seed(1)
+    x0 = torch.randn(2, 16, 23, 30)
+    x0[0, :, 3:6, 3:6] = 1.5  # ties inside windows: the first element in scan order must win, as in torch
+    x = x0.clone().cuda().requires_grad_(True)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, 16)
+    y, og = dense.MaxPool2d(3, 2, 1)(rows, dense.Grid(2, 23, 30))
+    xr = x0.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    gy = torch.randn_like(yr)
+    (yr * gy).sum().backward()
+    (_rows_to_nchw(y, og) * gy.cuda()).sum().backward()
+    assert torch.equal(_rows_to_nchw(y, og).detach().cpu(), yr.detach())
+    assert torch.allclose(x.grad.cpu(), xr.grad, atol=1e-6)
+    # batch norm (+ fused residual and ReLU) over N, H, W
+    bn, bnr = dense.BatchNorm2d(16).cuda(), nn.BatchNorm2d(16)
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, 16)), bnr.weight.copy_(torch.linspace(0.5, 1.5, 16))
+    x = x0.clone().cuda().requires_grad_(True)
+    res = torch.randn(2, 16, 23, 30)
+    out = bn(x.permute(0, 2, 3, 1).reshape(-1, 16), relu=True, residual=res.cuda().permute(0, 2, 3, 1).reshape(-1, 16))
+    xr = x0.clone().requires_grad_(True)
+    outr = torch.relu(bnr(xr) + res)
+    g = torch.randn_like(outr)
+    (outr * g).sum().backward()
+    (out.view(2, 23, 30, 16).permute(0, 3, 1, 2) * g.cuda()).sum().backward()
+    assert torch.allclose(out.view(2, 23, 30, 16).permute(0, 3, 1, 2).detach().cpu(), outr.detach(), atol=1e-5)
+    assert torch.allclose(x.grad.cpu(), xr.grad, atol=1e-5)
+    assert torch.allclose(bn.running_var.cpu(), bnr.running_var, atol=1e-5) and int(bn.num_batches_tracked) == 1
+
+
+class _TorchBlock(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        return torch.relu(self.bn2(self.conv2(torch.relu(self.bn1(self.conv1(x))))) + idt)
+
+
+class _TorchResNet18(nn.Module):
+    """torchvision.models.resnet18's topology and parameter names, written with torch's dense layers (the reference
+    model, co3d_2d/src/model/models.py:18-31: fc -> Identity, then Dropout + Linear(512, 51))."""
+
+    def __init__(self):
+        super().__init__()
+        m = nn.Module()
+        m.conv1, m.bn1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64)
+        inpl = 64
+        for i, (planes, stride) in enumerate([(64, 1), (128, 2), (256, 2), (512, 2)], start=1):
+            down = None
+            if stride != 1 or inpl != planes:
+                down = nn.Sequential(nn.Conv2d(inpl, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+            setattr(m, f"layer{i}", nn.Sequential(_TorchBlock(inpl, planes, stride, down), _TorchBlock(planes, planes)))
+            inpl = planes
+        self.model, self.fc, self.dropout = m, nn.Linear(512, 51), nn.Dropout(0.2)
+
+    def forward(self, x):
+        m = self.model
+        x = F.max_pool2d(torch.relu(m.bn1(m.conv1(x))), 3, 2, 1)
+        x = m.layer4(m.layer3(m.layer2(m.layer1(x))))
+        return self.fc(self.dropout(x.mean((2, 3))))
+
+
+def _pair():
+    from nerf_downstream_amd.co3d_2d.src.model.models import ResNetBased
+
+    torch.manual_seed(3)
+    hip = ResNetBased("resnet18", dropout_rate=0.0).cuda()
+    with torch.no_grad():  # zero_init_residual would silence the second conv of every block: give bn2 real scales
+        for k, p in hip.named_parameters():
+            if k.endswith("bn2.weight"):
+                p.fill_(0.5)
+    ref = _TorchResNet18()
+    ref.dropout.p = 0.0
+    assert list(ref.state_dict()) == [k for k in hip.state_dict()] or set(ref.state_dict()) == set(hip.state_dict())
+    ref.load_state_dict(hip.state_dict())
+    return hip, ref
+
+
+def test_resnet18_matches_plain_torch_resnet18():
+    hip, ref = _pair()
+    x = torch.randn(4, 3, 96, 96, generator=torch.Generator().manual_seed(5))
+    labels = torch.tensor([3, 17, 40, 50])
+    out, outr = hip(x.cuda()), ref(x)
+    assert out.shape == (4, 51)
+    assert torch.allclose(out.detach().cpu(), outr.detach(), atol=1e-3), (out.detach().cpu() - outr).abs().max()
+    F.cross_entropy(out, labels.cuda(), label_smoothing=0.005).backward()
+    F.cross_entropy(outr, labels, label_smoothing=0.005).backward()
+    hp, rp = dict(hip.named_parameters()), dict(ref.named_parameters())
+    g = torch.cat([hp[k].grad.cpu().double().flatten() for k in rp])
+    og = torch.cat([rp[k].grad.double().flatten() for k in rp])
+    assert float((g - og).norm() / og.norm()) < 2e-3
+    for k in ("model.conv1.weight", "model.layer2.0.downsample.0.weight", "model.layer4.1.conv2.weight", "fc.weight"):
+        rel = float((hp[k].grad.cpu() - rp[k].grad).norm() / rp[k].grad.norm())
+        assert rel < 5e-3, (k, rel)
+    assert torch.allclose(hip.model.bn1.running_mean.cpu(), ref.model.bn1.running_mean, atol=1e-5)
+
+
+def test_resnet18_bf16_matrix_cores_and_eval_mode():
+    """run.precision = 16: bf16 MFMA operands, fp32 accumulate -- logits within 3e-2 of the fp32 torch network (two
+    8-bit roundings per product over 20 convolution layers); eval mode (running statistics) matches torch's."""
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    hip, ref = _pair()
+    x = torch.randn(4, 3, 96, 96, generator=torch.Generator().manual_seed(6))
+    old = Fn.set_conv_math("bf16")
+    try:
+        out = hip(x.cuda())
+    finally:
+        Fn.set_conv_math(old)
+    outr = ref(x)
+    err = float((out.detach().cpu() - outr).abs().max())
+    assert err < 3e-2 * max(1.0, float(outr.abs().max())), err
+    hip.eval(), ref.eval()
+    with torch.no_grad():
+        assert torch.allclose(hip(x.cuda()).cpu(), ref(x), atol=2e-3)
+
+
+def test_co3d_2d_training_script_learns(tmp_path):
+    from nerf_downstream_amd import gin_lite as gin
+    from nerf_downstream_amd.co3d_2d.train import run
+
+    gin.clear_config()
+    gin.parse_config_files_and_bindings(
+        [os.path.join(ROOT, "nerf_downstream_amd", "co3d_2d", "configs", "resnet18.gin")],
+        ["DataModule.batch_size=8", "DataModule.chunks=8", "DataModule.num_workers=0", "DataModule.num_samples=32", "DataModule.size=64",
+         "SyntheticRenders.num_classes=4", "run.max_steps=24", "run.log_every_n_steps=4", "run.max_epochs=100",
+         "run.check_val_every_n_epoch=100", f"run.log_dir='{tmp_path}'", "LitModel.lr=0.02"])
+    try:
+        res = run(ckpt_path=None, resume_training=False, seed=1)
+    finally:
+        gin.clear_config()
+    logged = [h for h in res["history"] if "train/celoss" in h]
+    assert res["global_step"] == 24 and len(logged) == 6
+    assert logged[-1]["train/celoss"] < logged[0]["train/celoss"], [h["train/celoss"] for h in logged]
+    assert any("val/acc" in h for h in res["history"]) and any("test/acc" in h for h in res["history"])
+    assert os.path.exists(os.path.join(tmp_path, "co3d_perfception_resnet18_scratch_1", "last.ckpt"))
