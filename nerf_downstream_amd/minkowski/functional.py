@@ -459,7 +459,7 @@ class ConvolutionFunction(torch.autograd.Function):
                 home = _HOME_STREAMS.get(gw.device.index)
                 if home is not None and home != main:
                     gw.record_stream(home)  # a branch's gradient is consumed by the network's own stream later
-                if w.grad is None and not getattr(w, "_post_accumulate_grad_hooks", None) and \
+                if w.is_leaf and w.grad is None and not getattr(w, "_post_accumulate_grad_hooks", None) and \
                         not w._backward_hooks and gw.shape[1] == ctx.cin and not torch.is_grad_enabled():
                     _defer_join()
                 else:
