@@ -6,6 +6,8 @@
 // Both are implicit GEMMs over the neighbour table, accumulated in registers by
 // v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD), with no atomics: every output
 // element has exactly one owner, so results are bitwise reproducible run to run.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <mutex>
 #include <type_traits>
@@ -1459,7 +1461,11 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
     p.dyp = fuse->dyp, p.in2out = fuse->in2out, p.mean = fuse->mean, p.invstd = fuse->invstd, p.gamma = fuse->gamma;
     p.beta = fuse->beta, p.dgamma = fuse->dgamma, p.dbeta = fuse->dbeta, p.inv_n = 1.f / (float)n_out;
     p.dyp_bytes = (unsigned)(4 * fuse->n_pool * ldy), p.i2o_bytes = (unsigned)(4 * n_out);
-    wgrad_stream_kernel<4, true><<<grid, 256, 0, st>>>(p);
+    static const int depth = getenv("MINK_WGRAD_DEPTH") ? atoi(getenv("MINK_WGRAD_DEPTH")) : 4;  // tuning hook: row pairs in flight
+    if (depth == 6) wgrad_stream_kernel<6, true><<<grid, 256, 0, st>>>(p);
+    else if (depth == 8) wgrad_stream_kernel<8, true><<<grid, 256, 0, st>>>(p);
+    else if (depth == 2) wgrad_stream_kernel<2, true><<<grid, 256, 0, st>>>(p);
+    else wgrad_stream_kernel<4, true><<<grid, 256, 0, st>>>(p);
   } else if (pl.G == 9 && stream_ok && g_wgrad_stream) wgrad_stream_kernel<4><<<grid, 256, 0, st>>>(p);
   else if (pl.G == 9) launch_wgrad<9>(p, grid, st);
   else if (pl.G == 3) launch_wgrad<3>(p, grid, st);
