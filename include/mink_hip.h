@@ -140,8 +140,8 @@ typedef struct MinkKernelMapDesc {
   uint64_t *blk_table;      /* [blk_cap][2]: block key, inverted occupancy mask */
   int32_t *blk_base;        /* [blk_cap] */
   int32_t *blk_slot;        /* [n_in] scratch: block slot of every input row */
-  int32_t *blk_rowids;      /* [n_in] */
-  int32_t *blk_counter;     /* one int32 of scratch */
+  int32_t *blk_rowids;      /* [max(n_in, 8)] */
+  int32_t *blk_counter;     /* reserved */
   int64_t blk_cap;          /* power of two >= 2 * n_in */
 } MinkKernelMapDesc;
 int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *descs, void *stream);

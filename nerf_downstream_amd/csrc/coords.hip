@@ -229,18 +229,17 @@ __global__ __launch_bounds__(kBlock) void blk_insert_kernel(const int *__restric
   slot_of_row[i] = (int)s;
 }
 
-// One row per block (the one in its lowest occupied cell) reserves the block's run of `rowids`.  The order of the
-// runs depends on the order the workgroups arrive in; the look-up result does not.  One atomic per 1024-thread
-// workgroup: a single word takes ~90 atomics per microsecond, so 70 k block leaders -- or 13 k waves -- adding to it
-// one by one would serialise for longer than the rest of the build takes.
-constexpr int kLeaderBlock = 1024;
-__global__ __launch_bounds__(kLeaderBlock) void blk_leader_kernel(const int *__restrict__ coords, int64_t n, int ts,
-                                                                   const unsigned long long *__restrict__ table,
-                                                                   const int *__restrict__ slot_of_row,
-                                                                   int *__restrict__ base, int *counter) {
-  __shared__ int s_wave[kLeaderBlock / 64];
-  __shared__ int s_start;
-  const int64_t i0 = (int64_t)blockIdx.x * kLeaderBlock + threadIdx.x;
+// One row per block (the one in its lowest occupied cell, the "leader") owns the block's run of `rowids`.  Runs are
+// laid out in row order of the leaders: pass 1 counts the cells led by each workgroup, a single-workgroup scan turns
+// the counts into offsets, pass 2 hands every leader its start.  No atomics (a single counter word takes ~90 adds per
+// microsecond: 70 k leaders on it serialise for longer than the rest of the build), deterministic layout.
+template <bool ASSIGN>
+__global__ __launch_bounds__(kBlock) void blk_leader_kernel(const int *__restrict__ coords, int64_t n, int ts,
+                                                            const unsigned long long *__restrict__ table,
+                                                            const int *__restrict__ slot_of_row, int *__restrict__ base,
+                                                            int *__restrict__ wg_counts, const int *__restrict__ wg_offsets) {
+  __shared__ int s_wave[kBlock / 64];
+  const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool live = i0 < n;
   const int64_t i = live ? i0 : n - 1;  // (idle lanes shadow the last row and never lead: whole waves reach the shuffles)
   const int4 c = reinterpret_cast<const int4 *>(coords)[i];
@@ -261,17 +260,13 @@ __global__ __launch_bounds__(kLeaderBlock) void blk_leader_kernel(const int *__r
   }
   if (lane == 63) s_wave[wave] = incl;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int w = 0; w < kLeaderBlock / 64; ++w) {
-      const int t = s_wave[w];
-      s_wave[w] = run;
-      run += t;
-    }
-    s_start = run > 0 ? atomicAdd(counter, run) : 0;
+  if (!ASSIGN) {
+    if (threadIdx.x == 0) wg_counts[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    return;
   }
-  __syncthreads();
-  if (leader) base[s] = s_start + s_wave[wave] + incl - cnt;
+  int before = wg_offsets[blockIdx.x];
+  for (int w = 0; w < wave; ++w) before += s_wave[w];
+  if (leader) base[s] = before + incl - cnt;
 }
 
 __global__ __launch_bounds__(kBlock) void blk_fill_kernel(const int *__restrict__ coords, int64_t n, int ts,
@@ -731,14 +726,22 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
                  "kernel_map_batch: bad block-index buffers in descriptor %d", i);
     if (e.blk_build) {
       MINK_HIP(hipMemsetAsync(e.blk_table, 0xFF, sizeof(uint64_t) * 2 * e.blk_cap, st));
-      MINK_HIP(hipMemsetAsync(e.blk_counter, 0, sizeof(int32_t), st));
       if (e.n_in > 0) {
         const dim3 g((unsigned)cdiv(e.n_in, kBlock));
         blk_insert_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (unsigned long long *)e.blk_table,
                                                 (uint64_t)e.blk_cap - 1, e.blk_slot);
         MINK_CHECK_LAUNCH();
-        blk_leader_kernel<<<dim3((unsigned)cdiv(e.n_in, kLeaderBlock)), kLeaderBlock, 0, st>>>(
-            e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table, e.blk_slot, e.blk_base, e.blk_counter);
+        // (pass 1 / scan / pass 2 keep their workgroup counts and offsets in the head of blk_rowids, which the fill pass
+        //  overwrites only after the offsets have been turned into per-block bases)
+        MINK_REQUIRE(2 * (int64_t)g.x <= e.n_in || e.n_in >= 8, "kernel_map_batch: blk_rowids too small for the scan scratch");
+        int *wg_counts = e.blk_rowids, *wg_offsets = e.blk_rowids + g.x;
+        blk_leader_kernel<false><<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table,
+                                                       e.blk_slot, e.blk_base, wg_counts, nullptr);
+        MINK_CHECK_LAUNCH();
+        scan_kernel<<<1, 1024, 0, st>>>(wg_counts, wg_offsets, (int64_t)g.x, nullptr);
+        MINK_CHECK_LAUNCH();
+        blk_leader_kernel<true><<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table,
+                                                      e.blk_slot, e.blk_base, nullptr, wg_offsets);
         MINK_CHECK_LAUNCH();
         blk_fill_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table, e.blk_slot,
                                               e.blk_base, e.blk_rowids);

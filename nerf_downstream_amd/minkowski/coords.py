@@ -168,7 +168,7 @@ class CoordinateManager:
         L = lib()
         blk, need = {}, 0
         for ts_in in dict.fromkeys(t[0] for t in todo):
-            n_pad = (max(self.levels[ts_in].n, 1) + 1) // 2 * 2  # regions stay 16-byte aligned
+            n_pad = (max(self.levels[ts_in].n, 8) + 1) // 2 * 2  # regions stay 16-byte aligned (and hold the scan scratch)
             cap = int(L.mink_table_capacity(self.levels[ts_in].n))
             blk[ts_in] = [cap, need, True, n_pad]  # capacity, int32 offset into the index pool, still to build
             need += 4 * cap + cap + 2 * n_pad + 4  # table (2 x int64 per slot), base, slot, rowids, counter (+pad)
