@@ -204,6 +204,11 @@ int mink_conv_set_math(int mode);
 /* Split-K factor the library recommends for a layer (1 for large row counts).  row_classes != 0:
  * the launch will pass a class-partitioned row_perm (stride-2 dgrad), n_out = its n_virtual. */
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_classes);
+/* The same with the reduction width known: returns K -- one slab per kernel offset -- for the deep layers (cin >= 256),
+ * which mink_conv_gather_gemm then runs offset-major with the rows of each offset compacted into dense MFMA blocks (half of
+ * a deep layer's table is empty) and reduces in ascending offset order; otherwise mink_conv_plan_ksplit's answer.  The
+ * workspace is 4 * ksplit * n_out * cout bytes either way. */
+int mink_conv_plan(int64_t n_rows, int32_t K, int32_t cin, int32_t cout, int32_t row_classes);
 /* flip_k: bit 0 = read the weights of offset K-1-k for offset k (data gradient of a stride-1 convolution through the
  * forward table); bit 1 = ACCUMULATE, y[row] += result instead of y[row] = result -- for an un-split launch whose
  * row_perm visits every output row at most once (rows it does not visit are left untouched): the data gradient of

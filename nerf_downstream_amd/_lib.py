@@ -93,6 +93,7 @@ SIGNATURES = {
     "mink_conv_set_stagger": (ctypes.c_int, [ctypes.c_int]),
     "mink_conv_set_math": (ctypes.c_int, [ctypes.c_int]),
     "mink_conv_plan_ksplit": (ctypes.c_int, [_i64, _i32, _i32, _i32]),
+    "mink_conv_plan": (ctypes.c_int, [_i64, _i32, _i32, _i32, _i32]),
     "mink_conv_gather_gemm": (
         ctypes.c_int,
         [_p, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _p, _i32, _p, _p],

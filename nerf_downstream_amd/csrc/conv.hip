@@ -751,6 +751,196 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
   y[row * ldy + c] = s + (bias ? bias[c] : 0.f);
 }
 
+// ------------------------------------------------------------------ offset-major, row-compacted
+// The deep layers (Cin >= 256: a few hundred to a few thousand rows against 1-28 MB of weights) are where the
+// output-stationary kernel above is weakest: half of a 128-row tile's entries for an offset are empty (37-58 % of
+// the table), split-K leaves a handful of items per workgroup and every workgroup re-reads its weight slice.
+// Here a workgroup owns ONE kernel offset k for a 256-row tile and a 64-column slice:
+//   1. the rows of the tile that have a neighbour under offset k are compacted (wave64 ballot + prefix rank) into
+//      dense 32-row MFMA blocks -- ~5 blocks instead of 8, for a strided data gradient 1 instead of 8;
+//   2. plain double-staged GEMM over the input channels: gathered rows [m x 32] and the weight slice [32 x 64] go
+//      through LDS (next chunk's global loads in flight in registers), block x column-half units are dealt to
+//      the four waves;
+//   3. the result goes to slab k at the rows' own indices: (row, offset) entries without a neighbour are never
+//      written -- and never read: the reduce pass sums a row's slabs over the offsets its table row names, in
+//      ascending offset order (ME's summation order), adding bias / column statistics on the way.
+// Every output element still has one owner per pass: no atomics, bitwise reproducible.
+constexpr int OT = 256;  // rows per tile
+
+template <bool W_T>
+__global__ __launch_bounds__(256, 2) void offset_gemm_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) float sA[OT * LDA];
+  __shared__ __attribute__((aligned(16))) float sB[BK * BN];
+  __shared__ int s_in[OT], s_out[OT];
+  __shared__ int s_cnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t o0 = (int64_t)blockIdx.x * OT;
+  const int n0 = blockIdx.y * BN;
+  const int k = blockIdx.z;
+  const int kw = p.flip_k ? p.K - 1 - k : k;
+  // ---- 1. compaction of the tile's rows that have a neighbour under offset k
+  const int64_t o = o0 + tid;
+  const int nb = o < p.n_out ? p.nbr[o * p.K + k] : -1;
+  const unsigned long long bal = __ballot(nb >= 0);
+  if (lane == 0) s_cnt[wave] = __popcll(bal);
+  __syncthreads();
+  const int m = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  if (m == 0) return;  // (uniform) nothing under this offset in this tile
+  {
+    int pos = wave_rank(bal);
+    for (int w = 0; w < wave; ++w) pos += s_cnt[w];
+    if (nb >= 0) s_in[pos] = nb, s_out[pos] = (int)o;
+  }
+  const int mpad = (m + 31) & ~31;
+  if (tid >= m && tid < mpad) s_in[tid] = -1, s_out[tid] = -1;
+  __syncthreads();
+  const int nblk = mpad >> 5;       // 32-row MFMA blocks
+  const int nunits = 2 * nblk;      // (block, column half) units, dealt round-robin to the 4 waves
+  // ---- 2. GEMM over the input channels
+  const int a_cc = tid & 7, a_r = tid >> 3;     // A: rows a_r + 32 i, float4 column a_cc
+  const int b_n4 = tid & 15, b_kk = tid >> 4;   // B (!W_T): rows b_kk + 16 i, float4 column b_n4
+  const int bt_n = tid & 63, bt_k4 = tid >> 6;  // B (W_T) : column bt_n, float4 of k at 4*(bt_k4 + 4 i)
+  uint4 ga[8], gb[2];
+  unsigned okb = 0u;
+  auto ldraw = [&](const float *base, int64_t off, bool ok) { return *reinterpret_cast<const uint4 *>(base + (ok ? off : 0)); };
+  auto gload = [&](int c0) {
+    okb = 0u;
+    const int c = c0 + 4 * a_cc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = a_r + 32 * i;
+      const int src = r < mpad ? s_in[r] : -1;
+      const bool ok = src >= 0 && c < p.cin;
+      ga[i] = ldraw(p.x, (int64_t)src * p.ldx + c, ok);
+      okb |= ok ? (1u << i) : 0u;
+    }
+    if (!W_T) {
+      const int n = n0 + 4 * b_n4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = c0 + b_kk + 16 * i;
+        const bool ok = kk < p.cin && n < p.cout;
+        gb[i] = ldraw(p.w, ((int64_t)kw * p.cin + kk) * p.cout + n, ok);
+        okb |= ok ? (256u << i) : 0u;
+      }
+    } else {
+      const int n = n0 + bt_n;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = c0 + 4 * (bt_k4 + 4 * i);
+        const bool ok = n < p.cout && kk < p.cin;
+        gb[i] = ldraw(p.w, ((int64_t)kw * p.cout + n) * p.cin + kk, ok);
+        okb |= ok ? (256u << i) : 0u;
+      }
+    }
+  };
+  auto sts = [&]() {
+    auto masked = [&](uint4 u, unsigned bit) {
+      const unsigned mm = (okb & bit) ? 0xFFFFFFFFu : 0u;
+      return make_uint4(u.x & mm, u.y & mm, u.z & mm, u.w & mm);
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (a_r + 32 * i < mpad) *reinterpret_cast<uint4 *>(&sA[(a_r + 32 * i) * LDA + 4 * a_cc]) = masked(ga[i], 1u << i);
+    if (!W_T) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4 *>(&sB[(b_kk + 16 * i) * BN + 4 * b_n4]) = masked(gb[i], 256u << i);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = 4 * (bt_k4 + 4 * i);
+        const uint4 u = masked(gb[i], 256u << i);
+        sB[(kk + 0) * BN + bt_n] = __uint_as_float(u.x), sB[(kk + 1) * BN + bt_n] = __uint_as_float(u.y);
+        sB[(kk + 2) * BN + bt_n] = __uint_as_float(u.z), sB[(kk + 3) * BN + bt_n] = __uint_as_float(u.w);
+      }
+    }
+  };
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x16){0};
+  const int h = lane >> 5, col = lane & 31;
+  gload(0);
+  for (int c0 = 0; c0 < p.cin; c0 += BK) {
+    __syncthreads();  // the previous chunk's operands have been read
+    sts();
+    __syncthreads();
+    if (c0 + BK < p.cin) gload(c0 + BK);  // in flight during the MFMAs below
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = wave + 4 * i;
+      if (u < nunits) {  // uniform per wave
+        const int arow = (u >> 1) * 32 + col;
+        const int cb = (u & 1) * 32 + col;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float4 av = *reinterpret_cast<const float4 *>(&sA[arow * LDA + 8 * t + 4 * h]);
+          const float a4[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], sB[(8 * t + 4 * h + j) * BN + cb], acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- 3. slab k, at the rows' own indices (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+  float *dst = p.ws + (int64_t)k * p.n_out * p.cout;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = wave + 4 * i;
+    if (u < nunits) {
+      const int c = n0 + (u & 1) * 32 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = s_out[(u >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+        if (row >= 0 && c < p.cout) dst[(int64_t)row * p.cout + c] = acc[i][r];
+      }
+    }
+  }
+}
+
+// y[o] = bias + sum over the offsets k the table names for row o (ascending) of slab[k][o]; STATS: per-workgroup column
+// (sum, sum of squares) partials in double for the batch norm that follows (layout of splitk_reduce_stats_kernel)
+template <bool STATS>
+__global__ __launch_bounds__(256) void offset_reduce_kernel(const float *__restrict__ ws, const int *__restrict__ nbr,
+                                                            int64_t n_out, int cout, int K, const float *__restrict__ bias,
+                                                            float *__restrict__ y, int ldy, double *__restrict__ partial) {
+  extern __shared__ double s_red[];  // STATS: [row lanes][2][C]
+  const int tpr = cout >> 2, rlanes = 256 / tpr;
+  const int c4 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const int64_t total = n_out * cout;
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
+  if (rl < rlanes) {
+    const float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * c4) : make_float4(0, 0, 0, 0);
+    for (int64_t row = (int64_t)blockIdx.x * rlanes + rl; row < n_out; row += (int64_t)gridDim.x * rlanes) {
+      float4 v = b;
+      for (int k = 0; k < K; ++k) {
+        if (nbr[row * K + k] >= 0) {
+          const float4 t = *reinterpret_cast<const float4 *>(ws + (int64_t)k * total + row * cout + 4 * c4);
+          v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+        }
+      }
+      *reinterpret_cast<float4 *>(y + row * ldy + 4 * c4) = v;
+      if (STATS) {
+        s0.x += v.x, s0.y += v.y, s0.z += v.z, s0.w += v.w;
+        s1.x += v.x * v.x, s1.y += v.y * v.y, s1.z += v.z * v.z, s1.w += v.w * v.w;
+      }
+    }
+    if (STATS) {
+      double *d = s_red + ((int64_t)rl * 2) * cout + 4 * c4;
+      d[0] = s0.x, d[1] = s0.y, d[2] = s0.z, d[3] = s0.w;
+      d[cout + 0] = s1.x, d[cout + 1] = s1.y, d[cout + 2] = s1.z, d[cout + 3] = s1.w;
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * cout; e += 256) {
+      double s = 0.0;
+      for (int r = 0; r < rlanes; ++r) s += s_red[(int64_t)r * 2 * cout + e];
+      partial[(int64_t)blockIdx.x * 2 * cout + e] = s;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ wgrad
 // dW[k][ci][co] = sum over pairs (i,o) of offset k:  x[i][ci] * dy[o][co].
 //
@@ -1233,6 +1423,7 @@ struct ScopedTimer {  // records an event pair around the launches of one convol
 }  // namespace
 
 static int g_stagger = 0;
+static int g_offset_major = 1;  // tuning hook (mink_conv_set_stagger bit 11 switches it off)
 static int g_pipeline = 1;
 static int g_flat = 1;
 static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
@@ -1245,6 +1436,7 @@ int mink_conv_set_stagger(int units) {
   g_pipeline = !(units & 256);  // bit 8: fall back to the un-pipelined kernel (A/B benchmarks)
   g_flat = !(units & 512);      // bit 9: no flattened-K stem path
   g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
+  g_offset_major = !(units & 2048);  // bit 11: no offset-major path for the deep layers
   g_wgrad_force = (units >> 12) & 0xFFFF;  // bits 12-15: force G (1, 3, 9), bits 16-27: force the row split count
   return old;
 }
@@ -1280,6 +1472,13 @@ int mink_conv_set_math(int mode) {
   return old;
 }
 
+// Offset-major, row-compacted path (offset_gemm_kernel): worth its K slabs where a slab element stands for many FLOPs
+// (2 * cin per float) and the tables are half empty -- the deep layers.
+static bool offset_major_shape(int64_t n_out, int K, int cin, int cout) {
+  return g_offset_major && K >= 8 && cin >= 256 && (cout & 3) == 0 && cout <= 1024 && n_out >= 1 &&
+         4ll * K * n_out * cout <= (128ll << 20);
+}
+
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_classes) {
   if (n_out <= 0 || K <= 1) return 1;
   const int64_t tiles = cdiv(n_out, BM) * cdiv(cout, BN);
@@ -1308,6 +1507,11 @@ int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_cl
     if (score > best_score) best_score = score, best = zs;
   }
   return best;
+}
+
+int mink_conv_plan(int64_t n_rows, int32_t K, int32_t cin, int32_t cout, int32_t row_classes) {
+  if (offset_major_shape(n_rows, K, cin, cout)) return K;  // one slab per offset (offset_gemm_kernel)
+  return mink_conv_plan_ksplit(n_rows, K, cout, row_classes);
 }
 
 // stats_out (optional): double [<= 512][2][cout] column (sum, sum of squares) partials of y for the
@@ -1348,6 +1552,26 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   const bool stats_direct = want_stats && zs == 1 && vec && g_pipeline;  // conv epilogue -> per-tile partials -> stage 2
   const bool stats_split = want_stats && zs > 1 && (cout & 3) == 0 && cout <= 1024 && (ldy & 3) == 0 &&
                            (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
+  if (ksplit == K && vec && g_pipeline && !p.accumulate && offset_major_shape(n_out, K, cin, cout) && (ldy & 3) == 0 &&
+      (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0) {
+    // offset-major, row-compacted: one slab per offset, reduced in ascending offset order (a class permutation of the
+    // rows is not needed -- the per-offset compaction is the finer tool)
+    const dim3 og((unsigned)cdiv(n_out, OT), (unsigned)cdiv(cout, BN), (unsigned)K);
+    if (w_transposed) offset_gemm_kernel<true><<<og, 256, 0, st>>>(p);
+    else offset_gemm_kernel<false><<<og, 256, 0, st>>>(p);
+    MINK_CHECK_LAUNCH();
+    const int tpr = cout >> 2, rlanes = 256 / tpr;
+    const int rows = (int)std::max<int64_t>(1, std::min<int64_t>(512, cdiv(n_out, (int64_t)rlanes * 4)));
+    if (want_stats) {
+      offset_reduce_kernel<true><<<dim3((unsigned)rows), 256, (size_t)rlanes * 2 * cout * sizeof(double), st>>>(
+          workspace, nbr, n_out, cout, K, bias, y, ldy, stats_out);
+      *stats_rows = rows;
+    } else {
+      offset_reduce_kernel<false><<<dim3((unsigned)rows), 256, 0, st>>>(workspace, nbr, n_out, cout, K, bias, y, ldy, nullptr);
+    }
+    MINK_CHECK_LAUNCH();
+    return MINK_OK;
+  }
   if (stats_direct) p.stats = (float *)stats_ws;
   {
     const bool stage = row_perm != nullptr;

@@ -53,7 +53,7 @@ int order_after(hipStream_t waiter, hipStream_t producer, int slot) {
 int conv_stats(const MinkConvLayer &c, const MinkNormLayer &nm, const float *x, int64_t n_out, float *y, void *ws_base,
                int64_t ws_bytes, hipStream_t st) {
   Scratch ws(ws_base, ws_bytes);
-  const int ksplit = mink_conv_plan_ksplit(n_out, c.K, c.cout, 0);
+  const int ksplit = mink_conv_plan(n_out, c.K, c.cin, c.cout, 0);
   float *slabs = ksplit > 1 ? (float *)ws.take(4ll * ksplit * n_out * c.cout) : nullptr;
   void *stats_ws = ws.take(mink_conv_stats_workspace_bytes(n_out, c.cout));
   double *partial = (double *)ws.take(512ll * 2 * c.cout * sizeof(double));
@@ -92,7 +92,7 @@ int conv_backward(const MinkConvLayer &c, const float *x, int64_t n_in, int64_t 
   if (!gx) return MINK_OK;
   Scratch ws(data.ws, data.bytes);
   if (c.stride == 1) {  // centred odd kernel: the transposed table is the table with the offsets flipped
-    const int ksplit = mink_conv_plan_ksplit(n_out, c.K, c.cin, 0);
+    const int ksplit = mink_conv_plan(n_out, c.K, c.cout, c.cin, 0);
     float *slabs = ksplit > 1 ? (float *)ws.take(4ll * ksplit * n_out * c.cin) : nullptr;
     MINK_REQUIRE(ksplit == 1 || slabs, "block: data-gradient scratch too small");
     return mink_conv_gather_gemm(gy, c.cout, c.cout, c.w, 1, 1, c.nbr, n_out, c.K, nullptr, 0, gx, c.cin, c.cin, nullptr,
@@ -100,7 +100,7 @@ int conv_backward(const MinkConvLayer &c, const float *x, int64_t n_in, int64_t 
   }
   MINK_REQUIRE(c.nbr_t, "block: a strided convolution needs its transposed table for the data gradient");
   const int64_t rows = c.perm ? c.n_perm : n_in;
-  const int ksplit = mink_conv_plan_ksplit(rows, c.K, c.cin, c.perm ? 1 : 0);
+  const int ksplit = mink_conv_plan(rows, c.K, c.cout, c.cin, c.perm ? 1 : 0);
   float *slabs = ksplit > 1 ? (float *)ws.take(4ll * ksplit * n_in * c.cin) : nullptr;
   MINK_REQUIRE(ksplit == 1 || slabs, "block: data-gradient scratch too small");
   return mink_conv_gather_gemm(gy, c.cout, c.cout, c.w, 1, 0, c.nbr_t, n_in, c.K, c.perm, c.perm ? c.n_perm : 0, gx, c.cin,

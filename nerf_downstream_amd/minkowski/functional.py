@@ -143,6 +143,8 @@ def kernel_timings():
 
 # ------------------------------------------------------------------------- convolution
 _FORCE_KSPLIT = 0  # benchmarking hook (scripts/kbench.py ksweep)
+if os.environ.get("MINK_OFFSET_MAJOR") == "0":  # A/B hook: deep layers on the output-stationary split-K kernel
+    lib().mink_conv_set_stagger(2048)
 
 
 def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, row_perm=None, stats=False):
@@ -154,7 +156,7 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, ro
     cin = x.shape[1]
     y = torch.empty(n_out, cout, dtype=torch.float32, device=x.device)
     n_rows = n_out if row_perm is None else row_perm.numel()
-    ksplit = _FORCE_KSPLIT or _plan_ksplit(L, n_rows, K, cout, int(row_perm is not None))
+    ksplit = _FORCE_KSPLIT or _plan_ksplit(L, n_rows, K, cin, cout, int(row_perm is not None))
     ws = _scratch(4 * ksplit * n_out * cout, x.device, "splitk") if ksplit > 1 else None
     partial = None
     note_table(nbr)
@@ -219,13 +221,13 @@ def _wgrad_ws_bytes(L, n_out, K, cin, cout):
     return v
 
 
-def _plan_ksplit(L, n_rows, K, cout, classes):
-    key = ("ks", n_rows, K, cout, classes)
+def _plan_ksplit(L, n_rows, K, cin, cout, classes):
+    key = ("ks", n_rows, K, cin, cout, classes)
     v = _PLAN_CACHE.get(key)
     if v is None:
         if len(_PLAN_CACHE) > 4096:
             _PLAN_CACHE.clear()
-        v = _PLAN_CACHE[key] = int(L.mink_conv_plan_ksplit(n_rows, K, cout, classes))
+        v = _PLAN_CACHE[key] = int(L.mink_conv_plan(n_rows, K, cin, cout, classes))
     return v
 
 

@@ -36,7 +36,9 @@ def _to_ts(ME, x, ts):
         (64, 64, 3, 1, 4, 24),   # layer1.conv2 (same-map dgrad with flipped offsets)
         (64, 128, 1, 2, 2, 24),  # downsample 1x1 stride 2
         (128, 256, 3, 2, 4, 32), # small N: split-K path
-        (256, 256, 3, 1, 8, 32),
+        (256, 256, 3, 1, 8, 32),   # Cin >= 256: offset-major, row-compacted path (forward and flipped-table dgrad)
+        (256, 512, 3, 2, 8, 64),   # ... strided: the data gradient compacts the 1/8 of the rows an offset reaches
+        (512, 512, 3, 1, 16, 64),  # ... the deepest shape of the network
         (5, 7, 3, 1, 1, 12),     # odd channel counts everywhere (fully guarded path)
     ],
 )
