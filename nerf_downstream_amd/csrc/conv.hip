@@ -770,7 +770,10 @@ constexpr int OT = 256;  // rows per tile
 template <bool W_T>
 __global__ __launch_bounds__(256, 2) void offset_gemm_kernel(GemmParams p) {
   __shared__ __attribute__((aligned(16))) float sA[OT * LDA];
-  __shared__ __attribute__((aligned(16))) float sB[BK * BN];
+  // B tile: forward weights [cin][cout] arrive contiguous along the columns -> stored [kk][n]; the data gradient reads
+  // the same tensor transposed, contiguous along kk -> stored [n][kk] (row stride LDA), and its MFMA operand is then
+  // one 16-byte LDS read per four k-steps, like A
+  __shared__ __attribute__((aligned(16))) float sB[W_T ? BN * LDA : BK * BN];
   __shared__ int s_in[OT], s_out[OT];
   __shared__ int s_cnt[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -799,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void offset_gemm_kernel(GemmParams p) {
   // ---- 2. GEMM over the input channels
   const int a_cc = tid & 7, a_r = tid >> 3;     // A: rows a_r + 32 i, float4 column a_cc
   const int b_n4 = tid & 15, b_kk = tid >> 4;   // B (!W_T): rows b_kk + 16 i, float4 column b_n4
-  const int bt_n = tid & 63, bt_k4 = tid >> 6;  // B (W_T) : column bt_n, float4 of k at 4*(bt_k4 + 4 i)
+  const int bt_k4 = tid & 7, bt_n = tid >> 3;   // B (W_T) : columns bt_n + 32 i, float4 of k at 4 * bt_k4 (128 contiguous bytes per column)
   uint4 ga[8], gb[2];
   unsigned okb = 0u;
   auto ldraw = [&](const float *base, int64_t off, bool ok) { return *reinterpret_cast<const uint4 *>(base + (ok ? off : 0)); };
@@ -824,10 +827,10 @@ __global__ __launch_bounds__(256, 2) void offset_gemm_kernel(GemmParams p) {
         okb |= ok ? (256u << i) : 0u;
       }
     } else {
-      const int n = n0 + bt_n;
+      const int kk = c0 + 4 * bt_k4;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int kk = c0 + 4 * (bt_k4 + 4 * i);
+        const int n = n0 + bt_n + 32 * i;
         const bool ok = n < p.cout && kk < p.cin;
         gb[i] = ldraw(p.w, ((int64_t)kw * p.cout + n) * p.cin + kk, ok);
         okb |= ok ? (256u << i) : 0u;
@@ -847,12 +850,8 @@ __global__ __launch_bounds__(256, 2) void offset_gemm_kernel(GemmParams p) {
       for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4 *>(&sB[(b_kk + 16 * i) * BN + 4 * b_n4]) = masked(gb[i], 256u << i);
     } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int kk = 4 * (bt_k4 + 4 * i);
-        const uint4 u = masked(gb[i], 256u << i);
-        sB[(kk + 0) * BN + bt_n] = __uint_as_float(u.x), sB[(kk + 1) * BN + bt_n] = __uint_as_float(u.y);
-        sB[(kk + 2) * BN + bt_n] = __uint_as_float(u.z), sB[(kk + 3) * BN + bt_n] = __uint_as_float(u.w);
-      }
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<uint4 *>(&sB[(bt_n + 32 * i) * LDA + 4 * bt_k4]) = masked(gb[i], 256u << i);
     }
   };
   f32x16 acc[4];
@@ -875,9 +874,16 @@ __global__ __launch_bounds__(256, 2) void offset_gemm_kernel(GemmParams p) {
         for (int t = 0; t < 4; ++t) {
           const float4 av = *reinterpret_cast<const float4 *>(&sA[arow * LDA + 8 * t + 4 * h]);
           const float a4[4] = {av.x, av.y, av.z, av.w};
+          float b4[4];
+          if (W_T) {
+            const float4 bv = *reinterpret_cast<const float4 *>(&sB[cb * LDA + 8 * t + 4 * h]);
+            b4[0] = bv.x, b4[1] = bv.y, b4[2] = bv.z, b4[3] = bv.w;
+          } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], sB[(8 * t + 4 * h + j) * BN + cb], acc[i], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) b4[j] = sB[(8 * t + 4 * h + j) * BN + cb];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc[i], 0, 0, 0);
         }
       }
     }
@@ -913,10 +919,22 @@ __global__ __launch_bounds__(256) void offset_reduce_kernel(const float *__restr
     const float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * c4) : make_float4(0, 0, 0, 0);
     for (int64_t row = (int64_t)blockIdx.x * rlanes + rl; row < n_out; row += (int64_t)gridDim.x * rlanes) {
       float4 v = b;
-      for (int k = 0; k < K; ++k) {
-        if (nbr[row * K + k] >= 0) {
-          const float4 t = *reinterpret_cast<const float4 *>(ws + (int64_t)k * total + row * cout + 4 * c4);
-          v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+      // nine slabs per trip, loaded whether the table names them or not (a slab entry without a neighbour was never
+      // written: its bits are discarded by the select below) -- nine independent loads in flight instead of a chain of
+      // table-dependent ones; added in ascending offset order
+      for (int k0 = 0; k0 < K; k0 += 9) {
+        float4 t[9];
+        bool ok[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+          const int k = k0 + u < K ? k0 + u : K - 1;
+          ok[u] = k0 + u < K && nbr[row * K + k] >= 0;
+          t[u] = *reinterpret_cast<const float4 *>(ws + (int64_t)k * total + row * cout + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+          v.x += ok[u] ? t[u].x : 0.f, v.y += ok[u] ? t[u].y : 0.f;
+          v.z += ok[u] ? t[u].z : 0.f, v.w += ok[u] ? t[u].w : 0.f;
         }
       }
       *reinterpret_cast<float4 *>(y + row * ldy + 4 * c4) = v;
@@ -1423,7 +1441,11 @@ struct ScopedTimer {  // records an event pair around the launches of one convol
 }  // namespace
 
 static int g_stagger = 0;
-static int g_offset_major = 1;  // tuning hook (mink_conv_set_stagger bit 11 switches it off)
+// The offset-major path is built, tested and selectable (mink_conv_set_stagger bit 11 / MINK_OFFSET_MAJOR=1) but NOT the
+// default: alone on the chip it beats the output-stationary kernel on the deep layers (l4.conv2 forward 76 us against 94,
+// data gradient 72 against 92), inside a training step -- beside the weight-gradient and map-preparation streams -- its
+// slab traffic (60-120 MB per layer) makes it lose (step 4.66 ms against 4.52).  See DESIGN.md section 7.
+static int g_offset_major = 0;
 static int g_pipeline = 1;
 static int g_flat = 1;
 static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
@@ -1436,7 +1458,7 @@ int mink_conv_set_stagger(int units) {
   g_pipeline = !(units & 256);  // bit 8: fall back to the un-pipelined kernel (A/B benchmarks)
   g_flat = !(units & 512);      // bit 9: no flattened-K stem path
   g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
-  g_offset_major = !(units & 2048);  // bit 11: no offset-major path for the deep layers
+  g_offset_major = (units & 2048) != 0;  // bit 11: offset-major, row-compacted path for the deep layers (Cin >= 256)
   g_wgrad_force = (units >> 12) & 0xFFFF;  // bits 12-15: force G (1, 3, 9), bits 16-27: force the row split count
   return old;
 }
@@ -1561,7 +1583,8 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
     else offset_gemm_kernel<false><<<og, 256, 0, st>>>(p);
     MINK_CHECK_LAUNCH();
     const int tpr = cout >> 2, rlanes = 256 / tpr;
-    const int rows = (int)std::max<int64_t>(1, std::min<int64_t>(512, cdiv(n_out, (int64_t)rlanes * 4)));
+    // (the statistics partials are limited to 512 rows; without them every (row, 4 columns) gets its own thread)
+    const int rows = (int)std::max<int64_t>(1, std::min<int64_t>(want_stats ? 512 : (1 << 20), cdiv(n_out, (int64_t)rlanes)));
     if (want_stats) {
       offset_reduce_kernel<true><<<dim3((unsigned)rows), 256, (size_t)rlanes * 2 * cout * sizeof(double), st>>>(
           workspace, nbr, n_out, cout, K, bias, y, ldy, stats_out);

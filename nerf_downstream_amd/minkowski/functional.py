@@ -143,7 +143,7 @@ def kernel_timings():
 
 # ------------------------------------------------------------------------- convolution
 _FORCE_KSPLIT = 0  # benchmarking hook (scripts/kbench.py ksweep)
-if os.environ.get("MINK_OFFSET_MAJOR") == "0":  # A/B hook: deep layers on the output-stationary split-K kernel
+if os.environ.get("MINK_OFFSET_MAJOR") == "1":  # A/B hook: deep layers (Cin >= 256) on the offset-major, row-compacted kernel
     lib().mink_conv_set_stagger(2048)
 
 

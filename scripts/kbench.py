@@ -42,7 +42,12 @@ def bench_layer(name, xin, in_key, out_key, ks, cin, cout, stride):
         perm = m.class_perm(in_key) if stride == 2 else None
         wt = w.transpose(1, 2).contiguous()
         t = timeit(lambda: Fn.gather_gemm(gy, wt, nbr_t, cin, row_perm=perm), reps)
-    print(f"{name:10s} dgrad n_in ={xin.shape[0]:7d}                 {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s")
+    print(f"{name:10s} dgrad n_in ={xin.shape[0]:7d}                 {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s (materialised W^T)")
+    if stride == 1:
+        t = timeit(lambda: Fn.gather_gemm(gy, w, nbr, cin, w_transposed=True, flip_k=True), reps)
+    else:
+        t = timeit(lambda: Fn.gather_gemm(gy, w, nbr_t, cin, w_transposed=True, row_perm=perm), reps)
+    print(f"{name:10s} dgrad (W read transposed in place)   {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s")
     t = timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, w.shape), reps)
     print(f"{name:10s} wgrad                                {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s")
 

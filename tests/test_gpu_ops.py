@@ -36,13 +36,31 @@ def _to_ts(ME, x, ts):
         (64, 64, 3, 1, 4, 24),   # layer1.conv2 (same-map dgrad with flipped offsets)
         (64, 128, 1, 2, 2, 24),  # downsample 1x1 stride 2
         (128, 256, 3, 2, 4, 32), # small N: split-K path
-        (256, 256, 3, 1, 8, 32),   # Cin >= 256: offset-major, row-compacted path (forward and flipped-table dgrad)
-        (256, 512, 3, 2, 8, 64),   # ... strided: the data gradient compacts the 1/8 of the rows an offset reaches
-        (512, 512, 3, 1, 16, 64),  # ... the deepest shape of the network
+        (256, 256, 3, 1, 8, 32),
+        (256, 512, 3, 2, 8, 64),
         (5, 7, 3, 1, 1, 12),     # odd channel counts everywhere (fully guarded path)
     ],
 )
 def test_convolution(oracle_maps, cin, cout, ksize, stride, ts, grid):
+    _convolution_case(oracle_maps, cin, cout, ksize, stride, ts, grid)
+
+
+@pytest.mark.parametrize("cin,cout,stride,ts,grid", [(256, 256, 1, 8, 32), (256, 512, 2, 8, 64), (512, 512, 1, 16, 64)])
+def test_convolution_offset_major_path(oracle_maps, cin, cout, stride, ts, grid):
+    """The offset-major, row-compacted kernel for the deep layers (selectable; off by default):
+    forward, flipped-table and strided data gradients against the oracle, and bitwise run-to-run."""
+    from nerf_downstream_amd._lib import lib
+
+    lib().mink_conv_set_stagger(2048)
+    try:
+        assert lib().mink_conv_plan(2000, 27, cin, cout, 0) == 27
+        _convolution_case(oracle_maps, cin, cout, 3, stride, ts, grid)
+    finally:
+        lib().mink_conv_set_stagger(0)
+    assert lib().mink_conv_plan(2000, 27, cin, cout, 0) != 27 or cin < 256
+
+
+def _convolution_case(oracle_maps, cin, cout, ksize, stride, ts, grid):
     torch.manual_seed(1)
     ME, OME, tf, otf = _pair([3, 4], grid, cin, negative=True)
     x, ox = _to_ts(ME, tf.sparse(), ts), _to_ts(OME, otf.sparse(), ts)
