@@ -66,24 +66,38 @@ class Co3DDatasetBase(Dataset):
             self.files = [line.split()[:2] for line in f if line.strip()]
         self.CLASS_LABELS, self.NUM_CLASSES = CLASSES, len(CLASSES)
 
+    def _load_raw(self, inst_id):
+        """The scene in its on-disk form: (links int32 [N], density f32 [N], sh uint8 [N,27], sh_scale, sh_min, reso).
+        Two formats, as in the reference (co3d.py:133-176): the pre-processed `data.npz` (128^3 grid,
+        scripts/preprocess.py:30-57) and, failing that, the Plenoxel training checkpoint `last.ckpt` (256^3 grid;
+        `state_dict["model.links_idx" / "model.density_data" / "model.sh_data"]`, top-level `model.sh_data_min` /
+        `model.sh_data_scale`)."""
+        scene = os.path.join(self.data_root, f"plenoxel_co3d_{inst_id}")
+        numpy_file, torch_file = os.path.join(scene, "data.npz"), os.path.join(scene, "last.ckpt")
+        if os.path.exists(numpy_file):
+            z = np.load(numpy_file)
+            return (z["links"].astype(np.int32), z["density"].astype(np.float32).reshape(-1), np.ascontiguousarray(z["sh"]),
+                    z["sh_scale"], z["sh_min"], [128, 128, 128])
+        if os.path.exists(torch_file):
+            ck = torch.load(torch_file, map_location="cpu", weights_only=False)
+            sd = ck["state_dict"]
+            as_np = lambda t: t.numpy() if torch.is_tensor(t) else np.asarray(t)  # noqa: E731
+            return (as_np(sd["model.links_idx"]).astype(np.int32), as_np(sd["model.density_data"]).astype(np.float32).reshape(-1),
+                    np.ascontiguousarray(as_np(sd["model.sh_data"])), as_np(ck["model.sh_data_scale"]), as_np(ck["model.sh_data_min"]),
+                    [256, 256, 256])
+        raise ValueError(f"{inst_id} not exist in {self.data_root}")
+
     def load_data(self, inst_id):
-        path = os.path.join(self.data_root, f"plenoxel_co3d_{inst_id}", "data.npz")
-        if not os.path.exists(path):
-            raise ValueError(f"{inst_id} not exist in {self.data_root} (only the data.npz format is supported)")
-        z = np.load(path)
-        sh = z["sh"].astype(np.float32) * z["sh_scale"] + z["sh_min"]
-        return torch.from_numpy(z["links"]), torch.from_numpy(z["density"].astype(np.float32)), torch.from_numpy(sh)
+        links, density, sh_q, scale, mn, reso = self._load_raw(inst_id)
+        sh = sh_q.reshape(len(links), -1).astype(np.float32) * np.asarray(scale, np.float32) + np.asarray(mn, np.float32)
+        return torch.from_numpy(links), torch.from_numpy(density), torch.from_numpy(sh.astype(np.float32)), reso
 
     def load_compact(self, inst_id):
-        path = os.path.join(self.data_root, f"plenoxel_co3d_{inst_id}", "data.npz")
-        if not os.path.exists(path):
-            raise ValueError(f"{inst_id} not exist in {self.data_root} (only the data.npz format is supported)")
-        z = np.load(path)
+        links, density, sh_q, scale, mn, reso = self._load_raw(inst_id)
         bc = lambda a: np.broadcast_to(np.asarray(a, np.float32).reshape(-1), (27,)).copy()  # noqa: E731
-        return {"links": torch.from_numpy(z["links"].astype(np.int32)),
-                "density": torch.from_numpy(z["density"].astype(np.float32).reshape(-1)),
-                "sh_q": torch.from_numpy(np.ascontiguousarray(z["sh"]).reshape(len(z["links"]), -1)),
-                "sh_scale": torch.from_numpy(bc(z["sh_scale"])), "sh_min": torch.from_numpy(bc(z["sh_min"]))}
+        return {"links": torch.from_numpy(links), "density": torch.from_numpy(density),
+                "sh_q": torch.from_numpy(sh_q.reshape(len(links), -1)), "sh_scale": torch.from_numpy(bc(scale)),
+                "sh_min": torch.from_numpy(bc(mn)), "reso": tuple(reso)}
 
     def __getitem__(self, index):
         label, inst_id = self.files[index]
@@ -92,8 +106,8 @@ class Co3DDatasetBase(Dataset):
             sample["labels"] = np.array([self.CLASS_LABELS.index(label)])
             sample["feature_names"] = tuple(self.features)
             return self._with_program(sample)
-        links, density, sh = self.load_data(inst_id)
-        coordinates = links_to_coordinates(links, [128, 128, 128])
+        links, density, sh, reso = self.load_data(inst_id)
+        coordinates = links_to_coordinates(links, reso)
         feats, xyzs = select_features(coordinates, density.reshape(-1, 1), sh.reshape(len(links), -1), self.features)
         return self._with_program({"coordinates": coordinates, "features": feats, "xyzs": xyzs,
                                    "labels": np.array([self.CLASS_LABELS.index(label)]),

@@ -20,6 +20,10 @@ def collate_mink(list_data):
             "labels": torch.from_numpy(np.concatenate([np.asarray(d["labels"]) for d in list_data])),
             "feature_names": list_data[0]["feature_names"],
         }
+        resos = {tuple(d.get("reso", (128, 128, 128))) for d in list_data}
+        if len(resos) != 1:
+            raise ValueError(f"one batch mixes grid resolutions {sorted(resos)} (data.npz scenes are 128^3, last.ckpt scenes 256^3)")
+        package["reso"] = resos.pop()
         return _with_programs(package, list_data, n)
     coords, feats = me_utils.sparse_collate(
         [d["coordinates"] for d in list_data], [d["features"] for d in list_data], dtype=torch.float32

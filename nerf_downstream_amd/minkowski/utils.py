@@ -32,7 +32,7 @@ def sparse_collate(coords, feats, labels=None, dtype=torch.int32, device=None):
     return bcoords, bfeats, torch.cat([_t(l) for l in labels], 0)
 
 
-def decode_plenoxel_batch(batch, reso=(128, 128, 128)):
+def decode_plenoxel_batch(batch, reso=None):
     """Compact PeRFception `data.npz` batch (device tensors: links, density, sh_q, scene_offsets,
     sh_scale, sh_min + `feature_names`) -> (coordinates int32 [N,4], features f32 [N,C]) with one
     HIP kernel (`mink_decode_plenoxel`; reference co3d.py:160-166,196-229)."""
@@ -43,6 +43,7 @@ def decode_plenoxel_batch(batch, reso=(128, 128, 128)):
     links = batch["links"]
     if not links.is_cuda:
         raise RuntimeError("decode_plenoxel_batch runs on the GPU: move the batch to cuda first")
+    reso = tuple(reso or batch.get("reso") or (128, 128, 128))  # data.npz: 128^3; last.ckpt scenes: 256^3
     names = list(batch["feature_names"])
     width = {"density": 1, "sh": 27, "ones": 1}
     col, C = {"density": -1, "sh": -1, "ones": -1}, 0

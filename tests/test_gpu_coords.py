@@ -140,6 +140,12 @@ def test_decode_plenoxel_batch_matches_oracle(features):
     ocoords, ofeats = decode_batch(scenes, features=features)
     assert np.array_equal(coords.cpu().numpy(), ocoords)
     assert np.array_equal(feats.cpu().numpy(), ofeats)
+    # `last.ckpt` scenes live on a 256^3 grid (reference co3d.py:152): the batch carries its resolution
+    links256 = [np.sort(rng.choice(256 ** 3, len(s["links"]), replace=False)).astype(np.int32) for s in scenes]
+    b256 = dict(batch, links=torch.from_numpy(np.concatenate(links256)).cuda(), reso=(256, 256, 256))
+    c256, f256 = ME.utils.decode_plenoxel_batch(b256)
+    oc256, _ = decode_batch([dict(s, links=l) for s, l in zip(scenes, links256)], features=features, reso=(256, 256, 256))
+    assert np.array_equal(c256.cpu().numpy(), oc256) and int(c256[:, 1:].max()) > 127 and torch.equal(f256, feats)
     if features == ("density", "sh"):
         from nerf_downstream_amd.co3d_3d.src.models import get_model
 
