@@ -2,9 +2,10 @@
 from nerf_downstream_amd import gin_lite as gin
 
 from .co3d import Co3D10pDataset, Co3DDataset
+from .scannet import PlenoxelScannetDataset
 from .synthetic import SparseVoxelDataset, SparseVoxelSegDataset
 
-DATASETS = {c.__name__: c for c in (Co3DDataset, Co3D10pDataset, SparseVoxelDataset, SparseVoxelSegDataset)}
+DATASETS = {c.__name__: c for c in (Co3DDataset, Co3D10pDataset, PlenoxelScannetDataset, SparseVoxelDataset, SparseVoxelSegDataset)}
 
 
 @gin.configurable

@@ -358,3 +358,32 @@ def test_bench_two_ranks_self_launched(tmp_path):
     assert res["scaling"] == "weak" and res["steps"] == 3 and res["warmup"] == 2 and res["value"] > 0
     assert res["config"]["global_batch"] == 4 and "gloo" in res["config"]["collective"]
     assert np.isfinite(res["config"]["final_loss"])
+
+
+def test_scannet_plenoxel_segmentation_on_gpu(tmp_path):
+    """train.py on a tiny PeRFception-ScanNet tree (reference scannet.py:450-660 format) with the HIP backend: metric
+    float coordinates are floored and the features sharing a voxel averaged by TensorField.sparse(), predictions are
+    carried back to every input row by out.slice(field); the first-step loss equals the CPU oracle's."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_train_cpu import _write_scannet_tree
+
+    from nerf_downstream_amd.co3d_3d.train import train
+    from oracle import me_cpu as OME
+
+    data_root, _, _, _ = _write_scannet_tree(tmp_path)
+    losses = {}
+    for tag, ME_ in (("hip", None), ("cpu", OME)):
+        gin.clear_config()
+        gin.parse_config_files_and_bindings(
+            [f"{CFG}/scannet_plenoxel.gin", f"{CFG}/res16unet.gin"],
+            ["train.gpus=1", "train.max_steps=6", "train.val_every_n_steps=6", "train.log_every_n_steps=1", "train.batch_size=2",
+             "train.val_batch_size=1", "train.train_num_workers=0", "train.val_num_workers=0", "train.lr=0.01",
+             f"PlenoxelScannetDataset.data_root='{data_root}'", "get_model.name='Res16UNet14A'"])
+        try:
+            res = train(save_path=str(tmp_path / tag), resume_training=False, run_name="s", run_name_postfix=None, ME=ME_, seed=3)
+        finally:
+            gin.clear_config()
+        losses[tag] = [h["train/loss"] for h in res["history"] if "train/loss" in h]
+        assert any("val/mIoU" in h for h in res["history"])
+    assert len(losses["hip"]) == 6 and abs(losses["hip"][0] - losses["cpu"][0]) < 1e-3, (losses["hip"][:2], losses["cpu"][:2])
+    assert np.allclose(losses["hip"][:3], losses["cpu"][:3], atol=2e-2)
