@@ -1339,6 +1339,178 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   }
 }
 
+// ---------------------------------------------------- streaming wgrad on the bf16 matrix cores (cin <= 32)
+// BASELINE config "bf16 mixed precision": the stem's weight gradient with bf16 MFMA operands and fp32 accumulation
+// (v_mfma_f32_32x32x16_bf16: sixteen rows per instruction, 16x the fp32 matrix rate).  Same ownership as the fp32
+// streaming kernel -- a wave holds the nine 32 x 32 accumulators of one offset group and one 32-column half, two wave
+// rows interleave the 16-row blocks -- and the same "operands straight from global memory in register layout" idea:
+// lane (h, m) of the A operand holds x[nbr[R + 8h + j][k0 + g]][m], j = 0..7 (eight gathered rows of channel m), lane
+// (h, n) of the B operand dY[R + 8h + j][n]; values are loaded as fp32 and packed to bf16 in registers (HBM tensors
+// stay fp32).  With the matrix work down 16x the kernel is bound by its gathers, which are the fp32 kernel's.
+// Pipeline per wave: table entries of block b+1 are fetched during block b and broadcast through a wave-private LDS
+// slot; the x gathers run one three-offset sub-batch ahead of the MFMAs; FUSE recomputes dY from the conv output and
+// the pooled gradient as the fp32 kernel does (parents one block ahead).
+using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
+
+__device__ __forceinline__ bf16x8v pack_bf16x8(const float (&v)[8]) {
+  const uint4 u = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+  return __builtin_bit_cast(bf16x8v, u);
+}
+
+template <bool FUSE>
+__global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p) {
+  constexpr int G = 9, SB = 1;           // offsets per group, offsets per sub-batch (gathers run one sub-batch ahead)
+  constexpr unsigned OOB = 0x80000000u;  // beyond any descriptor this kernel is launched with
+  __shared__ float sR[2 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned sN[4][2][16][12];  // [wave][slot][row of the block][offset (9 used)]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wa = wave >> 1, h = lane >> 5, col = lane & 31;
+  const int grp = blockIdx.x % p.ngroups;
+  const int co0 = (blockIdx.x / p.ngroups) * WT;
+  const int k0 = grp * G;
+  const int64_t rbeg = (int64_t)blockIdx.y * p.rows_per_split;
+  const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
+  const int nrel = (int)(rend - rbeg);
+  const int nblocks = (nrel + 15) >> 4;
+  const int nq = (nblocks + 1 - wa) >> 1;  // this wave's blocks: b = 2 q + wa
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rd = make_rsrc(p.dy, p.dy_bytes), rn = make_rsrc(p.nbr, p.nbr_bytes);
+  const __amdgpu_buffer_rsrc_t rp = make_rsrc(FUSE ? (const void *)p.dyp : (const void *)p.dy, FUSE ? p.dyp_bytes : 0u),
+                               ri = make_rsrc(FUSE ? (const void *)p.in2out : (const void *)p.nbr, FUSE ? p.i2o_bytes : 0u);
+  const unsigned ldx4 = 4u * p.ldx, ldy4 = 4u * p.ldy, K4 = 4u * p.K;
+  const unsigned xcol = 4u * min(col, p.cin - 1);
+  const unsigned dcol = 4u * min(co0 + 32 * wn + col, p.cout - 1);
+  const int cco = min(co0 + 32 * wn + col, p.cout - 1);
+  const float c_mu = FUSE ? p.mean[cco] : 0.f, c_is = FUSE ? p.invstd[cco] : 0.f, c_ga = FUSE ? p.gamma[cco] : 0.f,
+              c_be = FUSE ? p.beta[cco] : 0.f, c_dgn = FUSE ? p.dgamma[cco] * p.inv_n : 0.f,
+              c_dbn = FUSE ? p.dbeta[cco] * p.inv_n : 0.f;
+  const unsigned nbase = (unsigned)rbeg * K4, ibase = (unsigned)rbeg * 4u, dbase = (unsigned)rbeg * ldy4 + dcol;
+
+  f32x16 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = (f32x16){0};
+  if (nq <= 0) goto epilogue;
+  {
+    // table loader lanes: row kk = lane >> 2 of the block, entries 3 (lane & 3) .. + 2 (lanes with (lane & 3) == 3 idle)
+    const int t_row = lane >> 2, t_part = lane & 3;
+    unsigned traw[3];
+    auto load_table = [&](int q) __attribute__((always_inline)) {  // block 2 q + wa (rows past the end read as "no neighbour")
+      const int r = 16 * (2 * q + wa) + t_row;
+      const bool ok = q < nq && r < nrel && t_part < 3;
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        traw[e] = ok ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rn, (int)(__umul24(r, K4) + nbase + 4u * (k0 + 3 * t_part + e)), 0, 0)
+                     : 0xFFFFFFFFu;
+    };
+    auto stash_table = [&](int slot) __attribute__((always_inline)) {
+      if (t_part < 3) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) sN[wave][slot][t_row][3 * t_part + e] = traw[e];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slot: in-order LDS, visible to the reads below
+    };
+    unsigned par[8];  // FUSE: pooled parent of this lane's eight rows, one block ahead
+    auto load_par = [&](int q) __attribute__((always_inline)) {
+      if (FUSE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 16 * (2 * q + wa) + 8 * h + j;
+          par[j] = (q < nq && r < nrel) ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ri, (int)(4u * r + ibase), 0, 0) : 0u;
+        }
+      }
+    };
+    float braw[8], bpool[8];
+    auto load_b = [&](int q) __attribute__((always_inline)) {  // dY rows (FUSE: conv output rows + pooled gradient of their parents)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 16 * (2 * q + wa) + 8 * h + j;
+        const bool ok = q < nq && r < nrel;
+        braw[j] = buf_load(rd, ok ? __umul24(r, ldy4) + dbase : OOB);
+        if (FUSE) bpool[j] = buf_load(rp, ok ? __umul24(par[j], ldy4) + dcol : OOB);
+      }
+    };
+    auto b_fragment = [&](int q) __attribute__((always_inline)) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (!FUSE) {
+          v[j] = braw[j];
+        } else {
+          const int r = 16 * (2 * q + wa) + 8 * h + j;
+          const float xh = (braw[j] - c_mu) * c_is;
+          const float g = bpool[j] * (xh * c_ga + c_be > 0.f ? 1.f : 0.f);
+          const float d = c_ga * c_is * (g - c_dbn - xh * c_dgn);
+          v[j] = r < nrel ? d : 0.f;  // a row past the end must not contribute (its x operand is zero too)
+        }
+      }
+      return pack_bf16x8(v);
+    };
+    float xraw[3][SB][8];
+    auto load_x = [&](int buf, int slot, int sb) __attribute__((always_inline)) {  // the x gathers of one sub-batch (three offsets x eight rows)
+#pragma unroll
+      for (int g = 0; g < SB; ++g) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned nb = sN[wave][slot][8 * h + j][SB * sb + g];
+          xraw[buf][g][j] = buf_load(rx, (nb & 0x80000000u) ? OOB : __umul24(nb, ldx4) + xcol);
+        }
+      }
+    };
+    // ---- prologue: table of block 0 staged, of block 1 in flight; B operands and first x sub-batch of block 0 in flight
+    load_table(0);
+    load_par(0);
+    stash_table(0);
+    load_b(0);
+    load_table(1);
+    load_par(1);
+    load_x(0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // one block = nine one-offset sub-batches; the gathers run one sub-batch ahead through a ring of three buffers
+    // (nine is a multiple of three: every register index is a compile-time constant without unrolling over blocks)
+    for (int q = 0; q < nq; ++q) {
+      const int slot = q & 1;
+      const bf16x8v bfrag = b_fragment(q);
+#pragma unroll
+      for (int sb = 0; sb < G; ++sb) {
+        const int cur = sb % 3, nxt = (sb + 1) % 3;
+        if (sb == 0) load_b(q + 1);  // (parents of block q + 1 arrived one block ago)
+        if (sb == 1) load_par(q + 2);
+        if (sb < G - 1) {
+          load_x(nxt, slot, sb + 1);
+        } else {
+          stash_table(slot ^ 1);  // entries of block q + 1, in flight since the previous block
+          load_x(nxt, slot ^ 1, 0);
+          load_table(q + 2);
+        }
+        acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_bf16x8(xraw[cur][0]), bfrag, acc[sb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the sub-batches (and the load FIFO) in program order
+      }
+    }
+  }
+epilogue:
+  // ---- add the two wave rows through LDS, store the partial slab
+  float *dst = p.out + (int64_t)blockIdx.y * p.K * p.cin * p.cout;
+  const int co = co0 + 32 * wn + col;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int k = k0 + g;
+    __syncthreads();
+    if (wa == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sR[(wn * 16 + r) * 64 + lane] = acc[g][r];
+    }
+    __syncthreads();
+    if (wa == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[g][r] + sR[(wn * 16 + r) * 64 + lane];
+        if (ci < p.cin && co < p.cout) dst[((int64_t)k * p.cin + ci) * p.cout + co] = v;
+      }
+    }
+  }
+}
+
 // out[i] = sum_z ws[z][i]: 64 outputs x 4 slab lanes per workgroup (fixed order -> deterministic)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ ws, int64_t count, int nslab,
                                                           float *__restrict__ out) {
@@ -1449,6 +1621,7 @@ static int g_offset_major = 0;
 static int g_pipeline = 1;
 static int g_flat = 1;
 static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
+static int g_wgrad_bf16 = getenv("MINK_WGRAD_BF16") ? atoi(getenv("MINK_WGRAD_BF16")) : 1;  // bf16 math: stem weight gradient on the bf16 MFMA too
 
 extern "C" {
 
@@ -1527,6 +1700,15 @@ int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_cl
     else if (row_classes) score = zs == 1;
     else score = zs > 7 ? 0.0 : (double)blocks / (512.0 * cdiv(blocks, 512)) - 0.01 * zs;
     if (score > best_score) best_score = score, best = zs;
+  }
+  static const int cap = getenv("MINK_KSPLIT_CAP") ? atoi(getenv("MINK_KSPLIT_CAP")) : 0;  // tuning hook (in-step sweeps)
+  if (cap > 0 && best > cap) {  // the largest legal split not above the cap
+    int alt = 1;
+    for (int kper = K; kper >= 1; --kper) {
+      const int zs = (int)cdiv(K, kper);
+      if (zs <= cap) alt = zs;
+    }
+    best = alt;
   }
   return best;
 }
@@ -1702,6 +1884,7 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
   const int64_t xb = 4 * n_in * ldx, db = 4 * n_out * ldy, nb = 4 * n_out * K;
   p.x_bytes = (unsigned)xb, p.dy_bytes = (unsigned)db, p.nbr_bytes = (unsigned)nb;
   const bool stream_ok = wgrad_stream_ok(n_in, ldx, cin, ldy, cout, n_out, K);
+  const bool bf16_stream = g_math == 1 && g_wgrad_bf16 && pl.G == 9 && stream_ok && g_wgrad_stream;
   if (fuse) {
     MINK_REQUIRE(pl.G == 9 && stream_ok && g_wgrad_stream && 4 * fuse->n_pool * ldy < (1ll << 31),
                  "wgrad_bn_relu_pool: shape not supported by the streaming kernel (ask mink_conv_wgrad_bn_relu_pool_supported)");
@@ -1709,11 +1892,13 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
     p.beta = fuse->beta, p.dgamma = fuse->dgamma, p.dbeta = fuse->dbeta, p.inv_n = 1.f / (float)n_out;
     p.dyp_bytes = (unsigned)(4 * fuse->n_pool * ldy), p.i2o_bytes = (unsigned)(4 * n_out);
     static const int depth = getenv("MINK_WGRAD_DEPTH") ? atoi(getenv("MINK_WGRAD_DEPTH")) : 4;  // tuning hook: row pairs in flight
-    if (depth == 6) wgrad_stream_kernel<6, true><<<grid, 256, 0, st>>>(p);
+    if (bf16_stream) wgrad_stream_bf16_kernel<true><<<grid, 256, 0, st>>>(p);
+    else if (depth == 6) wgrad_stream_kernel<6, true><<<grid, 256, 0, st>>>(p);
     else if (depth == 8) wgrad_stream_kernel<8, true><<<grid, 256, 0, st>>>(p);
     else if (depth == 2) wgrad_stream_kernel<2, true><<<grid, 256, 0, st>>>(p);
     else wgrad_stream_kernel<4, true><<<grid, 256, 0, st>>>(p);
-  } else if (pl.G == 9 && stream_ok && g_wgrad_stream) wgrad_stream_kernel<4><<<grid, 256, 0, st>>>(p);
+  } else if (bf16_stream) wgrad_stream_bf16_kernel<false><<<grid, 256, 0, st>>>(p);
+  else if (pl.G == 9 && stream_ok && g_wgrad_stream) wgrad_stream_kernel<4><<<grid, 256, 0, st>>>(p);
   else if (pl.G == 9) launch_wgrad<9>(p, grid, st);
   else if (pl.G == 3) launch_wgrad<3>(p, grid, st);
   else launch_wgrad<1>(p, grid, st);
