@@ -377,7 +377,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 (MFMA operands; fp32 accumulate, storage and wgrad)",
+            "dtype": {"fp32": "f32", "bf16": "bf16 (MFMA operands of forward, data gradient and the stem weight gradient; fp32 accumulate and storage, mid-layer wgrad fp32)",
                       "bf16x3": "f32 via split-bf16 MFMA (3 products)"}[args.math],
             "data": "synthetic",
             "config": {
