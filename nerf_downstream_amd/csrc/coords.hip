@@ -82,16 +82,20 @@ __global__ __launch_bounds__(kBlock) void flag_kernel(const int *__restrict__ tv
 }
 
 // single-workgroup exclusive scan of int32 (n up to a few 1e5); total -> *total_out.
-// 1024 threads x 8 consecutive items per trip: wave-level shuffles scan the per-thread sums.
-__global__ __launch_bounds__(1024) void scan_kernel(const int *__restrict__ in, int *__restrict__ out, int64_t n,
-                                                    int *total_out) {
-  constexpr int IT = 8;
-  __shared__ int s_wave[16];
+// 256 threads x 16 consecutive items per trip: wave-level shuffles scan the per-thread sums.  (One wave per SIMD on
+// purpose: a 1024-thread workgroup needs four free wave slots on EVERY SIMD of one CU at once, and beside a kernel that
+// fills the register files -- the stem convolution runs while the next batch's maps are built -- it was seen waiting
+// 590 us for that to happen.)
+constexpr int kScanBlock = 256;
+__global__ __launch_bounds__(kScanBlock) void scan_kernel(const int *__restrict__ in, int *__restrict__ out, int64_t n,
+                                                          int *total_out) {
+  constexpr int IT = 16;
+  __shared__ int s_wave[kScanBlock / 64];
   __shared__ int s_carry;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t base = 0; base < n; base += 1024 * IT) {
+  for (int64_t base = 0; base < n; base += kScanBlock * IT) {
     const int64_t i0 = base + (int64_t)threadIdx.x * IT;
     int v[IT], tsum = 0;
 #pragma unroll
@@ -107,15 +111,13 @@ __global__ __launch_bounds__(1024) void scan_kernel(const int *__restrict__ in, 
     }
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    int wv = lane < 16 ? s_wave[lane] : 0;  // every wave scans the 16 wave totals
-    int wincl = wv;
+    int woff = 0, total = 0;
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-      const int t = __shfl_up(wincl, d);
-      if (lane >= d) wincl += t;
+    for (int w = 0; w < kScanBlock / 64; ++w) {
+      const int t = s_wave[w];
+      if (w < wave) woff += t;
+      total += t;
     }
-    const int woff = __shfl(wincl - wv, wave);
-    const int total = __shfl(wincl, 15);
     int run = s_carry + woff + incl - tsum;
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
@@ -230,14 +232,14 @@ __global__ __launch_bounds__(kBlock) void blk_insert_kernel(const int *__restric
 }
 
 // One row per block (the one in its lowest occupied cell, the "leader") owns the block's run of `rowids`.  Runs are
-// laid out in row order of the leaders: pass 1 counts the cells led by each workgroup, a single-workgroup scan turns
-// the counts into offsets, pass 2 hands every leader its start.  No atomics (a single counter word takes ~90 adds per
+// laid out in row order of the leaders: pass 1 counts the cells led by each workgroup, pass 2 sums the counts before
+// its own workgroup and hands every leader its start.  No atomics (a single counter word takes ~90 adds per
 // microsecond: 70 k leaders on it serialise for longer than the rest of the build), deterministic layout.
 template <bool ASSIGN>
 __global__ __launch_bounds__(kBlock) void blk_leader_kernel(const int *__restrict__ coords, int64_t n, int ts,
                                                             const unsigned long long *__restrict__ table,
                                                             const int *__restrict__ slot_of_row, int *__restrict__ base,
-                                                            int *__restrict__ wg_counts, const int *__restrict__ wg_offsets) {
+                                                            int *__restrict__ wg_counts) {
   __shared__ int s_wave[kBlock / 64];
   const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool live = i0 < n;
@@ -264,7 +266,16 @@ __global__ __launch_bounds__(kBlock) void blk_leader_kernel(const int *__restric
     if (threadIdx.x == 0) wg_counts[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
     return;
   }
-  int before = wg_offsets[blockIdx.x];
+  // this workgroup's offset = sum of the counts of the workgroups before it (a few thousand ints from L2: cheaper than
+  // a scan launch between the two passes, and nothing here can be held up by a single-workgroup kernel)
+  __shared__ int s_part[kBlock / 64];
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) part += wg_counts[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+  if (lane == 0) s_part[wave] = part;
+  __syncthreads();
+  int before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
   for (int w = 0; w < wave; ++w) before += s_wave[w];
   if (leader) base[s] = before + incl - cnt;
 }
@@ -594,7 +605,7 @@ static int unique_launch(const uint64_t *keys, int64_t n, const int *n_dev, uint
   MINK_CHECK_LAUNCH();
   flag_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, n_dev, flags, block_counts);
   MINK_CHECK_LAUNCH();
-  scan_kernel<<<1, 1024, 0, st>>>(block_counts, block_offsets, nb, n_unique);
+  scan_kernel<<<1, kScanBlock, 0, st>>>(block_counts, block_offsets, nb, n_unique);
   MINK_CHECK_LAUNCH();
   assign_kernel<<<grid, kBlock, 0, st>>>(keys, flags, slot_of_row, block_offsets, n, n_dev, table_vals, out_coords,
                                          unique_index);
@@ -731,17 +742,14 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
         blk_insert_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (unsigned long long *)e.blk_table,
                                                 (uint64_t)e.blk_cap - 1, e.blk_slot);
         MINK_CHECK_LAUNCH();
-        // (pass 1 / scan / pass 2 keep their workgroup counts and offsets in the head of blk_rowids, which the fill pass
-        //  overwrites only after the offsets have been turned into per-block bases)
-        MINK_REQUIRE(2 * (int64_t)g.x <= e.n_in || e.n_in >= 8, "kernel_map_batch: blk_rowids too small for the scan scratch");
-        int *wg_counts = e.blk_rowids, *wg_offsets = e.blk_rowids + g.x;
+        // (the two passes keep the workgroup counts in the head of blk_rowids, which the fill pass overwrites only after
+        //  they have been turned into per-block bases)
+        int *wg_counts = e.blk_rowids;
         blk_leader_kernel<false><<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table,
-                                                       e.blk_slot, e.blk_base, wg_counts, nullptr);
-        MINK_CHECK_LAUNCH();
-        scan_kernel<<<1, 1024, 0, st>>>(wg_counts, wg_offsets, (int64_t)g.x, nullptr);
+                                                       e.blk_slot, e.blk_base, wg_counts);
         MINK_CHECK_LAUNCH();
         blk_leader_kernel<true><<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table,
-                                                      e.blk_slot, e.blk_base, nullptr, wg_offsets);
+                                                      e.blk_slot, e.blk_base, wg_counts);
         MINK_CHECK_LAUNCH();
         blk_fill_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table, e.blk_slot,
                                               e.blk_base, e.blk_rowids);
@@ -799,7 +807,7 @@ int mink_rulebook(const int32_t *nbr, int64_t n_out, int32_t K, int32_t *counts,
   const dim3 grid((unsigned)nchunk);
   rulebook_kernel<false><<<grid, kBlock, 0, st>>>(nbr, n_out, K, nchunk, chunk_counts, nullptr, nullptr, nullptr);
   MINK_CHECK_LAUNCH();
-  scan_kernel<<<1, 1024, 0, st>>>(chunk_counts, chunk_offsets, nchunk * K, total);
+  scan_kernel<<<1, kScanBlock, 0, st>>>(chunk_counts, chunk_offsets, nchunk * K, total);
   MINK_CHECK_LAUNCH();
   rulebook_counts_kernel<<<1, 64, 0, st>>>(chunk_offsets, nchunk, K, total, counts);
   MINK_CHECK_LAUNCH();
@@ -833,7 +841,7 @@ int mink_class_partition(const int32_t *coords, int64_t n, int32_t ts, int32_t p
   const dim3 grid((unsigned)nchunk);
   class_partition_kernel<false><<<grid, kBlock, 0, st>>>(coords, n, ts, nchunk, pad, chunk_counts, nullptr, nullptr, nullptr);
   MINK_CHECK_LAUNCH();
-  scan_kernel<<<1, 1024, 0, st>>>(chunk_counts, chunk_offsets, nchunk * 8, total);
+  scan_kernel<<<1, kScanBlock, 0, st>>>(chunk_counts, chunk_offsets, nchunk * 8, total);
   MINK_CHECK_LAUNCH();
   class_partition_kernel<true><<<grid, kBlock, 0, st>>>(coords, n, ts, nchunk, pad, nullptr, chunk_offsets, total, perm);
   MINK_CHECK_LAUNCH();
