@@ -94,6 +94,9 @@ int mink_coords_unique(const uint64_t *keys, int64_t n, uint64_t *table_keys, in
  *   in2out of level l), index_a[l][n] (first-occurrence rows; may be NULL for l > 0).
  *   meta[nlev+2] (device int32): unique rows per level, then the status word, then the batch
  *   count (batch index of the last row + 1).  The caller reads `meta` back once.
+ * The hash map of level l > 0 occupies only the first mink_table_capacity(rows of level l-1) slots of its
+ * buffer -- the capacity for the rows it really receives, computed on the device; a later look-up in it
+ * (mink_kernel_map) must be given that capacity, which the caller can compute once it has read `meta`.
  * Replaces the chain TensorField.sparse() -> stride() x5 of one forward pass
  * (resnet.py:164-173, sparse_conv.py:403-405). */
 int64_t mink_levels_workspace_bytes(int64_t n);

@@ -46,10 +46,30 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restric
 }
 
 // ---------------------------------------------------------------------------- unique
+// Hash-map capacity for n keys (== mink_table_capacity): in a level chain the row count of a level is only known on
+// the device, and so is the capacity of the next level's map -- sized for the rows it really receives, not for the
+// field's row count (a 2 M-slot table per level for 173 k / 37 k / 8 k ... rows cost 125 MB of clearing per batch and
+// scattered the few keys over 25 MB each).
+__device__ __forceinline__ uint64_t dev_table_capacity(int64_t n) {
+  uint64_t cap = 64;
+  while (cap < (uint64_t)(2 * n)) cap <<= 1;
+  return cap;
+}
+
+__global__ __launch_bounds__(kBlock) void clear_table_kernel(unsigned long long *__restrict__ tkeys, int *__restrict__ tvals,
+                                                             const int *__restrict__ n_dev) {
+  const uint64_t cap = dev_table_capacity(*n_dev);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * kBlock) {
+    tkeys[i] = kEmptyKey;
+    tvals[i] = 0x7F7F7F7F;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void insert_kernel(const uint64_t *__restrict__ keys, int64_t n_host,
                                                         const int *__restrict__ n_dev, unsigned long long *tkeys,
                                                         int *tvals, uint64_t mask, int *__restrict__ slot_of_row) {
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
+  if (n_dev) mask = dev_table_capacity(n) - 1;  // chained level: the map is sized for the rows that arrive
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const uint64_t key = keys[i];
@@ -687,8 +707,13 @@ int mink_coords_build_levels(const void *coords, int mode, int64_t n, int32_t nl
     else
       make_keys_kernel<1><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status);
     MINK_CHECK_LAUNCH();
-    MINK_HIP(hipMemsetAsync(table_keys[l], 0xFF, cap * sizeof(uint64_t), st));
-    MINK_HIP(hipMemsetAsync(table_vals[l], 0x7F, cap * sizeof(int32_t), st));
+    if (l == 0) {
+      MINK_HIP(hipMemsetAsync(table_keys[l], 0xFF, cap * sizeof(uint64_t), st));
+      MINK_HIP(hipMemsetAsync(table_vals[l], 0x7F, cap * sizeof(int32_t), st));
+    } else {  // only the mink_table_capacity(n_{l-1}) slots this level uses (row count on the device)
+      clear_table_kernel<<<dim3(512), kBlock, 0, st>>>((unsigned long long *)table_keys[l], table_vals[l], n_dev);
+      MINK_CHECK_LAUNCH();
+    }
     // index_a: first-occurrence rows (optional, kept for level 0), index_b: inverse / in2out
     int rc = unique_launch(keys, n, n_dev, table_keys[l], table_vals[l], cap, out_coords[l],
                            index_a[l], index_b[l], meta + l, uws, st);

@@ -305,9 +305,12 @@ class CoordinateManager:
             )
         self._batch_size = m[nlev + 1]
         n_prev = n
+        L = lib()
         for l, ts in enumerate(ts_list):
             lev = _Level()
-            lev.n, lev.cap, lev.tkeys, lev.tvals = m[l], cap, tkeys[l], tvals[l]
+            # level l > 0 hashed the m[l-1] rows of the level above into a map of exactly their capacity (device-side count)
+            cap_l = cap if l == 0 else int(L.mink_table_capacity(m[l - 1]))
+            lev.n, lev.cap, lev.tkeys, lev.tvals = m[l], cap_l, tkeys[l, :cap_l], tvals[l, :cap_l]
             lev.coords = coords[l, : m[l]]
             self.levels[ts] = lev
             if l == 0:
