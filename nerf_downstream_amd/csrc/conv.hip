@@ -1181,6 +1181,25 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned byt
 }
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 
+// Workgroup -> (offset group, cout tile, row split) of the streaming kernels.  Workgroups are dealt to the eight XCDs
+// round-robin in launch order, and the three offset groups of one row split read the same conv output, pooled gradient
+// and table rows: with the plain (x = group, y = split) order they land on three different XCDs and every L2 fetches
+// those rows for itself (r01: 2.0 GB of HBM reads against 0.43 GB algorithmic).  When the split count is a multiple of
+// eight the groups of a split are given to consecutive slots of ONE XCD instead.
+struct StreamSlot {
+  int grp, cot, split;
+};
+__device__ __forceinline__ StreamSlot stream_slot(const WgradParams &p) {
+  StreamSlot s;
+  if ((int)gridDim.x == p.ngroups && (gridDim.y & 7) == 0 && !(p.ablate & 4096)) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, slot = lin >> 3;
+    s.grp = (int)(slot % (unsigned)p.ngroups), s.cot = 0, s.split = (int)((slot / (unsigned)p.ngroups) * 8 + xcd);
+  } else {
+    s.grp = blockIdx.x % p.ngroups, s.cot = blockIdx.x / p.ngroups, s.split = blockIdx.y;
+  }
+  return s;
+}
+
 template <int D, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   static_assert(D % 2 == 0, "the neighbour staging ring has two slots");
@@ -1194,11 +1213,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wa = wave >> 1, h = lane >> 5, col = lane & 31;
-  const int grp = blockIdx.x % p.ngroups;
-  const int co0 = (blockIdx.x / p.ngroups) * WT;
+  const StreamSlot ss = stream_slot(p);
+  const int grp = ss.grp;
+  const int co0 = ss.cot * WT;
   const int k0 = grp * G;
   constexpr int ng = G;
-  const int64_t rbeg = (int64_t)blockIdx.y * p.rows_per_split;
+  const int64_t rbeg = (int64_t)ss.split * p.rows_per_split;
   const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rd = make_rsrc(p.dy, p.dy_bytes),
                                rn = make_rsrc(p.nbr, p.nbr_bytes);
@@ -1315,7 +1335,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   }
 
   // ---- epilogue: add the two wave rows through LDS, store the partial slab
-  float *dst = p.out + (int64_t)blockIdx.y * p.K * p.cin * p.cout;
+  float *dst = p.out + (int64_t)ss.split * p.K * p.cin * p.cout;
   const int co = co0 + 32 * wn + col;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -1366,10 +1386,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wa = wave >> 1, h = lane >> 5, col = lane & 31;
-  const int grp = blockIdx.x % p.ngroups;
-  const int co0 = (blockIdx.x / p.ngroups) * WT;
+  const StreamSlot ss = stream_slot(p);
+  const int grp = ss.grp;
+  const int co0 = ss.cot * WT;
   const int k0 = grp * G;
-  const int64_t rbeg = (int64_t)blockIdx.y * p.rows_per_split;
+  const int64_t rbeg = (int64_t)ss.split * p.rows_per_split;
   const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
   const int nrel = (int)(rend - rbeg);
   const int nblocks = (nrel + 15) >> 4;
@@ -1489,7 +1510,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
   }
 epilogue:
   // ---- add the two wave rows through LDS, store the partial slab
-  float *dst = p.out + (int64_t)blockIdx.y * p.K * p.cin * p.cout;
+  float *dst = p.out + (int64_t)ss.split * p.K * p.cin * p.cout;
   const int co = co0 + 32 * wn + col;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -1551,9 +1572,12 @@ static WgradPlan wgrad_plan(int64_t n_out, int K, int cin, int cout) {
   if (g_wgrad_force >> 4) z = g_wgrad_force >> 4;
   if (z > row_tiles) z = row_tiles;
   if (z < 1) z = 1;
+  const bool streamed = pl.G == 9 && K == 27 && cin <= 32 && tiles == 1 && z >= 16;  // see stream_slot: splits in eights
+  if (streamed) z = z / 8 * 8;  // rounded DOWN: 3 x 176 workgroups no longer fit the 512 resident slots (measured 1.21 ms against 0.86)
   pl.rows_per_split = align_up(cdiv(n_out, z), WROWS);
   pl.nsplit = (int)cdiv(n_out, pl.rows_per_split);
   if (pl.nsplit < 1) pl.nsplit = 1;
+  if (streamed) pl.nsplit = (int)align_up(pl.nsplit, 8);  // trailing splits may be empty: they store zero slabs
   return pl;
 }
 
@@ -1623,6 +1647,7 @@ static int g_flat = 1;
 static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
 static int g_wgrad_bf16 = getenv("MINK_WGRAD_BF16") ? atoi(getenv("MINK_WGRAD_BF16")) : 1;  // bf16 math: stem weight gradient on the bf16 MFMA too
 static int g_wgrad_bf16_off = 0;
+static int g_wgrad_xcd = getenv("MINK_WGRAD_XCD") ? atoi(getenv("MINK_WGRAD_XCD")) : 1;  // streaming wgrad: groups of a row split share an XCD (stream_slot)
 
 extern "C" {
 
@@ -1633,6 +1658,7 @@ int mink_conv_set_stagger(int units) {
   g_flat = !(units & 512);      // bit 9: no flattened-K stem path
   g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
   g_wgrad_bf16_off = (units >> 28) & 1;  // bit 28: bf16 math keeps the exact-fp32 weight-gradient kernel (A/B tests)
+  g_wgrad_xcd = !((units >> 29) & 1);    // bit 29: plain workgroup order in the streaming weight-gradient kernels (A/B)
   g_offset_major = (units & 2048) != 0;  // bit 11: offset-major, row-compacted path for the deep layers (Cin >= 256)
   g_wgrad_force = (units >> 12) & 0xFFFF;  // bits 12-15: force G (1, 3, 9), bits 16-27: force the row split count
   return old;
@@ -1881,7 +1907,7 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
   p.n_out = n_out, p.rows_per_split = pl.rows_per_split, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K;
   p.ct_tiles = (int)cdiv(cout, WT);
   p.ngroups = pl.ngroups;
-  p.ablate = g_stagger;
+  p.ablate = g_stagger | (g_wgrad_xcd ? 0 : 4096);
   const dim3 grid((unsigned)(pl.ngroups * cdiv(cin, WT) * p.ct_tiles), (unsigned)pl.nsplit);
   const int64_t xb = 4 * n_in * ldx, db = 4 * n_out * ldy, nb = 4 * n_out * K;
   p.x_bytes = (unsigned)xb, p.dy_bytes = (unsigned)db, p.nbr_bytes = (unsigned)nb;

@@ -76,6 +76,21 @@ if which == "wablate":
     b = Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64))
     lib().mink_conv_set_stagger(0)
     print("stream vs tiled wgrad: max |diff|", float((a - b).abs().max()), "max |ref|", float(b.abs().max()))
+if which == "wxcd":  # streaming stem wgrad: groups of a row split on one XCD (default) against plain workgroup order (bit 29)
+    from nerf_downstream_amd._lib import lib
+    nbr, _ = m.kernel_table(k1, k1, 3, 1)
+    xin = x.F.contiguous()
+    gy = torch.randn(nbr.shape[0], 64, device=dev)
+    for st in (0, 1 << 29, 0, 1 << 29):
+        lib().mink_conv_set_stagger(st)
+        t = timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64)), reps)
+        print(f"plain order {st >> 29}: stem wgrad {t*1e3:8.1f} us")
+    lib().mink_conv_set_stagger(0)
+    a = Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64))
+    lib().mink_conv_set_stagger(1 << 29)
+    b = Fn.conv_wgrad(xin, gy, nbr, (27, 28, 64))
+    lib().mink_conv_set_stagger(0)
+    print("bitwise equal:", bool(torch.equal(a, b)))
 if which == "decode":
     import numpy as np
     n = x.F.shape[0]
