@@ -959,6 +959,270 @@ __global__ __launch_bounds__(256) void offset_reduce_kernel(const float *__restr
   }
 }
 
+// ------------------------------------------------ output-stationary gather-GEMM over ROW-COMPACTED offsets (fp32)
+// 37-48 % of a mid-layer table is empty, and the kernel above multiplies those entries as zero rows ("zero
+// rows").  Here the workgroup still owns a 128-row x 64-column tile of the output, but
+//   * the tile's accumulator lives in LDS, not in registers;
+//   * for every offset k of the workgroup's slice the tile rows that HAVE a neighbour are compacted into dense 16-row
+//     blocks (rulebook of the tile: wave64 ballot + prefix rank, built once from the tile's table slice) -- ~80 rows
+//     instead of 128;
+//   * a wave owns a 16-column strip and multiplies EVERY compacted block of the offset for it (v_mfma_f32_16x16x4_f32,
+//     operands swapped so that a lane ends up with four consecutive columns of one row): the work is balanced whatever
+//     the block count is, and padding is to 16 rows, not 32;
+//   * the weight fragment of a wave (32 channels x 16 columns per item) goes from global memory straight into its
+//     registers -- only the gathered rows pass through LDS;
+//   * after the last channel chunk of an offset the wave adds its blocks into the tile rows they belong to (one
+//     16-byte LDS read-modify-write per block and lane, through the rulebook; no other wave touches its strip).
+// Offsets and channel chunks are visited in ascending order: bitwise reproducible.  Pipeline: LDS double buffer for the
+// gathered rows, CD items (offset, 32-channel chunk) of global loads in flight in registers, one raw barrier per item;
+// 78 KB of LDS per workgroup -> two workgroups per CU hide each other's barriers.  Split-K / statistics epilogues are
+// those of gather_gemm2_kernel.  Offsets per workgroup <= CKP (split launches; the planner's slices are 2-9 offsets).
+constexpr int CLDC = BN + 4;         // row stride of the C tile (floats)
+constexpr int CKP = 9;               // offsets per workgroup the rulebook has room for
+constexpr int CD = 3;                // items of global loads in flight
+constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * LDA + CKP * CM + 32) * 4 + CKP * CM; }
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// CM: rows per tile.  64: 39 KB of LDS, four workgroups (16 waves) per CU -- the latency of an item's chain (barrier,
+// LDS stores, rulebook reads, operand reads, scatter) is hidden by the other workgroups; 128: half the weight traffic.
+template <bool W_T, int CM>
+__global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(GemmParams p) {
+  constexpr int NBLK = CM / 16, NH = CM / 64, NA = CM / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char c_smem[];
+  float *sC = reinterpret_cast<float *>(c_smem);             // [CM + 1][CLDC]; row CM takes the padding lanes
+  float *sA = sC + (CM + 1) * CLDC;                          // [2][CM][LDA] compacted gathered rows
+  int *s_src = reinterpret_cast<int *>(sA + 2 * CM * LDA);   // [CKP][CM] input row of the p-th compacted row (-1: padding)
+  int *s_cnt = s_src + CKP * CM;                             // [32] compacted rows per offset of the slice
+  unsigned char *s_lrow = reinterpret_cast<unsigned char *>(s_cnt + 32);  // [CKP][CM] tile row of the p-th compacted row
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int cs = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = column strip
+  const int kq = lane >> 4, n = lane & 15;
+  const int64_t o0 = (int64_t)blockIdx.x * CM;
+  const int n0 = blockIdx.y * BN;
+  const int K = p.K;
+  const int kbeg = blockIdx.z * p.kper, nk = min(K, kbeg + p.kper) - kbeg;
+  const int rows_here = (int)min((int64_t)CM, p.n_out - o0);
+
+  // ---- prologue: rulebook of the slice (a wave takes offsets cs, cs + 4, cs + 8; their table entries are requested
+  // together, straight from global memory: one round trip), C = 0
+  static_assert(CKP <= 12, "three offsets per wave");
+  int tv[3][NH];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int jj = cs + 4 * u;
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+      const int r = lane + 64 * hh;
+      tv[u][hh] = (jj < nk && r < rows_here) ? p.nbr[(o0 + r) * K + kbeg + jj] : -1;
+    }
+  }
+  for (int e = tid; e < (CM + 1) * CLDC / 4; e += 256) reinterpret_cast<float4 *>(sC)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int jj = cs + 4 * u;
+    if (jj < nk) {  // uniform
+      int cnt = 0;
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        const int v = tv[u][hh];
+        const unsigned long long b = __ballot(v >= 0);
+        if (v >= 0) {
+          const int pos = cnt + wave_rank(b);
+          s_src[jj * CM + pos] = v, s_lrow[jj * CM + pos] = (unsigned char)(lane + 64 * hh);
+        }
+        cnt += __popcll(b);
+      }
+      const int pad = ((cnt + 15) & ~15) - cnt;
+      if (lane < pad) s_src[jj * CM + cnt + lane] = -1, s_lrow[jj * CM + cnt + lane] = (unsigned char)CM;
+      if (lane == 0) s_cnt[jj] = cnt;
+    }
+  }
+  __syncthreads();
+  // offsets of the slice that have rows, packed four bits each (nk <= CKP = 9 < 16 entries)
+  unsigned long long act = 0ull;
+  int na = 0;
+  for (int j = 0; j < nk; ++j)
+    if (s_cnt[j] > 0) act |= (unsigned long long)j << (4 * na++);
+  auto act_at = [&](int a) { return (int)((act >> (4 * a)) & 15u); };
+  const int ncc = p.cin / BK;
+  const int n_items = na * ncc;
+
+  // ---- staging: A rows a_r + 32 i (float4 column a_cc); weight fragment of this lane: channels 4 kq + s + 16 h
+  const int a_cc = tid & 7, a_r = tid >> 3;
+  uint4 ga[CD][NA];
+  float gw[CD][8];
+  unsigned g_ok[CD];
+  int g_nbp[CD];
+  int g_ka = 0, g_cc = 0;  // iterator of the global-load stage
+  auto ldraw = [&](const float *base, int64_t off, bool ok) { return *reinterpret_cast<const uint4 *>(base + (ok ? off : 0)); };
+  auto gload = [&](int slot) __attribute__((always_inline)) {
+    const int j = act_at(min(g_ka, 15));
+    const int nbp = g_ka < na ? (s_cnt[j] + 15) & ~15 : 0;  // past the end: nothing is requested
+    const int k = kbeg + j;
+    const int kw = p.flip_k ? K - 1 - k : k;
+    const int c0 = g_cc * BK;
+    unsigned okb = 0u;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int r = a_r + 32 * i;
+      const int src = r < nbp ? s_src[j * CM + r] : -1;
+      const bool ok = src >= 0;
+      ga[slot][i] = ldraw(p.x, (int64_t)src * p.ldx + c0 + 4 * a_cc, ok);
+      okb |= ok ? (1u << i) : 0u;
+    }
+    if (nbp) {  // uniform
+      if (!W_T) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            gw[slot][4 * h + s] = p.w[((int64_t)kw * p.cin + c0 + 16 * h + 4 * kq + s) * p.cout + n0 + 16 * cs + n];
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 t = *reinterpret_cast<const float4 *>(p.w + ((int64_t)kw * p.cout + n0 + 16 * cs + n) * p.cin + c0 + 16 * h + 4 * kq);
+          gw[slot][4 * h + 0] = t.x, gw[slot][4 * h + 1] = t.y, gw[slot][4 * h + 2] = t.z, gw[slot][4 * h + 3] = t.w;
+        }
+      }
+    }
+    g_ok[slot] = okb, g_nbp[slot] = nbp;
+    if (++g_cc == ncc) g_cc = 0, ++g_ka;
+  };
+  auto sts = [&](int slot, int buf) __attribute__((always_inline)) {
+    float *a = sA + buf * CM * LDA;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int r = a_r + 32 * i;
+      const unsigned m = (g_ok[slot] >> i) & 1u ? 0xFFFFFFFFu : 0u;
+      if (r < g_nbp[slot])
+        *reinterpret_cast<uint4 *>(&a[r * LDA + 4 * a_cc]) = make_uint4(ga[slot][i].x & m, ga[slot][i].y & m, ga[slot][i].z & m, ga[slot][i].w & m);
+    }
+  };
+
+  f32x4 acc[NBLK];
+#pragma unroll
+  for (int i = 0; i < NBLK; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float *myC = sC + 16 * cs + 4 * kq;
+  float wf[8], wf_next[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) wf[e] = 0.f, wf_next[e] = 0.f;
+
+  if (n_items > 0) {  // item 0 -> LDS, items 1 .. CD in flight (slot = item % CD)
+    gload(0);
+    sts(0, 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wf[e] = gw[0][e];
+#pragma unroll
+    for (int d = 1; d <= CD; ++d) gload(d % CD);
+  }
+  MINK_LDS_BARRIER();
+  int ka = 0, cc = 0;
+  auto step = [&](int it, auto nslot_c) __attribute__((always_inline)) {
+    constexpr int nslot = decltype(nslot_c)::value;
+    if (it + 1 < n_items) {
+      sts(nslot, (it + 1) & 1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wf_next[e] = gw[nslot][e];
+    }
+    gload(nslot);  // item it + 1 + CD (requests nothing past the end)
+    const int j = act_at(ka);
+    const int nb = __builtin_amdgcn_readfirstlane((s_cnt[j] + 15) >> 4);  // >= 1
+    const float *a = sA + (it & 1) * CM * LDA + n * LDA + 4 * kq;
+    // the operands of block b + 1 are read before the MFMAs of block b; block 0 is unconditional so that its MFMAs
+    // share a scheduling region with the LDS stores / address arithmetic / global loads above
+    float4 x0 = *reinterpret_cast<const float4 *>(a), x1 = *reinterpret_cast<const float4 *>(a + 16);
+    auto mfma8 = [&](f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], u0.z, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], u0.w, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], u1.x, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], u1.y, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], u1.z, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], u1.w, c, 0, 0, 0);
+    };
+    {
+      const float4 y0 = *reinterpret_cast<const float4 *>(a + 16 * LDA), y1 = *reinterpret_cast<const float4 *>(a + 16 * LDA + 16);
+      mfma8(acc[0], x0, x1);
+      x0 = y0, x1 = y1;
+    }
+#pragma unroll
+    for (int blk = 1; blk < NBLK; ++blk) {
+      if (blk < nb) {  // uniform
+        const int nx = blk + 1 < NBLK ? blk + 1 : NBLK - 1;  // (rows past the compacted count hold stale data that is never multiplied)
+        const float4 y0 = *reinterpret_cast<const float4 *>(a + nx * 16 * LDA), y1 = *reinterpret_cast<const float4 *>(a + nx * 16 * LDA + 16);
+        mfma8(acc[blk], x0, x1);
+        x0 = y0, x1 = y1;
+      }
+    }
+    if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
+      cc = 0, ++ka;
+      auto scatter = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
+        constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+        int lr[hi - lo];
+        float4 c[hi - lo];
+#pragma unroll
+        for (int b = lo; b < hi; ++b) lr[b - lo] = b < nb ? (int)s_lrow[j * CM + b * 16 + n] : CM;
+#pragma unroll
+        for (int b = lo; b < hi; ++b) c[b - lo] = *reinterpret_cast<const float4 *>(myC + lr[b - lo] * CLDC);
+#pragma unroll
+        for (int b = lo; b < hi; ++b) {
+          float4 &v = c[b - lo];
+          v.x += acc[b][0], v.y += acc[b][1], v.z += acc[b][2], v.w += acc[b][3];
+          *reinterpret_cast<float4 *>(myC + lr[b - lo] * CLDC) = v;
+          acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      };
+      scatter(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+      if constexpr (NBLK > 4) {
+        if (nb > 4) scatter(std::integral_constant<int, 4>{}, std::integral_constant<int, NBLK>{});
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wf[e] = wf_next[e];
+    MINK_LDS_BARRIER();
+  };
+  static_assert(CD == 3, "the steady-state loop is unrolled by hand");
+  for (int base = 0; base < n_items; base += CD) {
+    step(base, std::integral_constant<int, 1>{});
+    if (base + 1 < n_items) step(base + 1, std::integral_constant<int, 2>{});
+    if (base + 2 < n_items) step(base + 2, std::integral_constant<int, 0>{});
+  }
+
+  // ---- epilogue: y / slab = C (+ bias), column statistics of the tile for the batch norm that follows
+  const bool direct = gridDim.z == 1;
+  float *dst = direct ? p.y : p.ws + (int64_t)blockIdx.z * p.n_out * p.cout;
+  const int ldd = direct ? p.ldy : p.cout;
+  const int c4 = tid & 15, rg = tid >> 4;
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (direct && p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n0 + 4 * c4);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+#pragma unroll
+  for (int jr = 0; jr < NBLK; ++jr) {
+    const int r = rg + 16 * jr;
+    if (r < rows_here) {
+      const float4 u = *reinterpret_cast<const float4 *>(&sC[r * CLDC + 4 * c4]);
+      const float4 o = make_float4(u.x + bias.x, u.y + bias.y, u.z + bias.z, u.w + bias.w);
+      *reinterpret_cast<float4 *>(&dst[(o0 + r) * ldd + n0 + 4 * c4]) = o;
+      s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
+      q.x += o.x * o.x, q.y += o.y * o.y, q.z += o.z * o.z, q.w += o.w * o.w;
+    }
+  }
+  if (p.stats && direct) {  // uniform
+    float *red = sA;  // [16 row groups][2][64]; the tiles are dead (last barrier)
+    *reinterpret_cast<float4 *>(&red[(rg * 2 + 0) * BN + 4 * c4]) = s;
+    *reinterpret_cast<float4 *>(&red[(rg * 2 + 1) * BN + 4 * c4]) = q;
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid >> 6, c = tid & 63;
+      float t = 0.f;
+      for (int g = 0; g < 16; ++g) t += red[(g * 2 + which) * BN + c];
+      p.stats[((int64_t)blockIdx.x * 2 + which) * p.cout + n0 + c] = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ wgrad
 // dW[k][ci][co] = sum over pairs (i,o) of offset k:  x[i][ci] * dy[o][co].
 //
@@ -1647,6 +1911,7 @@ static int g_flat = 1;
 static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
 static int g_wgrad_bf16 = getenv("MINK_WGRAD_BF16") ? atoi(getenv("MINK_WGRAD_BF16")) : 1;  // bf16 math: stem weight gradient on the bf16 MFMA too
 static int g_wgrad_bf16_off = 0;
+static int g_compact = getenv("MINK_COMPACT") ? atoi(getenv("MINK_COMPACT")) : 1;  // fp32 mid layers on compact_gemm_kernel
 static int g_wgrad_xcd = getenv("MINK_WGRAD_XCD") ? atoi(getenv("MINK_WGRAD_XCD")) : 1;  // streaming wgrad: groups of a row split share an XCD (stream_slot)
 
 extern "C" {
@@ -1659,6 +1924,7 @@ int mink_conv_set_stagger(int units) {
   g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
   g_wgrad_bf16_off = (units >> 28) & 1;  // bit 28: bf16 math keeps the exact-fp32 weight-gradient kernel (A/B tests)
   g_wgrad_xcd = !((units >> 29) & 1);    // bit 29: plain workgroup order in the streaming weight-gradient kernels (A/B)
+  g_compact = !((units >> 30) & 1);      // bit 30: mid layers back on gather_gemm2_kernel (A/B)
   g_offset_major = (units & 2048) != 0;  // bit 11: offset-major, row-compacted path for the deep layers (Cin >= 256)
   g_wgrad_force = (units >> 12) & 0xFFFF;  // bits 12-15: force G (1, 3, 9), bits 16-27: force the row split count
   return old;
@@ -1741,8 +2007,30 @@ int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_cl
   return best;
 }
 
+// compact_gemm_kernel (fp32, no row permutation): 64-row tiles, four workgroups per CU, at most CKP offsets per workgroup.
+// kbench ksweep on the ResNet layers: the best split is the largest one that keeps the launch within two resident rounds
+// (2 x 1024 workgroups), capped at 14 slabs -- l2.conv2 83 us at 7 slabs against 94 at the 3 the older rule picks.
+static bool compact_shape(int64_t n_rows, int K, int cin, int cout, int row_classes) {
+  if (!(g_compact && g_math == 0 && !row_classes && K >= 8 && cin >= 64 && cin % BK == 0 && cout % BN == 0 && n_rows >= 1))
+    return false;
+  const int64_t zmin = cdiv(K, CKP);  // the fewest slabs the rulebook allows; beyond the slab budget: the dense kernel, un-split
+  return zmin == 1 || zmin * 4 * n_rows * cout <= (128ll << 20);
+}
+static int compact_plan(int64_t n_rows, int K, int cout) {
+  const int64_t tiles = cdiv(n_rows, 64) * cdiv(cout, BN);
+  const int64_t slab_cap = std::max<int64_t>(1, (128ll << 20) / (4 * n_rows * cout));
+  int best = (int)cdiv(K, CKP);
+  for (int kper = CKP; kper >= 1; --kper) {
+    const int zs = (int)cdiv(K, kper);
+    if (zs > 14 || tiles * zs > 2048 || (zs > 1 && zs > slab_cap)) break;
+    best = zs;
+  }
+  return best;
+}
+
 int mink_conv_plan(int64_t n_rows, int32_t K, int32_t cin, int32_t cout, int32_t row_classes) {
   if (offset_major_shape(n_rows, K, cin, cout)) return K;  // one slab per offset (offset_gemm_kernel)
+  if (compact_shape(n_rows, K, cin, cout, row_classes)) return compact_plan(n_rows, K, cout);
   return mink_conv_plan_ksplit(n_rows, K, cout, row_classes);
 }
 
@@ -1806,7 +2094,25 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
     return MINK_OK;
   }
   if (stats_direct) p.stats = (float *)stats_ws;
-  {
+  unsigned tiles_x = grid.x;  // row tiles that wrote statistics partials
+  const bool compact = g_compact && g_math == 0 && vec && g_pipeline && !row_perm && !p.accumulate && K >= 8 && p.kper <= CKP && cin >= 64 &&
+                       cin % BK == 0 && cout % BN == 0 && (ldy & 3) == 0 &&
+                       (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
+  if (compact) {  // row-compacted offsets, C tile in LDS (compact_gemm_kernel)
+    constexpr int CMT = 64;
+    constexpr int smem = compact_smem(CMT);
+    static const bool attr_ok = [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<false, CMT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 smem) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<true, CMT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 smem) == hipSuccess;
+    }();
+    MINK_REQUIRE(attr_ok, "gather_gemm: %d bytes of LDS per workgroup refused", smem);
+    const dim3 cgrid((unsigned)cdiv(n_out, CMT), grid.y, grid.z);
+    if (w_transposed) compact_gemm_kernel<true, CMT><<<cgrid, 256, smem, st>>>(p);
+    else compact_gemm_kernel<false, CMT><<<cgrid, 256, smem, st>>>(p);
+    tiles_x = cgrid.x;
+  } else {
     const bool stage = row_perm != nullptr;
     if (vec && g_pipeline) {
       const bool flat = cin == 28 && zs == 1 && !flip_k && !w_transposed && !stage && g_flat;
@@ -1829,8 +2135,8 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   }
   MINK_CHECK_LAUNCH();
   if (stats_direct) {
-    const int rows = (int)std::min<int64_t>(512, cdiv((int64_t)grid.x, 8));  // >= 8 tiles per partial row: a latency-bound pass
-    colsum_f32_kernel<<<dim3((unsigned)rows), 256, 0, st>>>((const float *)stats_ws, (int64_t)grid.x, 2 * cout, stats_out);
+    const int rows = (int)std::min<int64_t>(512, cdiv((int64_t)tiles_x, 8));  // >= 8 tiles per partial row: a latency-bound pass
+    colsum_f32_kernel<<<dim3((unsigned)rows), 256, 0, st>>>((const float *)stats_ws, (int64_t)tiles_x, 2 * cout, stats_out);
     MINK_CHECK_LAUNCH();
     *stats_rows = rows;
   }
@@ -1858,7 +2164,7 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
 }
 
 int64_t mink_conv_stats_workspace_bytes(int64_t n_out, int32_t cout) {
-  return (int64_t)cdiv(n_out > 0 ? n_out : 1, BM) * 2 * cout * sizeof(float);
+  return (int64_t)cdiv(n_out > 0 ? n_out : 1, 64) * 2 * cout * sizeof(float);  // (row tiles of 64: compact_gemm_kernel)
 }
 
 int mink_conv_gather_gemm_stats(const float *x, int32_t ldx, int32_t cin, const float *w, const int32_t *nbr,

@@ -60,6 +60,7 @@ def set_conv_math(mode="fp32"):
     if mode not in _MATH:
         raise ValueError(f"conv math {mode!r}: choose from {sorted(set(_MATH))}")
     old = lib().mink_conv_set_math(_MATH[mode])
+    _PLAN_CACHE.clear()  # the split plan depends on which kernel the mode selects
     return {0: "fp32", 1: "bf16", 3: "bf16x3"}[old]
 
 

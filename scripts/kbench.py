@@ -182,6 +182,50 @@ if which == "ksweep":
                 Fn._FORCE_KSPLIT = 0
                 t0 = timeit(lambda: Fn.gather_gemm(gy, wt, nbr_t, ci, row_perm=perm), reps) * 1e3
                 print(f"{name} dgrad n_in={xin.shape[0]} {cout}->{ci} planner={t0:.1f}us | " + " ".join(f"{z}:{t:.0f}" for z, t in res))
+if which == "compact":  # mid layers: row-compacted kernel (default) against gather_gemm2 (set_stagger bit 30)
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    tot = {0: 0.0, 1: 0.0}
+    for ts in (2, 4, 8, 16):
+        cin, cout = chans[ts], chans[ts * 2]
+        for name, ik, ok, ci, stride in ((f"l@{ts}.c1", keys[ts], keys[ts * 2], cin, 2), (f"l@{ts*2}.c2", keys[ts * 2], keys[ts * 2], cout, 1)):
+            nbr, _ = m.kernel_table(ik, ok, 3, 1)
+            fill = float((nbr >= 0).float().mean())
+            xin = torch.randn(m.levels[ts if stride == 2 else ts * 2].n, ci, device=dev)
+            w = torch.randn(27, ci, cout, device=dev) * 0.05
+            cases = [("fwd", lambda: Fn.gather_gemm(xin, w, nbr, cout))]
+            if stride == 1:
+                gy = torch.randn(nbr.shape[0], cout, device=dev)
+                cases.append(("dgrad", lambda: Fn.gather_gemm(gy, w, nbr, ci, w_transposed=True, flip_k=True)))
+            for cname, fn in cases:
+                out, tt = {}, {}
+                for off in (1, 0, 1, 0):
+                    lib().mink_conv_set_stagger(off << 30)
+                    Fn._PLAN_CACHE.clear()
+                    tt[off] = timeit(fn, reps) * 1e3
+                    out[off] = fn()
+                lib().mink_conv_set_stagger(0)
+                err = float((out[0] - out[1]).abs().max() / out[1].abs().max())
+                tot[0] += tt[0]; tot[1] += tt[1]
+                print(f"{name} {cname:5s} rows={nbr.shape[0]:6d} {ci}->{cout} fill={fill:.2f}: compact {tt[0]:7.1f} us, dense {tt[1]:7.1f} us, rel diff {err:.2e}")
+    print(f"sum: compact {tot[0]:.1f} us, dense {tot[1]:.1f} us")
+if which == "cablate":  # compact kernel: what does an item wait for?  (ablation bits in the low byte of set_stagger)
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    for ts, c in ((4, 64), (32, 512)):
+        nbr, _ = m.kernel_table(keys[ts], keys[ts], 3, 1)
+        xin = torch.randn(nbr.shape[0], c, device=dev)
+        w = torch.randn(27, c, c, device=dev) * 0.05
+        for bits, label in ((0, "full"), (1, "no scatter"), (2, "gathers of row 0"), (4, "no MFMA"), (8, "no store"), (16, "no weight loads"), (31, "nothing"), (1 << 30, "dense kernel")):
+            lib().mink_conv_set_stagger(bits)
+            t = timeit(lambda: Fn.gather_gemm(xin, w, nbr, c), reps) * 1e3
+            print(f"ts={ts} rows={nbr.shape[0]} {c}->{c}: {label:18s} {t:7.1f} us")
+        lib().mink_conv_set_stagger(0)
 if which == "wsweep":
     from nerf_downstream_amd._lib import lib
     keys = {1: k1}
