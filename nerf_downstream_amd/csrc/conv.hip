@@ -979,19 +979,27 @@ __global__ __launch_bounds__(256) void offset_reduce_kernel(const float *__restr
 // those of gather_gemm2_kernel.  Offsets per workgroup <= CKP (split launches; the planner's slices are 2-9 offsets).
 constexpr int CLDC = BN + 4;         // row stride of the C tile (floats)
 constexpr int CKP = 9;               // offsets per workgroup the rulebook has room for
-constexpr int CD = 3;                // items of global loads in flight
+constexpr int CD = 3;                // ring of global-load register sets (an item is requested CD - 1 items ahead; 4 sets spill at 128 VGPRs)
 constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * LDA + CKP * CM + 32) * 4 + CKP * CM; }
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+// raw buffer loads with a per-lane byte offset (VGPR) and a per-item byte offset (SGPR): no address arithmetic per load
+__device__ f32x4 raw_load_v4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float raw_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 
 // CM: rows per tile.  64: 39 KB of LDS, four workgroups (16 waves) per CU -- the latency of an item's chain (barrier,
-// LDS stores, rulebook reads, operand reads, scatter) is hidden by the other workgroups; 128: half the weight traffic.
+// LDS stores, operand reads, scatter) is hidden by the other workgroups; 128: half the weight traffic.
+// Instruction diet (PMC: the matrix pipe and the vector ALU do not co-execute on this part, every VALU instruction is
+// a slot the MFMAs lose): item metadata (offset list, block counts) lives in SGPRs; weight fragments come through
+// buffer loads whose lane offsets are computed once; padding rows of a block are not zeroed -- row n of the gathered
+// operand only reaches column n of the product, which the rulebook sends to the spare C row.
 template <bool W_T, int CM>
 __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(GemmParams p) {
   constexpr int NBLK = CM / 16, NH = CM / 64, NA = CM / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char c_smem[];
   float *sC = reinterpret_cast<float *>(c_smem);             // [CM + 1][CLDC]; row CM takes the padding lanes
   float *sA = sC + (CM + 1) * CLDC;                          // [2][CM][LDA] compacted gathered rows
-  int *s_src = reinterpret_cast<int *>(sA + 2 * CM * LDA);   // [CKP][CM] input row of the p-th compacted row (-1: padding)
+  int *s_src = reinterpret_cast<int *>(sA + 2 * CM * LDA);   // [CKP][CM] input row of the p-th compacted row (padding: row 0)
   int *s_cnt = s_src + CKP * CM;                             // [32] compacted rows per offset of the slice
   unsigned char *s_lrow = reinterpret_cast<unsigned char *>(s_cnt + 32);  // [CKP][CM] tile row of the p-th compacted row
 
@@ -1033,105 +1041,106 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
         }
         cnt += __popcll(b);
       }
-      const int pad = ((cnt + 15) & ~15) - cnt;
-      if (lane < pad) s_src[jj * CM + cnt + lane] = -1, s_lrow[jj * CM + cnt + lane] = (unsigned char)CM;
+      // behind the compacted rows: input row 0 (read, multiplied into columns nobody keeps) and the spare C row
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh)
+        if (lane + 64 * hh >= cnt) s_src[jj * CM + lane + 64 * hh] = 0, s_lrow[jj * CM + lane + 64 * hh] = (unsigned char)CM;
       if (lane == 0) s_cnt[jj] = cnt;
     }
   }
   __syncthreads();
-  // offsets of the slice that have rows, packed four bits each (nk <= CKP = 9 < 16 entries)
-  unsigned long long act = 0ull;
+  // the slice's offsets that have rows and their block counts, four bits each, in scalar registers (nk <= 9 entries)
+  unsigned act_lo = 0u, act_hi = 0u, nbs_lo = 0u, nbs_hi = 0u;
   int na = 0;
-  for (int j = 0; j < nk; ++j)
-    if (s_cnt[j] > 0) act |= (unsigned long long)j << (4 * na++);
-  auto act_at = [&](int a) { return (int)((act >> (4 * a)) & 15u); };
+  for (int j = 0; j < nk; ++j) {
+    const int cnt = __builtin_amdgcn_readfirstlane(s_cnt[j]);
+    if (cnt > 0) {
+      const unsigned nbj = (unsigned)((cnt + 15) >> 4);
+      if (na < 8) act_lo |= (unsigned)j << (4 * na), nbs_lo |= nbj << (4 * na);
+      else act_hi |= (unsigned)j << (4 * (na - 8)), nbs_hi |= nbj << (4 * (na - 8));
+      ++na;
+    }
+  }
+  auto nib = [](unsigned lo, unsigned hi, int a) { return (int)(((a < 8 ? lo : hi) >> (4 * (a & 7))) & 15u); };
   const int ncc = p.cin / BK;
   const int n_items = na * ncc;
 
-  // ---- staging: A rows a_r + 32 i (float4 column a_cc); weight fragment of this lane: channels 4 kq + s + 16 h
+  // ---- weight fragment of this lane: channels 16 h + 4 kq + s of the chunk, column 16 cs + n; byte offsets inside the
+  // chunk are fixed per lane, the chunk's own offset is a scalar
+  i32x4 rw;
+  {
+    const unsigned long long wa = (unsigned long long)p.w;
+    rw.x = (int)(unsigned)wa, rw.y = (int)((wa >> 32) & 0xFFFFu), rw.z = (int)(4u * (unsigned)K * (unsigned)p.cin * (unsigned)p.cout), rw.w = 0x00020000;
+  }
+  int wv[W_T ? 2 : 8];
+  if (!W_T) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wv[e] = 4 * ((16 * (e >> 2) + 4 * kq + (e & 3)) * p.cout + 16 * cs + n);
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) wv[h] = 4 * ((16 * cs + n) * p.cin + 16 * h + 4 * kq);
+  }
+  // ---- staging of the gathered rows: rows a_r + 32 i, float4 column a_cc
   const int a_cc = tid & 7, a_r = tid >> 3;
-  uint4 ga[CD][NA];
+  const float *xcol = p.x + 4 * a_cc;
+  f32x4 ga[CD][NA];  // (a native vector: copies of the HIP uint4 struct become memcpy calls that keep the ring in scratch)
   float gw[CD][8];
-  unsigned g_ok[CD];
-  int g_nbp[CD];
   int g_ka = 0, g_cc = 0;  // iterator of the global-load stage
-  auto ldraw = [&](const float *base, int64_t off, bool ok) { return *reinterpret_cast<const uint4 *>(base + (ok ? off : 0)); };
+  // every call issues the same NA + (W_T ? 2 : 8) loads, whatever the item: the vmcnt distances of the ring are static
+  // (a conditional load would make every wait a wait for ALL loads in flight); past the end the last item is re-read
   auto gload = [&](int slot) __attribute__((always_inline)) {
-    const int j = act_at(min(g_ka, 15));
-    const int nbp = g_ka < na ? (s_cnt[j] + 15) & ~15 : 0;  // past the end: nothing is requested
+    const int ga_ = min(g_ka, na - 1);
+    const int j = nib(act_lo, act_hi, ga_);
     const int k = kbeg + j;
     const int kw = p.flip_k ? K - 1 - k : k;
     const int c0 = g_cc * BK;
-    unsigned okb = 0u;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int r = a_r + 32 * i;
-      const int src = r < nbp ? s_src[j * CM + r] : -1;
-      const bool ok = src >= 0;
-      ga[slot][i] = ldraw(p.x, (int64_t)src * p.ldx + c0 + 4 * a_cc, ok);
-      okb |= ok ? (1u << i) : 0u;
-    }
-    if (nbp) {  // uniform
-      if (!W_T) {
+    for (int i = 0; i < NA; ++i)
+      ga[slot][i] = *reinterpret_cast<const f32x4 *>(xcol + (int64_t)s_src[j * CM + a_r + 32 * i] * p.ldx + c0);
+    if (!W_T) {
+      const int so = 4 * ((kw * p.cin + c0) * p.cout + n0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+      for (int e = 0; e < 8; ++e) gw[slot][e] = raw_load_f32(rw, wv[e], so, 0);
+    } else {
+      const int so = 4 * ((kw * p.cout + n0) * p.cin + c0);
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            gw[slot][4 * h + s] = p.w[((int64_t)kw * p.cin + c0 + 16 * h + 4 * kq + s) * p.cout + n0 + 16 * cs + n];
-      } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float4 t = *reinterpret_cast<const float4 *>(p.w + ((int64_t)kw * p.cout + n0 + 16 * cs + n) * p.cin + c0 + 16 * h + 4 * kq);
-          gw[slot][4 * h + 0] = t.x, gw[slot][4 * h + 1] = t.y, gw[slot][4 * h + 2] = t.z, gw[slot][4 * h + 3] = t.w;
-        }
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 t = raw_load_v4(rw, wv[h], so, 0);
+        gw[slot][4 * h + 0] = t[0], gw[slot][4 * h + 1] = t[1], gw[slot][4 * h + 2] = t[2], gw[slot][4 * h + 3] = t[3];
       }
     }
-    g_ok[slot] = okb, g_nbp[slot] = nbp;
-    if (++g_cc == ncc) g_cc = 0, ++g_ka;
+    if (g_ka < na && ++g_cc == ncc) g_cc = 0, ++g_ka;
   };
   auto sts = [&](int slot, int buf) __attribute__((always_inline)) {
     float *a = sA + buf * CM * LDA;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int r = a_r + 32 * i;
-      const unsigned m = (g_ok[slot] >> i) & 1u ? 0xFFFFFFFFu : 0u;
-      if (r < g_nbp[slot])
-        *reinterpret_cast<uint4 *>(&a[r * LDA + 4 * a_cc]) = make_uint4(ga[slot][i].x & m, ga[slot][i].y & m, ga[slot][i].z & m, ga[slot][i].w & m);
-    }
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&a[(a_r + 32 * i) * LDA + 4 * a_cc]) = ga[slot][i];
   };
 
   f32x4 acc[NBLK];
 #pragma unroll
   for (int i = 0; i < NBLK; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float *myC = sC + 16 * cs + 4 * kq;
-  float wf[8], wf_next[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) wf[e] = 0.f, wf_next[e] = 0.f;
 
-  if (n_items > 0) {  // item 0 -> LDS, items 1 .. CD in flight (slot = item % CD)
-    gload(0);
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  static_assert(CD == 3, "the steady-state loop is unrolled by hand");
+  // items 0 .. CD - 1 requested (slot = item % CD), item 0 -> LDS
+  if (n_items > 0) {  // uniform
+    gload(0), gload(1), gload(2);
     sts(0, 0);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) wf[e] = gw[0][e];
-#pragma unroll
-    for (int d = 1; d <= CD; ++d) gload(d % CD);
   }
   MINK_LDS_BARRIER();
   int ka = 0, cc = 0;
-  auto step = [&](int it, auto nslot_c) __attribute__((always_inline)) {
-    constexpr int nslot = decltype(nslot_c)::value;
-    if (it + 1 < n_items) {
-      sts(nslot, (it + 1) & 1);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) wf_next[e] = gw[nslot][e];
-    }
-    gload(nslot);  // item it + 1 + CD (requests nothing past the end)
-    const int j = act_at(ka);
-    const int nb = __builtin_amdgcn_readfirstlane((s_cnt[j] + 15) >> 4);  // >= 1
+  auto step = [&](int it, auto slot_c, auto nslot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
+    const int j = nib(act_lo, act_hi, ka), nb = nib(nbs_lo, nbs_hi, ka);  // nb >= 1
+    sts(decltype(nslot_c)::value, (it + 1) & 1);  // item it + 1 (after the last item: a re-read copy nobody multiplies)
     const float *a = sA + (it & 1) * CM * LDA + n * LDA + 4 * kq;
-    // the operands of block b + 1 are read before the MFMAs of block b; block 0 is unconditional so that its MFMAs
-    // share a scheduling region with the LDS stores / address arithmetic / global loads above
-    float4 x0 = *reinterpret_cast<const float4 *>(a), x1 = *reinterpret_cast<const float4 *>(a + 16);
+    float wf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wf[e] = gw[slot][e];
     auto mfma8 = [&](f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
       c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
@@ -1142,18 +1151,39 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], u1.z, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], u1.w, c, 0, 0, 0);
     };
-    {
-      const float4 y0 = *reinterpret_cast<const float4 *>(a + 16 * LDA), y1 = *reinterpret_cast<const float4 *>(a + 16 * LDA + 16);
-      mfma8(acc[0], x0, x1);
-      x0 = y0, x1 = y1;
-    }
+    auto mfma16 = [&](f32x4 &c, f32x4 &d, const float4 &u0, const float4 &u1, const float4 &v0, const float4 &v1) __attribute__((always_inline)) {
+      // two blocks, alternating accumulators: a dependent MFMA is two instructions away
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], v0.x, d, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], v0.y, d, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], u0.z, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], v0.z, d, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], u0.w, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], v0.w, d, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], u1.x, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], v1.x, d, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], u1.y, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], v1.y, d, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], u1.z, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], v1.z, d, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], u1.w, c, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], v1.w, d, 0, 0, 0);
+    };
+    auto xr = [&](int blk, int half) __attribute__((always_inline)) { return *reinterpret_cast<const float4 *>(a + blk * 16 * LDA + 16 * half); };
+    // blocks in pairs; the operands of the next pair are read before this pair's MFMAs (rows past the compacted count
+    // hold stale data that is read but never multiplied)
+    float4 x[4] = {xr(0, 0), xr(0, 1), xr(1, 0), xr(1, 1)};
 #pragma unroll
-    for (int blk = 1; blk < NBLK; ++blk) {
-      if (blk < nb) {  // uniform
-        const int nx = blk + 1 < NBLK ? blk + 1 : NBLK - 1;  // (rows past the compacted count hold stale data that is never multiplied)
-        const float4 y0 = *reinterpret_cast<const float4 *>(a + nx * 16 * LDA), y1 = *reinterpret_cast<const float4 *>(a + nx * 16 * LDA + 16);
-        mfma8(acc[blk], x0, x1);
-        x0 = y0, x1 = y1;
+    for (int b = 0; b < NBLK; b += 2) {
+      if (b < nb) {  // uniform
+        float4 y[4];
+        const int nx = b + 2 < NBLK ? b + 2 : b;
+        y[0] = xr(nx, 0), y[1] = xr(nx, 1), y[2] = xr(nx + 1, 0), y[3] = xr(nx + 1, 1);
+        if (b + 1 < nb) mfma16(acc[b], acc[b + 1], x[0], x[1], x[2], x[3]);
+        else mfma8(acc[b], x[0], x[1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = y[e];
       }
     }
     if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
@@ -1174,20 +1204,22 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
           acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
       };
-      scatter(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+      // (each accumulator is named in ONE place: two call sites that differ only in the block index get tail-merged
+      //  behind a pointer phi, and the accumulators then live in scratch memory)
+      scatter(S0{}, S2{});
+      if (nb > 2) scatter(S2{}, std::integral_constant<int, 4>{});
       if constexpr (NBLK > 4) {
-        if (nb > 4) scatter(std::integral_constant<int, 4>{}, std::integral_constant<int, NBLK>{});
+        if (nb > 4) scatter(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
+        if (nb > 6) scatter(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
       }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) wf[e] = wf_next[e];
+    gload(slot);  // item it + CD takes the registers of item it
     MINK_LDS_BARRIER();
   };
-  static_assert(CD == 3, "the steady-state loop is unrolled by hand");
   for (int base = 0; base < n_items; base += CD) {
-    step(base, std::integral_constant<int, 1>{});
-    if (base + 1 < n_items) step(base + 1, std::integral_constant<int, 2>{});
-    if (base + 2 < n_items) step(base + 2, std::integral_constant<int, 0>{});
+    step(base, S0{}, S1{});
+    if (base + 1 < n_items) step(base + 1, S1{}, S2{});
+    if (base + 2 < n_items) step(base + 2, S2{}, S0{});
   }
 
   // ---- epilogue: y / slab = C (+ bias), column statistics of the tile for the batch norm that follows
@@ -2096,7 +2128,7 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   if (stats_direct) p.stats = (float *)stats_ws;
   unsigned tiles_x = grid.x;  // row tiles that wrote statistics partials
   const bool compact = g_compact && g_math == 0 && vec && g_pipeline && !row_perm && !p.accumulate && K >= 8 && p.kper <= CKP && cin >= 64 &&
-                       cin % BK == 0 && cout % BN == 0 && (ldy & 3) == 0 &&
+                       cin % BK == 0 && cout % BN == 0 && (ldy & 3) == 0 && 4ll * K * cin * cout < (1ll << 31) &&
                        (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
   if (compact) {  // row-compacted offsets, C tile in LDS (compact_gemm_kernel)
     constexpr int CMT = 64;

@@ -212,7 +212,7 @@ if which == "compact":  # mid layers: row-compacted kernel (default) against gat
                 tot[0] += tt[0]; tot[1] += tt[1]
                 print(f"{name} {cname:5s} rows={nbr.shape[0]:6d} {ci}->{cout} fill={fill:.2f}: compact {tt[0]:7.1f} us, dense {tt[1]:7.1f} us, rel diff {err:.2e}")
     print(f"sum: compact {tot[0]:.1f} us, dense {tot[1]:.1f} us")
-if which == "cablate":  # compact kernel: what does an item wait for?  (ablation bits in the low byte of set_stagger)
+if which == "cablate":  # l1.conv2 / l4.conv2 forward on the compact and the dense kernel (the PMC passes of scripts/pmc_kbench.sh run this)
     from nerf_downstream_amd._lib import lib
     keys = {1: k1}
     for ts in (2, 4, 8, 16, 32):
@@ -221,8 +221,9 @@ if which == "cablate":  # compact kernel: what does an item wait for?  (ablation
         nbr, _ = m.kernel_table(keys[ts], keys[ts], 3, 1)
         xin = torch.randn(nbr.shape[0], c, device=dev)
         w = torch.randn(27, c, c, device=dev) * 0.05
-        for bits, label in ((0, "full"), (1, "no scatter"), (2, "gathers of row 0"), (4, "no MFMA"), (8, "no store"), (16, "no weight loads"), (31, "nothing"), (1 << 30, "dense kernel")):
+        for bits, label in ((0, "compact kernel"), (1 << 30, "dense kernel")):
             lib().mink_conv_set_stagger(bits)
+            Fn._PLAN_CACHE.clear()
             t = timeit(lambda: Fn.gather_gemm(xin, w, nbr, c), reps) * 1e3
             print(f"ts={ts} rows={nbr.shape[0]} {c}->{c}: {label:18s} {t:7.1f} us")
         lib().mink_conv_set_stagger(0)

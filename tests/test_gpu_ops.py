@@ -465,3 +465,66 @@ def test_stem_weight_gradient_on_bf16_matrix_cores(oracle_maps):
         grads[tag] = net.conv1.kernel.grad.clone()
     rel = float((grads["bf16 wgrad"] - grads["fp32 wgrad"]).norm() / grads["fp32 wgrad"].norm())
     assert 1e-6 < rel < 1e-2, rel
+
+
+@pytest.mark.parametrize("n_out,K,cin,cout", [(1, 27, 64, 64), (63, 27, 64, 128), (65, 27, 96, 64), (1000, 27, 128, 128),
+                                              (4097, 27, 64, 64), (300, 8, 64, 64), (129, 9, 256, 64)])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_row_compacted_kernel_against_float64(n_out, K, cin, cout, transposed):
+    """compact_gemm_kernel (fp32 mid layers: per-offset row compaction, C tile in LDS) on synthetic tables: ragged row
+    counts (1, 63, 65 rows: partial tiles and partial 16-row blocks), offsets without any neighbour in a tile, every
+    legal split of the offsets (un-split launches for K <= 9 take the direct epilogue with bias and the fused column
+    statistics), forward and transposed-weight (data gradient) forms -- against a float64 gather + matmul, and bitwise
+    against itself (two runs)."""
+    import ctypes
+    from nerf_downstream_amd._lib import lib
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(n_out * 31 + K + cin)
+    n_in = max(4, n_out + 17)
+    nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
+    nbr[torch.rand(n_out, K, generator=g) < 0.45] = -1      # the mid-layer fill
+    nbr[:, K // 2 - 1] = -1                                  # an offset nobody has
+    if n_out > 70:
+        nbr[64:128, 1] = -1                                  # ... and one that a whole tile lacks
+    x = torch.randn(n_in, cin, generator=g)
+    w = torch.randn(K, cin, cout, generator=g) * 0.1
+    bias = torch.randn(cout, generator=g)
+    wk = w.transpose(1, 2).contiguous() if transposed else w   # transposed form reads W[k] as [cout][cin] and flips k
+    ref = torch.zeros(n_out, cout, dtype=torch.float64)
+    for k in range(K):
+        sel = nbr[:, k] >= 0
+        kw = K - 1 - k if transposed else k
+        ref[sel] += x[nbr[sel, k].long()].double() @ w[kw].double()
+    xd, wd, nd, bd = x.to(dev), wk.to(dev), nbr.to(dev), bias.to(dev)
+    scale = float(ref.abs().max()) + 1e-30
+    L = lib()
+    assert L.mink_conv_plan(n_out, K, cin, cout, 0) * 9 >= K, "the planner must hand this shape to the compacted kernel"
+    splits = sorted({-(-K // kper) for kper in range(1, 10)})
+    try:
+        for zs in splits:
+            Fn._FORCE_KSPLIT = zs
+            direct = zs == 1
+            if transposed:
+                y = Fn.gather_gemm(xd, wd, nd, cout, w_transposed=True, flip_k=True, bias=bd if direct else None)
+                part = None
+            else:
+                y, part = Fn.gather_gemm(xd, wd, nd, cout, bias=bd if direct else None, stats=True)
+            want = ref + (bias.double() if direct else 0.0)
+            err = float((y.cpu().double() - want).abs().max()) / scale
+            assert err < 2e-6, (zs, err)
+            if part is not None:
+                s = part.sum(0).cpu()
+                assert torch.allclose(s[0], want.sum(0), rtol=1e-4, atol=1e-3 * scale), zs
+                assert torch.allclose(s[1], (want * want).sum(0), rtol=1e-4, atol=1e-3 * scale * scale), zs
+            y2 = Fn.gather_gemm(xd, wd, nd, cout, w_transposed=transposed, flip_k=transposed, bias=bd if direct else None)
+            assert torch.equal(y, y2), zs
+            # and the output-stationary kernel it replaces agrees to rounding
+            L.mink_conv_set_stagger(1 << 30)
+            y3 = Fn.gather_gemm(xd, wd, nd, cout, w_transposed=transposed, flip_k=transposed, bias=bd if direct else None)
+            L.mink_conv_set_stagger(0)
+            assert float((y3 - y).abs().max()) / scale < 2e-6, zs
+    finally:
+        Fn._FORCE_KSPLIT = 0
+        L.mink_conv_set_stagger(0)
