@@ -202,6 +202,8 @@ def main():
                     help="launch plumbing only (CPU test): rendezvous over gloo, one all-reduce, print ranks_seen; no compute, no number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--timeline", action="store_true", help="after the timed region: print where the phases of a step "
+                    "fall on the GPU clock of every stream and when the host queued them (diagnostic)")
     args = ap.parse_args()
     if os.environ.get("BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit if stuck
         import faulthandler
@@ -286,24 +288,42 @@ def main():
         Fn.set_wgrad_overlap(os.environ["BENCH_WGRAD_OVERLAP"] != "0")
     state = {"tf": model.process_input(batches[0])}
 
+    gated = os.environ.get("BENCH_PREPARE_GATE", "0") != "0"
+
     def step(i):
         # software pipeline: the TensorField (+ coordinate/kernel maps, built on a side stream) of
         # batch i+1 is prepared while batch i computes; every step builds exactly one set.  The
         # coordinate pyramid is launched first, its row counts are read back (and the kernel maps
         # launched) after forward+backward have been queued, so the host never waits for them.
         tf = state["tf"]
-        nxt = model.process_input(batches[(i + 1) % len(batches)], defer=True)
+        side = getattr(model, "_side", None)
+        Fn.log_phase("step_begin", torch.cuda.current_stream())
+        if not gated:
+            Fn.log_phase("pyramid_begin", side)
+            nxt = model.process_input(batches[(i + 1) % len(batches)], defer=True)
+            Fn.log_phase("pyramid_end", side)
         if reducer is not None:
             reducer.zero_grad()
         else:
             opt.zero_grad(set_to_none=True)
         out = model(tf)
+        if gated:  # the next batch's preparation starts once this batch's stem convolution is done (Fn.mark_phase)
+            Fn.log_phase("forward_queued", torch.cuda.current_stream())
+            if Fn._PHASE_LOG is not None and side is not None:  # (so that the mark below is stamped behind the gate)
+                side.wait_event(Fn.phase_event("stem_forward"))
+            Fn.log_phase("pyramid_begin", side)
+            nxt = model.process_input(batches[(i + 1) % len(batches)], defer=True, gate=Fn.phase_event("stem_forward"))
+            Fn.log_phase("pyramid_end", side)
         loss = F.cross_entropy(out, batches[i % len(batches)]["labels"].long())
         loss.backward()
+        Fn.log_phase("backward_queued", torch.cuda.current_stream())
+        Fn.log_phase("maps_begin", side)
         state["tf"] = model.finish_input(nxt)
+        Fn.log_phase("maps_end", side)
         if reducer is not None:
             reducer.finish()
         opt.step()
+        Fn.log_phase("step_end", torch.cuda.current_stream())
         sched.step()
         return loss
 
@@ -354,6 +374,32 @@ def main():
     dt = time.perf_counter() - t0
     timings = Fn.kernel_timings() if not args.no_kernel_timing else {}
     Fn.enable_kernel_timing(False)
+
+    if args.timeline and rank == 0:
+        # diagnostic: where the phases of a step fall on the GPU clock (every stream) and when the host queued them;
+        # events are per mark and per step, read after one synchronisation, so the host runs ahead as in the timed region
+        Fn._PHASE_LOG = log = []
+        nt = 12
+        for i in range(nt):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        Fn._PHASE_LOG = None
+        begins = [k for k, (n, _, _) in enumerate(log) if n == "step_begin"]
+        acc = {}
+        for b0, b1 in zip(begins[3:-1], begins[4:]):  # steady-state steps: marks of one step relative to its first
+            e0, h0 = log[b0][1], log[b0][2]
+            for n, e, h in log[b0:b1]:
+                a_ = acc.setdefault(n, [0.0, 0.0, 0])
+                a_[0] += e0.elapsed_time(e)
+                a_[1] += (h - h0) * 1e3
+                a_[2] += 1
+            a_ = acc.setdefault("next_step_begin", [0.0, 0.0, 0])
+            a_[0] += e0.elapsed_time(log[b1][1])
+            a_[1] += (log[b1][2] - h0) * 1e3
+            a_[2] += 1
+        print("[bench] timeline (ms after step_begin; GPU clock / host clock when queued):", file=sys.stderr)
+        for n, (g_, h_, c_) in sorted(acc.items(), key=lambda kv: kv[1][0] / kv[1][2]):
+            print(f"[bench]   {n:22s} gpu {g_ / c_:7.3f}   host {h_ / c_:7.3f}", file=sys.stderr)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     vox = torch.tensor([float(sum(vox_per_step[(args.warmup + i) % len(batches)] for i in range(args.steps)))],

@@ -980,7 +980,7 @@ __global__ __launch_bounds__(256) void offset_reduce_kernel(const float *__restr
 constexpr int CLDC = BN + 4;         // row stride of the C tile (floats)
 constexpr int CKP = 9;               // offsets per workgroup the rulebook has room for
 constexpr int CD = 3;                // ring of global-load register sets (an item is requested CD - 1 items ahead; 4 sets spill at 128 VGPRs)
-constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * LDA + CKP * CM + 32) * 4 + CKP * CM; }
+constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * LDA + CKP * CM + 32) * 4 + CKP * CM + 4 * CM; }
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 // raw buffer loads with a per-lane byte offset (VGPR) and a per-item byte offset (SGPR): no address arithmetic per load
@@ -993,15 +993,22 @@ __device__ float raw_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __a
 // a slot the MFMAs lose): item metadata (offset list, block counts) lives in SGPRs; weight fragments come through
 // buffer loads whose lane offsets are computed once; padding rows of a block are not zeroed -- row n of the gathered
 // operand only reaches column n of the product, which the rulebook sends to the spare C row.
-template <bool W_T, int CM>
+// PERM (the data gradient of a strided convolution, rows grouped by parity class): tile row v computes output row
+// row_perm[v]; a class-pure tile has at most eight live offsets anywhere among the K, so the slice of a workgroup is not
+// an offset range but ALL offsets -- the rulebook holds the live ones (CKP at a time: a tile that is not class-pure
+// just takes more rounds) -- and a split launch cuts the CHANNEL chunks instead (every slice sees every live offset:
+// balanced whatever the class is).  p.kper is then the number of 32-channel chunks per slice.
+template <bool W_T, int CM, bool PERM = false>
 __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(GemmParams p) {
   constexpr int NBLK = CM / 16, NH = CM / 64, NA = CM / 32;
+  constexpr int NU = PERM ? 7 : 3;  // offsets of the slice a wave looks at (cs, cs + 4, ...)
   extern __shared__ __attribute__((aligned(16))) unsigned char c_smem[];
   float *sC = reinterpret_cast<float *>(c_smem);             // [CM + 1][CLDC]; row CM takes the padding lanes
   float *sA = sC + (CM + 1) * CLDC;                          // [2][CM][LDA] compacted gathered rows
   int *s_src = reinterpret_cast<int *>(sA + 2 * CM * LDA);   // [CKP][CM] input row of the p-th compacted row (padding: row 0)
   int *s_cnt = s_src + CKP * CM;                             // [32] compacted rows per offset of the slice
   unsigned char *s_lrow = reinterpret_cast<unsigned char *>(s_cnt + 32);  // [CKP][CM] tile row of the p-th compacted row
+  int *s_orow = reinterpret_cast<int *>(s_lrow + CKP * CM);  // PERM: [CM] output row of a tile row (-1: padding)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int cs = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = column strip
@@ -1009,61 +1016,48 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
   const int64_t o0 = (int64_t)blockIdx.x * CM;
   const int n0 = blockIdx.y * BN;
   const int K = p.K;
-  const int kbeg = blockIdx.z * p.kper, nk = min(K, kbeg + p.kper) - kbeg;
-  const int rows_here = (int)min((int64_t)CM, p.n_out - o0);
+  const int kbeg = PERM ? 0 : blockIdx.z * p.kper, nk = PERM ? K : min(K, kbeg + p.kper) - kbeg;
+  const int rows_here = (int)min((int64_t)CM, (PERM ? p.n_virtual : p.n_out) - o0);
+  const int ncc_all = p.cin / BK;
+  const int cbeg = PERM ? blockIdx.z * p.kper : 0;                       // first channel chunk of this slice
+  const int ncc = PERM ? min(ncc_all, cbeg + p.kper) - cbeg : ncc_all;   // channel chunks of this slice
 
-  // ---- prologue: rulebook of the slice (a wave takes offsets cs, cs + 4, cs + 8; their table entries are requested
-  // together, straight from global memory: one round trip), C = 0
+  // ---- prologue: table entries of the slice (a wave takes offsets cs, cs + 4, ...; they are requested together,
+  // straight from global memory: one round trip), C = 0
   static_assert(CKP <= 12, "three offsets per wave");
-  int tv[3][NH];
+  int orow[NH];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int hh = 0; hh < NH; ++hh) {
+    const int r = lane + 64 * hh;
+    orow[hh] = r < rows_here ? (PERM ? p.row_perm[o0 + r] : (int)(o0 + r)) : -1;
+    if (PERM && cs == 0) s_orow[r] = orow[hh];
+  }
+  int tv[NU][NH];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
     const int jj = cs + 4 * u;
 #pragma unroll
-    for (int hh = 0; hh < NH; ++hh) {
-      const int r = lane + 64 * hh;
-      tv[u][hh] = (jj < nk && r < rows_here) ? p.nbr[(o0 + r) * K + kbeg + jj] : -1;
-    }
+    for (int hh = 0; hh < NH; ++hh)
+      tv[u][hh] = (jj < nk && orow[hh] >= 0) ? p.nbr[(int64_t)orow[hh] * K + kbeg + jj] : -1;
   }
   for (int e = tid; e < (CM + 1) * CLDC / 4; e += 256) reinterpret_cast<float4 *>(sC)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (PERM) {  // rows per offset first: the live offsets get the rulebook's slots in ascending order
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const int jj = cs + 4 * u;
-    if (jj < nk) {  // uniform
+    for (int u = 0; u < NU; ++u) {
+      const int jj = cs + 4 * u;
       int cnt = 0;
 #pragma unroll
-      for (int hh = 0; hh < NH; ++hh) {
-        const int v = tv[u][hh];
-        const unsigned long long b = __ballot(v >= 0);
-        if (v >= 0) {
-          const int pos = cnt + wave_rank(b);
-          s_src[jj * CM + pos] = v, s_lrow[jj * CM + pos] = (unsigned char)(lane + 64 * hh);
-        }
-        cnt += __popcll(b);
-      }
-      // behind the compacted rows: input row 0 (read, multiplied into columns nobody keeps) and the spare C row
-#pragma unroll
-      for (int hh = 0; hh < NH; ++hh)
-        if (lane + 64 * hh >= cnt) s_src[jj * CM + lane + 64 * hh] = 0, s_lrow[jj * CM + lane + 64 * hh] = (unsigned char)CM;
-      if (lane == 0) s_cnt[jj] = cnt;
+      for (int hh = 0; hh < NH; ++hh) cnt += __popcll(__ballot(tv[u][hh] >= 0));
+      if (lane == 0 && jj < 32) s_cnt[jj] = jj < nk ? cnt : 0;
     }
+    __syncthreads();
   }
-  __syncthreads();
-  // the slice's offsets that have rows and their block counts, four bits each, in scalar registers (nk <= 9 entries)
-  unsigned act_lo = 0u, act_hi = 0u, nbs_lo = 0u, nbs_hi = 0u;
-  int na = 0;
-  for (int j = 0; j < nk; ++j) {
-    const int cnt = __builtin_amdgcn_readfirstlane(s_cnt[j]);
-    if (cnt > 0) {
-      const unsigned nbj = (unsigned)((cnt + 15) >> 4);
-      if (na < 8) act_lo |= (unsigned)j << (4 * na), nbs_lo |= nbj << (4 * na);
-      else act_hi |= (unsigned)j << (4 * (na - 8)), nbs_hi |= nbj << (4 * (na - 8));
-      ++na;
-    }
+  unsigned amask = 0u;  // PERM: live offsets of the tile
+  if (PERM) {
+    for (int j = 0; j < nk; ++j)
+      if (__builtin_amdgcn_readfirstlane(s_cnt[j]) > 0) amask |= 1u << j;
   }
-  auto nib = [](unsigned lo, unsigned hi, int a) { return (int)(((a < 8 ? lo : hi) >> (4 * (a & 7))) & 15u); };
-  const int ncc = p.cin / BK;
-  const int n_items = na * ncc;
+  const int n_live = PERM ? __popc(amask) : 1;
 
   // ---- weight fragment of this lane: channels 16 h + 4 kq + s of the chunk, column 16 cs + n; byte offsets inside the
   // chunk are fixed per lane, the chunk's own offset is a scalar
@@ -1085,141 +1079,208 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
   const float *xcol = p.x + 4 * a_cc;
   f32x4 ga[CD][NA];  // (a native vector: copies of the HIP uint4 struct become memcpy calls that keep the ring in scratch)
   float gw[CD][8];
-  int g_ka = 0, g_cc = 0;  // iterator of the global-load stage
-  // every call issues the same NA + (W_T ? 2 : 8) loads, whatever the item: the vmcnt distances of the ring are static
-  // (a conditional load would make every wait a wait for ALL loads in flight); past the end the last item is re-read
-  auto gload = [&](int slot) __attribute__((always_inline)) {
-    const int ga_ = min(g_ka, na - 1);
-    const int j = nib(act_lo, act_hi, ga_);
-    const int k = kbeg + j;
-    const int kw = p.flip_k ? K - 1 - k : k;
-    const int c0 = g_cc * BK;
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-      ga[slot][i] = *reinterpret_cast<const f32x4 *>(xcol + (int64_t)s_src[j * CM + a_r + 32 * i] * p.ldx + c0);
-    if (!W_T) {
-      const int so = 4 * ((kw * p.cin + c0) * p.cout + n0);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gw[slot][e] = raw_load_f32(rw, wv[e], so, 0);
-    } else {
-      const int so = 4 * ((kw * p.cout + n0) * p.cin + c0);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x4 t = raw_load_v4(rw, wv[h], so, 0);
-        gw[slot][4 * h + 0] = t[0], gw[slot][4 * h + 1] = t[1], gw[slot][4 * h + 2] = t[2], gw[slot][4 * h + 3] = t[3];
-      }
-    }
-    if (g_ka < na && ++g_cc == ncc) g_cc = 0, ++g_ka;
-  };
-  auto sts = [&](int slot, int buf) __attribute__((always_inline)) {
-    float *a = sA + buf * CM * LDA;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&a[(a_r + 32 * i) * LDA + 4 * a_cc]) = ga[slot][i];
-  };
-
   f32x4 acc[NBLK];
 #pragma unroll
   for (int i = 0; i < NBLK; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float *myC = sC + 16 * cs + 4 * kq;
 
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  using S2 = std::integral_constant<int, 2>;
-  static_assert(CD == 3, "the steady-state loop is unrolled by hand");
-  // items 0 .. CD - 1 requested (slot = item % CD), item 0 -> LDS
-  if (n_items > 0) {  // uniform
-    gload(0), gload(1), gload(2);
-    sts(0, 0);
-  }
-  MINK_LDS_BARRIER();
-  int ka = 0, cc = 0;
-  auto step = [&](int it, auto slot_c, auto nslot_c) __attribute__((always_inline)) {
-    constexpr int slot = decltype(slot_c)::value;
-    const int j = nib(act_lo, act_hi, ka), nb = nib(nbs_lo, nbs_hi, ka);  // nb >= 1
-    sts(decltype(nslot_c)::value, (it + 1) & 1);  // item it + 1 (after the last item: a re-read copy nobody multiplies)
-    const float *a = sA + (it & 1) * CM * LDA + n * LDA + 4 * kq;
-    float wf[8];
+  // PERM: the live offsets CKP at a time (a class-pure tile has at most eight: one round)
+  for (int round0 = 0; round0 < n_live; round0 += CKP) {
+    // ---- rulebook of the round: wave64 ballot + prefix rank per offset
 #pragma unroll
-    for (int e = 0; e < 8; ++e) wf[e] = gw[slot][e];
-    auto mfma8 = [&](f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], u0.z, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], u0.w, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], u1.x, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], u1.y, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], u1.z, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], u1.w, c, 0, 0, 0);
-    };
-    auto mfma16 = [&](f32x4 &c, f32x4 &d, const float4 &u0, const float4 &u1, const float4 &v0, const float4 &v1) __attribute__((always_inline)) {
-      // two blocks, alternating accumulators: a dependent MFMA is two instructions away
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], v0.x, d, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], v0.y, d, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], u0.z, c, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], v0.z, d, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], u0.w, c, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], v0.w, d, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], u1.x, c, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], v1.x, d, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], u1.y, c, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], v1.y, d, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], u1.z, c, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], v1.z, d, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], u1.w, c, 0, 0, 0);
-      d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], v1.w, d, 0, 0, 0);
-    };
-    auto xr = [&](int blk, int half) __attribute__((always_inline)) { return *reinterpret_cast<const float4 *>(a + blk * 16 * LDA + 16 * half); };
-    // blocks in pairs; the operands of the next pair are read before this pair's MFMAs (rows past the compacted count
-    // hold stale data that is read but never multiplied)
-    float4 x[4] = {xr(0, 0), xr(0, 1), xr(1, 0), xr(1, 1)};
+    for (int u = 0; u < NU; ++u) {
+      const int jj = cs + 4 * u;
+      const int slot = PERM ? __popc(amask & ((1u << jj) - 1u)) - round0 : jj;
+      const bool mine = PERM ? (jj < nk && ((amask >> jj) & 1u) && slot >= 0 && slot < CKP) : jj < nk;
+      if (mine) {  // uniform
+        int cnt = 0;
 #pragma unroll
-    for (int b = 0; b < NBLK; b += 2) {
-      if (b < nb) {  // uniform
-        float4 y[4];
-        const int nx = b + 2 < NBLK ? b + 2 : b;
-        y[0] = xr(nx, 0), y[1] = xr(nx, 1), y[2] = xr(nx + 1, 0), y[3] = xr(nx + 1, 1);
-        if (b + 1 < nb) mfma16(acc[b], acc[b + 1], x[0], x[1], x[2], x[3]);
-        else mfma8(acc[b], x[0], x[1]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = y[e];
-      }
-    }
-    if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
-      cc = 0, ++ka;
-      auto scatter = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
-        constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
-        int lr[hi - lo];
-        float4 c[hi - lo];
-#pragma unroll
-        for (int b = lo; b < hi; ++b) lr[b - lo] = b < nb ? (int)s_lrow[j * CM + b * 16 + n] : CM;
-#pragma unroll
-        for (int b = lo; b < hi; ++b) c[b - lo] = *reinterpret_cast<const float4 *>(myC + lr[b - lo] * CLDC);
-#pragma unroll
-        for (int b = lo; b < hi; ++b) {
-          float4 &v = c[b - lo];
-          v.x += acc[b][0], v.y += acc[b][1], v.z += acc[b][2], v.w += acc[b][3];
-          *reinterpret_cast<float4 *>(myC + lr[b - lo] * CLDC) = v;
-          acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int hh = 0; hh < NH; ++hh) {
+          const int v = tv[u][hh];
+          const unsigned long long b = __ballot(v >= 0);
+          if (v >= 0) {
+            const int pos = cnt + wave_rank(b);
+            s_src[slot * CM + pos] = v, s_lrow[slot * CM + pos] = (unsigned char)(lane + 64 * hh);
+          }
+          cnt += __popcll(b);
         }
-      };
-      // (each accumulator is named in ONE place: two call sites that differ only in the block index get tail-merged
-      //  behind a pointer phi, and the accumulators then live in scratch memory)
-      scatter(S0{}, S2{});
-      if (nb > 2) scatter(S2{}, std::integral_constant<int, 4>{});
-      if constexpr (NBLK > 4) {
-        if (nb > 4) scatter(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
-        if (nb > 6) scatter(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+        // behind the compacted rows: input row 0 (read, multiplied into columns nobody keeps) and the spare C row
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
+          if (lane + 64 * hh >= cnt) s_src[slot * CM + lane + 64 * hh] = 0, s_lrow[slot * CM + lane + 64 * hh] = (unsigned char)CM;
+        if (!PERM && lane == 0) s_cnt[jj] = cnt;
       }
     }
-    gload(slot);  // item it + CD takes the registers of item it
+    __syncthreads();
+    // the round's offsets that have rows and their block counts, four bits each, in scalar registers (<= 9 entries);
+    // PERM: entry a is rulebook slot a, its offset is the (round0 + a)-th live one (a byte each in kl0..kl2)
+    unsigned act_lo = 0u, act_hi = 0u, nbs_lo = 0u, nbs_hi = 0u, kl0 = 0u, kl1 = 0u, kl2 = 0u;
+    int na = 0;
+    if (PERM) {
+      unsigned rest = amask;
+      for (int a = 0; a < round0; ++a) rest &= rest - 1u;
+      for (; rest && na < CKP; rest &= rest - 1u) {
+        const int j = __builtin_ctz(rest);
+        const unsigned nbj = (unsigned)((__builtin_amdgcn_readfirstlane(s_cnt[j]) + 15) >> 4);
+        if (na < 8) act_lo |= (unsigned)na << (4 * na), nbs_lo |= nbj << (4 * na);
+        else act_hi |= (unsigned)na << (4 * (na - 8)), nbs_hi |= nbj << (4 * (na - 8));
+        const unsigned kb_ = (unsigned)j << (8 * (na & 3));
+        if (na < 4) kl0 |= kb_;
+        else if (na < 8) kl1 |= kb_;
+        else kl2 |= kb_;
+        ++na;
+      }
+    } else {
+      for (int j = 0; j < nk; ++j) {
+        const int cnt = __builtin_amdgcn_readfirstlane(s_cnt[j]);
+        if (cnt > 0) {
+          const unsigned nbj = (unsigned)((cnt + 15) >> 4);
+          if (na < 8) act_lo |= (unsigned)j << (4 * na), nbs_lo |= nbj << (4 * na);
+          else act_hi |= (unsigned)j << (4 * (na - 8)), nbs_hi |= nbj << (4 * (na - 8));
+          ++na;
+        }
+      }
+    }
+    auto nib = [](unsigned lo, unsigned hi, int a) { return (int)(((a < 8 ? lo : hi) >> (4 * (a & 7))) & 15u); };
+    auto kof = [&](int a, int j) {  // kernel offset of entry a (rulebook slot j)
+      if (!PERM) return kbeg + j;
+      const unsigned w_ = a < 4 ? kl0 : a < 8 ? kl1 : kl2;
+      return (int)((w_ >> (8 * (a & 3))) & 255u);
+    };
+    const int n_items = na * ncc;
+
+    int g_ka = 0, g_cc = 0;  // iterator of the global-load stage
+    // every call issues the same NA + (W_T ? 2 : 8) loads, whatever the item: the vmcnt distances of the ring are static
+    // (a conditional load would make every wait a wait for ALL loads in flight); past the end the last item is re-read
+    auto gload = [&](int slot) __attribute__((always_inline)) {
+      const int ga_ = min(g_ka, na - 1);
+      const int j = nib(act_lo, act_hi, ga_);
+      const int k = kof(ga_, j);
+      const int kw = p.flip_k ? K - 1 - k : k;
+      const int c0 = (cbeg + g_cc) * BK;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        ga[slot][i] = *reinterpret_cast<const f32x4 *>(xcol + (int64_t)s_src[j * CM + a_r + 32 * i] * p.ldx + c0);
+      if (!W_T) {
+        const int so = 4 * ((kw * p.cin + c0) * p.cout + n0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gw[slot][e] = raw_load_f32(rw, wv[e], so, 0);
+      } else {
+        const int so = 4 * ((kw * p.cout + n0) * p.cin + c0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 t = raw_load_v4(rw, wv[h], so, 0);
+          gw[slot][4 * h + 0] = t[0], gw[slot][4 * h + 1] = t[1], gw[slot][4 * h + 2] = t[2], gw[slot][4 * h + 3] = t[3];
+        }
+      }
+      if (g_ka < na && ++g_cc == ncc) g_cc = 0, ++g_ka;
+    };
+    auto sts = [&](int slot, int buf) __attribute__((always_inline)) {
+      float *a = sA + buf * CM * LDA;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&a[(a_r + 32 * i) * LDA + 4 * a_cc]) = ga[slot][i];
+    };
+
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    static_assert(CD == 3, "the steady-state loop is unrolled by hand");
+    // items 0 .. CD - 1 requested (slot = item % CD), item 0 -> LDS
+    if (n_items > 0) {  // uniform
+      gload(0), gload(1), gload(2);
+      sts(0, 0);
+    }
     MINK_LDS_BARRIER();
-  };
-  for (int base = 0; base < n_items; base += CD) {
-    step(base, S0{}, S1{});
-    if (base + 1 < n_items) step(base + 1, S1{}, S2{});
-    if (base + 2 < n_items) step(base + 2, S2{}, S0{});
+    int ka = 0, cc = 0;
+    auto step = [&](int it, auto slot_c, auto nslot_c) __attribute__((always_inline)) {
+      constexpr int slot = decltype(slot_c)::value;
+      const int j = nib(act_lo, act_hi, ka), nb = nib(nbs_lo, nbs_hi, ka);  // nb >= 1
+      sts(decltype(nslot_c)::value, (it + 1) & 1);  // item it + 1 (after the last item: a re-read copy nobody multiplies)
+      const float *a = sA + (it & 1) * CM * LDA + n * LDA + 4 * kq;
+      float wf[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wf[e] = gw[slot][e];
+      auto mfma8 = [&](f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], u0.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], u0.w, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], u1.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], u1.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], u1.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], u1.w, c, 0, 0, 0);
+      };
+      auto mfma16 = [&](f32x4 &c, f32x4 &d, const float4 &u0, const float4 &u1, const float4 &v0, const float4 &v1) __attribute__((always_inline)) {
+        // two blocks, alternating accumulators: a dependent MFMA is two instructions away
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], v0.x, d, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], v0.y, d, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], u0.z, c, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], v0.z, d, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], u0.w, c, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], v0.w, d, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], u1.x, c, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], v1.x, d, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], u1.y, c, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], v1.y, d, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], u1.z, c, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], v1.z, d, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], u1.w, c, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], v1.w, d, 0, 0, 0);
+      };
+      auto xr = [&](int blk, int half) __attribute__((always_inline)) { return *reinterpret_cast<const float4 *>(a + blk * 16 * LDA + 16 * half); };
+      // blocks in pairs; the operands of the next pair are read before this pair's MFMAs (rows past the compacted count
+      // hold stale data that is read but never multiplied)
+      float4 x[4] = {xr(0, 0), xr(0, 1), xr(1, 0), xr(1, 1)};
+#pragma unroll
+      for (int b = 0; b < NBLK; b += 2) {
+        if (b < nb) {  // uniform
+          float4 y[4];
+          const int nx = b + 2 < NBLK ? b + 2 : b;
+          y[0] = xr(nx, 0), y[1] = xr(nx, 1), y[2] = xr(nx + 1, 0), y[3] = xr(nx + 1, 1);
+          if (b + 1 < nb) mfma16(acc[b], acc[b + 1], x[0], x[1], x[2], x[3]);
+          else mfma8(acc[b], x[0], x[1]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = y[e];
+        }
+      }
+      if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
+        cc = 0, ++ka;
+        auto scatter = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
+          constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+          int lr[hi - lo];
+          float4 c[hi - lo];
+#pragma unroll
+          for (int b = lo; b < hi; ++b) lr[b - lo] = b < nb ? (int)s_lrow[j * CM + b * 16 + n] : CM;
+#pragma unroll
+          for (int b = lo; b < hi; ++b) c[b - lo] = *reinterpret_cast<const float4 *>(myC + lr[b - lo] * CLDC);
+#pragma unroll
+          for (int b = lo; b < hi; ++b) {
+            float4 &v = c[b - lo];
+            v.x += acc[b][0], v.y += acc[b][1], v.z += acc[b][2], v.w += acc[b][3];
+            *reinterpret_cast<float4 *>(myC + lr[b - lo] * CLDC) = v;
+            acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        };
+        // (each accumulator is named in ONE place: two call sites that differ only in the block index get tail-merged
+        //  behind a pointer phi, and the accumulators then live in scratch memory)
+        scatter(S0{}, S2{});
+        if (nb > 2) scatter(S2{}, std::integral_constant<int, 4>{});
+        if constexpr (NBLK > 4) {
+          if (nb > 4) scatter(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
+          if (nb > 6) scatter(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+        }
+      }
+      gload(slot);  // item it + CD takes the registers of item it
+      MINK_LDS_BARRIER();
+    };
+    for (int base = 0; base < n_items; base += CD) {
+      step(base, S0{}, S1{});
+      if (base + 1 < n_items) step(base + 1, S1{}, S2{});
+      if (base + 2 < n_items) step(base + 2, S2{}, S0{});
+    }
+    if (!PERM) break;
   }
 
   // ---- epilogue: y / slab = C (+ bias), column statistics of the tile for the batch norm that follows
@@ -1233,15 +1294,16 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
 #pragma unroll
   for (int jr = 0; jr < NBLK; ++jr) {
     const int r = rg + 16 * jr;
-    if (r < rows_here) {
+    const int64_t row = PERM ? (int64_t)s_orow[r] : (r < rows_here ? o0 + r : -1);
+    if (row >= 0) {
       const float4 u = *reinterpret_cast<const float4 *>(&sC[r * CLDC + 4 * c4]);
       const float4 o = make_float4(u.x + bias.x, u.y + bias.y, u.z + bias.z, u.w + bias.w);
-      *reinterpret_cast<float4 *>(&dst[(o0 + r) * ldd + n0 + 4 * c4]) = o;
+      *reinterpret_cast<float4 *>(&dst[row * ldd + n0 + 4 * c4]) = o;
       s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
       q.x += o.x * o.x, q.y += o.y * o.y, q.z += o.z * o.z, q.w += o.w * o.w;
     }
   }
-  if (p.stats && direct) {  // uniform
+  if (!PERM && p.stats && direct) {  // uniform
     float *red = sA;  // [16 row groups][2][64]; the tiles are dead (last barrier)
     *reinterpret_cast<float4 *>(&red[(rg * 2 + 0) * BN + 4 * c4]) = s;
     *reinterpret_cast<float4 *>(&red[(rg * 2 + 1) * BN + 4 * c4]) = q;
@@ -1496,10 +1558,17 @@ __device__ __forceinline__ StreamSlot stream_slot(const WgradParams &p) {
   return s;
 }
 
-template <int D, bool FUSE = false>
+// FLAT: the (offset, channel) axis of dW is tiled as ONE flattened axis f = k * cin + ci in runs of 32 (the forward
+// kernel's FLAT=28 idea): 27 x 28 = 756 rows are 24 tiles instead of 27 offset tiles padded from 28 to 32 channels --
+// a ninth fewer MFMAs, gathers and address instructions.  A lane's row of a tile then belongs to one of two offsets,
+// so every lane picks ITS neighbour entry from the staged table row (a per-lane LDS read at an address that is a
+// constant of (lane, tile)) instead of the half-wave sharing a broadcast; a lane past the end of the axis adds an
+// out-of-range column offset.  A group is eight tiles = 256 flat rows = at most 16 offsets from kb = 256 grp / cin.
+template <int D, bool FUSE = false, bool FLAT = false>
 __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   static_assert(D % 2 == 0, "the neighbour staging ring has two slots");
-  constexpr int G = 9;                   // K == 27: three groups of nine offsets
+  constexpr int G = FLAT ? 8 : 9;        // K == 27: three groups of nine offsets / of eight 32-row tiles of the flat axis
+  constexpr int NK = FLAT ? 16 : 9;      // table entries of a row staged per group
   constexpr unsigned OOB = 0x80000000u;  // beyond any descriptor this kernel is launched with
   __shared__ float sR[2 * 16 * 64];
   // wave-private staging of the neighbour entries of one row pair: one lane per entry loads
@@ -1522,7 +1591,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   // lanes beyond cin / cout only feed rows / columns of the product that are never stored
   const unsigned xcol = 4u * min(col, p.cin - 1);
   const unsigned dcol = 4u * min(co0 + 32 * wn + col, p.cout - 1);
-  const unsigned ncol = col < G ? 4u * (k0 + col) : OOB;
+  const int kb = FLAT ? (256 * grp) / p.cin : k0;  // first offset this group touches
+  const unsigned ncol = col < NK && kb + col < p.K ? 4u * (kb + col) : OOB;
+  unsigned kidx[G], xoff[G];  // FLAT: this lane's table entry (relative to kb) and column byte offset in tile g
+  if (FLAT) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int f = 32 * (grp * G + g) + col, k = f / p.cin;
+      const bool in = k < p.K;
+      kidx[g] = in ? (unsigned)(k - kb) : 0u;
+      xoff[g] = in ? 4u * (unsigned)(f - k * p.cin) : OOB;
+    }
+  }
   // FUSE: per-lane constants of this lane's output channel
   const int cco = min(co0 + 32 * wn + col, p.cout - 1);
   const __amdgpu_buffer_rsrc_t rp = make_rsrc(FUSE ? (const void *)p.dyp : (const void *)p.dy, FUSE ? p.dyp_bytes : 0u),
@@ -1554,8 +1634,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
     const int r = rel_of(q);
     nraw[s] = __builtin_amdgcn_raw_buffer_load_b32(rn, (int)(r < nrel ? __umul24(r, K4) + nbase : OOB), 0, 0);
   };
-  auto stash = [&](int s, int slot) {
-    sN[wave][slot][h][col] = nraw[s];  // lanes col >= 9 store padding: no exec-mask branch in the loop
+  auto stash = [&](int s, int slot, int q) {
+    // lanes col >= NK store padding: no exec-mask branch in the loop.  FLAT: a row past the end stages "no neighbour"
+    // (the column offsets are per tile there, so the row test cannot ride on them as it does below)
+    sN[wave][slot][h][col] = FLAT && rel_of(q) >= nrel ? 0xFFFFFFFFu : nraw[s];
   };
   auto load_i2o = [&](int s, int q) {  // (a row past the end reads parent 0: its x operand is zero anyway)
     if (FUSE) {
@@ -1576,10 +1658,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
     return c_ga * c_is * (g - c_dbn - xh * c_dgn);
   };
   auto load_xs = [&](int s, int slot, int q, auto &&between) {  // the nine x values of pair q
+    if constexpr (FLAT) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        between(g);
+        xa[s][g] = buf_load(rx, __umul24(sN[wave][slot][h][kidx[g]], ldx4) + xoff[g]);
+      }
+      return;
+    }
     const uint4 n0 = *reinterpret_cast<const uint4 *>(&sN[wave][slot][h][0]);
     const uint4 n1 = *reinterpret_cast<const uint4 *>(&sN[wave][slot][h][4]);
     const unsigned n2 = sN[wave][slot][h][8];
-    const unsigned nbv[G] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2};
+    const unsigned nbv[9] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2};
     const unsigned xbase = rel_of(q) < nrel ? xcol : OOB;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -1597,14 +1687,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < D; ++s) {  // same load order as the loop body: the vmcnt waits there are FIFO distances
-      stash(s, s & 1);
+      stash(s, s & 1, s);
       load_xs(s, s & 1, s, [](int) {});
       load_dy(s, s);
       load_raw(s, s + D);
       load_i2o(s, s + D);
       __builtin_amdgcn_sched_barrier(0);
     }
-    stash(0, 0);  // pair D
+    stash(0, 0, D);  // pair D
     for (int q0 = 0; q0 < nq; q0 += D) {
 #pragma unroll
       for (int s = 0; s < D; ++s) {  // pair q0 + s from slot s; pairs past nq were loaded as zeros
@@ -1616,7 +1706,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
           acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g], b, acc[g], 0, 0, 0);
         });
         load_dy(s, q0 + s + D);
-        stash((s + 1) % D, (s + 1) & 1);  // pair q0 + s + D + 1, loaded D - 1 pairs ago
+        stash((s + 1) % D, (s + 1) & 1, q0 + s + D + 1);  // pair q0 + s + D + 1, loaded D - 1 pairs ago
         load_raw(s, q0 + s + 2 * D);
         load_i2o(s, q0 + s + 2 * D);
 #pragma unroll
@@ -1648,7 +1738,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
         for (int r = 0; r < 16; ++r) {
           const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
           const float v = acc[g][r] + sR[(wn * 16 + r) * 64 + lane];
-          if (ci < p.cin && co < p.cout) dst[((int64_t)k * p.cin + ci) * p.cout + co] = v;
+          if (FLAT) {
+            const int f = 32 * (grp * G + g) + ci;  // flat row of the [K * cin][cout] matrix
+            if (f < p.K * p.cin && co < p.cout) dst[(int64_t)f * p.cout + co] = v;
+          } else if (ci < p.cin && co < p.cout) dst[((int64_t)k * p.cin + ci) * p.cout + co] = v;
         }
       }
     }
@@ -1944,6 +2037,7 @@ static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
 static int g_wgrad_bf16 = getenv("MINK_WGRAD_BF16") ? atoi(getenv("MINK_WGRAD_BF16")) : 1;  // bf16 math: stem weight gradient on the bf16 MFMA too
 static int g_wgrad_bf16_off = 0;
 static int g_compact = getenv("MINK_COMPACT") ? atoi(getenv("MINK_COMPACT")) : 1;  // fp32 mid layers on compact_gemm_kernel
+static int g_compact_perm = getenv("MINK_COMPACT_PERM") ? atoi(getenv("MINK_COMPACT_PERM")) : 1;  // ... and the class-permuted strided data gradients
 static int g_wgrad_xcd = getenv("MINK_WGRAD_XCD") ? atoi(getenv("MINK_WGRAD_XCD")) : 1;  // streaming wgrad: groups of a row split share an XCD (stream_slot)
 
 extern "C" {
@@ -1957,6 +2051,7 @@ int mink_conv_set_stagger(int units) {
   g_wgrad_bf16_off = (units >> 28) & 1;  // bit 28: bf16 math keeps the exact-fp32 weight-gradient kernel (A/B tests)
   g_wgrad_xcd = !((units >> 29) & 1);    // bit 29: plain workgroup order in the streaming weight-gradient kernels (A/B)
   g_compact = !((units >> 30) & 1);      // bit 30: mid layers back on gather_gemm2_kernel (A/B)
+  g_compact_perm = !(((unsigned)units >> 31) & 1u);  // bit 31: class-permuted strided data gradients back on gather_gemm2_kernel (A/B)
   g_offset_major = (units & 2048) != 0;  // bit 11: offset-major, row-compacted path for the deep layers (Cin >= 256)
   g_wgrad_force = (units >> 12) & 0xFFFF;  // bits 12-15: force G (1, 3, 9), bits 16-27: force the row split count
   return old;
@@ -2060,7 +2155,26 @@ static int compact_plan(int64_t n_rows, int K, int cout) {
   return best;
 }
 
+// compact_gemm_kernel<.., PERM> (fp32, rows grouped by parity class: the data gradient of a strided convolution): the split
+// is over 32-channel chunks, a power of two that divides their number; kbench psweep: the largest that keeps the launch
+// within one resident round of 1024 workgroups.
+static bool compact_perm_shape(int64_t n_rows, int K, int cin, int cout, int row_classes) {
+  return g_compact && g_compact_perm && g_math == 0 && row_classes && K >= 8 && cin >= 64 && cin % BK == 0 && cout % BN == 0 && n_rows >= 1;
+}
+static int compact_perm_plan(int64_t n_rows, int cin, int cout) {
+  static const int cap = getenv("MINK_PERM_SPLIT_CAP") ? atoi(getenv("MINK_PERM_SPLIT_CAP")) : 1024;  // tuning hook
+  const int ncc = cin / BK;
+  const int64_t tiles = cdiv(n_rows, 64) * cdiv(cout, BN);
+  int best = 1;
+  for (int zs = 2; zs <= ncc && ncc % zs == 0; zs *= 2) {
+    if (tiles * zs > cap || zs * 4 * n_rows * cout > (128ll << 20)) break;
+    best = zs;
+  }
+  return best;
+}
+
 int mink_conv_plan(int64_t n_rows, int32_t K, int32_t cin, int32_t cout, int32_t row_classes) {
+  if (compact_perm_shape(n_rows, K, cin, cout, row_classes)) return compact_perm_plan(n_rows, cin, cout);
   if (offset_major_shape(n_rows, K, cin, cout)) return K;  // one slab per offset (offset_gemm_kernel)
   if (compact_shape(n_rows, K, cin, cout, row_classes)) return compact_plan(n_rows, K, cout);
   return mink_conv_plan_ksplit(n_rows, K, cout, row_classes);
@@ -2123,6 +2237,31 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
       offset_reduce_kernel<false><<<dim3((unsigned)rows), 256, 0, st>>>(workspace, nbr, n_out, cout, K, bias, y, ldy, nullptr);
     }
     MINK_CHECK_LAUNCH();
+    return MINK_OK;
+  }
+  if (compact_perm_shape(n_virtual, K, cin, cout, row_perm != nullptr) && row_perm && vec && g_pipeline && !p.accumulate && !stats_out &&
+      (ldy & 3) == 0 && 4ll * K * cin * cout < (1ll << 31) && (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0) {
+    // class-permuted rows, every live offset of a tile, split over channel chunks (compact_gemm_kernel<.., PERM>)
+    constexpr int CMT = 64;
+    constexpr int smem = compact_smem(CMT);
+    static const bool attr_ok = [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<false, CMT, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<true, CMT, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
+    }();
+    MINK_REQUIRE(attr_ok, "gather_gemm: %d bytes of LDS per workgroup refused", smem);
+    const int ncc = cin / BK;
+    p.kper = (int)cdiv(ncc, ksplit);  // channel chunks per slice
+    const int zc = (int)cdiv(ncc, p.kper);
+    const dim3 cgrid((unsigned)cdiv(n_virtual, CMT), grid.y, (unsigned)zc);
+    if (w_transposed) compact_gemm_kernel<true, CMT, true><<<cgrid, 256, smem, st>>>(p);
+    else compact_gemm_kernel<false, CMT, true><<<cgrid, 256, smem, st>>>(p);
+    MINK_CHECK_LAUNCH();
+    if (zc > 1) {
+      splitk_reduce_kernel<<<dim3((unsigned)cdiv(n_out * cout, 256)), 256, 0, st>>>(workspace, n_out, cout, zc, bias, y, ldy);
+      MINK_CHECK_LAUNCH();
+    }
     return MINK_OK;
   }
   if (stats_direct) p.stats = (float *)stats_ws;
@@ -2251,6 +2390,10 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
   p.x_bytes = (unsigned)xb, p.dy_bytes = (unsigned)db, p.nbr_bytes = (unsigned)nb;
   const bool stream_ok = wgrad_stream_ok(n_in, ldx, cin, ldy, cout, n_out, K);
   const bool bf16_stream = g_math == 1 && g_wgrad_bf16 && !g_wgrad_bf16_off && pl.G == 9 && stream_ok && g_wgrad_stream;
+  // flattened (offset, channel) tiling: 24 instead of 27 tiles when the axis fits three groups of 256 rows and the
+  // padded channels are worth saving; ldx <= 32 keeps "no neighbour" + "past the axis" inside 32-bit offset arithmetic
+  static const int flat_on = getenv("MINK_WGRAD_FLAT") ? atoi(getenv("MINK_WGRAD_FLAT")) : 1;
+  const bool flat = flat_on && K * cin <= 768 && K * cin > 512 && ldx <= 32 && cin >= 16;
   if (fuse) {
     MINK_REQUIRE(pl.G == 9 && stream_ok && g_wgrad_stream && 4 * fuse->n_pool * ldy < (1ll << 31),
                  "wgrad_bn_relu_pool: shape not supported by the streaming kernel (ask mink_conv_wgrad_bn_relu_pool_supported)");
@@ -2262,8 +2405,10 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
     else if (depth == 6) wgrad_stream_kernel<6, true><<<grid, 256, 0, st>>>(p);
     else if (depth == 8) wgrad_stream_kernel<8, true><<<grid, 256, 0, st>>>(p);
     else if (depth == 2) wgrad_stream_kernel<2, true><<<grid, 256, 0, st>>>(p);
+    else if (flat) wgrad_stream_kernel<4, true, true><<<grid, 256, 0, st>>>(p);
     else wgrad_stream_kernel<4, true><<<grid, 256, 0, st>>>(p);
   } else if (bf16_stream) wgrad_stream_bf16_kernel<false><<<grid, 256, 0, st>>>(p);
+  else if (pl.G == 9 && stream_ok && g_wgrad_stream && flat) wgrad_stream_kernel<4, false, true><<<grid, 256, 0, st>>>(p);
   else if (pl.G == 9 && stream_ok && g_wgrad_stream) wgrad_stream_kernel<4><<<grid, 256, 0, st>>>(p);
   else if (pl.G == 9) launch_wgrad<9>(p, grid, st);
   else if (pl.G == 3) launch_wgrad<3>(p, grid, st);

@@ -213,6 +213,7 @@ class TrunkFunction(torch.autograd.Function):
         sd.nbr_pool, sd.in2out, sd.n, sd.n_pool = nbr_pool.data_ptr(), i2o.data_ptr(), n0, n1
         sd.x, sd.y, sd.out, sd.g_out = x.data_ptr(), a0, a0 + 4 * n0 * C0, None
         check(L.mink_stem_forward(ctypes.byref(sd), exp))
+        Fn.mark_phase("stem_forward", cur)
         Fn.note_table(nbr0)
         saved = [(x, w0, arena0, nbr0, nbr_pool, i2o, pad)]
         # ---- residual blocks
@@ -344,7 +345,9 @@ class TrunkFunction(torch.autograd.Function):
         if sd.x != x.data_ptr() or sd.y != arena0.data_ptr():
             TrunkFunction._restore_stem(plan, saved[0])
         sd.conv.dw, sd.norm.dgamma, sd.norm.dbeta, sd.g_out = gs[0].data_ptr(), gs[1].data_ptr(), gs[2].data_ptr(), gp
+        Fn.log_phase("stem_backward_begin", torch.cuda.current_stream(dev))
         check(L.mink_stem_backward(ctypes.byref(sd), exp))
+        Fn.log_phase("stem_backward_end", torch.cuda.current_stream(dev))
         Fn.note_table(nbr0)
         _KEEPALIVE.append(g)
         if views is not None:

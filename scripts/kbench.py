@@ -296,6 +296,32 @@ if which == "pad":
         print(f"{name}: stem fwd {t*1e3:8.1f} us")
     ya = Fn.gather_gemm(xc, w, nbr, 64); yb = Fn.gather_gemm(xp, w, nbr, 64)
     print("fwd diff", float((ya - yb).abs().max()))
+if which == "perm":  # data gradient of the strided convolutions: row-compacted kernel over class-permuted rows against gather_gemm2 (bit 31)
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    for ts in (2, 4, 8, 16):
+        cin, cout = chans[ts], chans[ts * 2]
+        nbr, nbr_t = m.kernel_table(keys[ts], keys[ts * 2], 3, 1, transposed=True)
+        perm = m.class_perm(keys[ts])
+        pairs = int((nbr >= 0).sum())
+        w = torch.randn(27, cin, cout, device=dev) * 0.05
+        gy = torch.randn(nbr.shape[0], cout, device=dev)
+        fl = 2.0 * pairs * cin * cout
+        outs = []
+        for bit in (0, -(1 << 31), 0, -(1 << 31)):
+            lib().mink_conv_set_stagger(bit)
+            Fn._PLAN_CACHE.clear()
+            t = timeit(lambda: Fn.gather_gemm(gy, w, nbr_t, cin, w_transposed=True, row_perm=perm), reps)
+            outs.append(Fn.gather_gemm(gy, w, nbr_t, cin, w_transposed=True, row_perm=perm))
+            ks = Fn._plan_ksplit(lib(), perm.numel(), 27, cout, cin, 1)
+            print(f"l@{ts}.c1 dgrad rows={nbr_t.shape[0]:7d} {cout}->{cin} {'dense ' if bit else 'compact'} split={ks:2d} {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s")
+        lib().mink_conv_set_stagger(0)
+        Fn._PLAN_CACHE.clear()
+        print("   max |compact - dense|", float((outs[0] - outs[1]).abs().max()), "max |dense|", float(outs[1].abs().max()),
+              "bitwise repeatable:", bool(torch.equal(outs[0], outs[2])))
 if which in ("stem", "all"):
     bench_layer("stem", x.F.contiguous(), k1, k1, 3, 28, 64, 1)
 if which in ("l1", "l4", "all"):
