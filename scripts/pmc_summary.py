@@ -27,5 +27,5 @@ for (name, grid), d in agg.items():
     res.append(e)
 res.sort(key=lambda e: -e.get("GRBM_GUI_ACTIVE", e.get("FETCH_SIZE", 0)))
 json.dump(res, open(out, "w"), indent=1)
-for e in res[:14]:
-    print({k: e[k] for k in ("kernel", "workgroups", "hbm_traffic_bytes_per_launch", "mfma_pipe_util") if k in e})
+for e in res[:16]:
+    print({k: e[k] for k in ("kernel", "workgroups", "launches", "hbm_traffic_bytes_per_launch", "mfma_pipe_util") if k in e})
