@@ -193,7 +193,10 @@ int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *bat
  *   row_perm/n_virtual : optional row permutation (NULL/0 = identity): tile row v computes
  *                        output row row_perm[v], -1 entries are padding (mink_class_partition)
  *   ksplit             : >1 splits the K offsets over `ksplit` workgroups per tile and
- *                        reduces through `workspace` (ksplit*n_out*cout floats)
+ *                        reduces through `workspace` (ksplit*n_out*cout floats).  With a class
+ *                        permutation of an fp32 mid layer (cin >= 64, K >= 8) the split is over
+ *                        the cin/32 channel chunks instead (<= cin/32 slices; a tile of one
+ *                        parity class has few live offsets, every slice sees all of them)
  */
 /* Tuning / A-B knob (benchmarks only): bits 0-5 start-up stagger of the un-pipelined kernel,
  * bit 8 = use the un-pipelined kernel, bit 9 = disable the flattened-K stem path.  Returns the
@@ -209,8 +212,9 @@ int mink_conv_set_math(int mode);
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_classes);
 /* The same with the reduction width known: returns K -- one slab per kernel offset -- for the deep layers (cin >= 256),
  * which mink_conv_gather_gemm then runs offset-major with the rows of each offset compacted into dense MFMA blocks (half of
- * a deep layer's table is empty) and reduces in ascending offset order; otherwise mink_conv_plan_ksplit's answer.  The
- * workspace is 4 * ksplit * n_out * cout bytes either way. */
+ * a deep layer's table is empty) and reduces in ascending offset order; for row_classes != 0 on an fp32 mid layer the
+ * channel split of the row-compacted kernel; otherwise mink_conv_plan_ksplit's answer.  The workspace is
+ * 4 * ksplit * n_out * cout bytes in every case. */
 int mink_conv_plan(int64_t n_rows, int32_t K, int32_t cin, int32_t cout, int32_t row_classes);
 /* flip_k: bit 0 = read the weights of offset K-1-k for offset k (data gradient of a stride-1 convolution through the
  * forward table); bit 1 = ACCUMULATE, y[row] += result instead of y[row] = result -- for an un-split launch whose

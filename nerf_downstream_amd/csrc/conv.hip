@@ -2190,7 +2190,7 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   if (stats_rows) *stats_rows = 0;
   MINK_REQUIRE(K >= 1 && K <= KMAX, "gather_gemm: kernel volume %d unsupported", K);
   MINK_REQUIRE(cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0, "gather_gemm: bad shape");
-  MINK_REQUIRE(ksplit >= 1 && ksplit <= K, "gather_gemm: bad ksplit %d", ksplit);
+  MINK_REQUIRE(ksplit >= 1 && ksplit <= std::max(K, cin / BK), "gather_gemm: bad ksplit %d", ksplit);  // (offsets, or channel chunks: compact_perm_plan)
   MINK_REQUIRE(n_out * (int64_t)K < (1ll << 31), "gather_gemm: table too large");
   if (n_out == 0) return MINK_OK;
   MINK_REQUIRE(x && w && nbr && y, "gather_gemm: NULL pointer");

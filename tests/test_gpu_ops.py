@@ -528,3 +528,64 @@ def test_row_compacted_kernel_against_float64(n_out, K, cin, cout, transposed):
     finally:
         Fn._FORCE_KSPLIT = 0
         L.mink_conv_set_stagger(0)
+
+
+@pytest.mark.parametrize("n_out,K,cin,cout,pure", [(1, 27, 64, 64, True), (130, 27, 64, 64, True), (1000, 27, 128, 64, True),
+                                                   (517, 27, 256, 128, False), (4097, 27, 64, 64, False), (300, 9, 512, 64, True)])
+@pytest.mark.parametrize("transposed", [False, True])
+def test_row_compacted_kernel_over_permuted_rows_against_float64(n_out, K, cin, cout, pure, transposed):
+    """compact_gemm_kernel<.., PERM> (fp32 data gradient of a strided convolution: rows through a class permutation, ALL
+    offsets per tile, split over 32-channel chunks) on synthetic tables: a permutation with -1 padding between its
+    segments; `pure` segments whose rows share at most eight live offsets (the parity classes) and mixed tiles with
+    more live offsets than the rulebook's nine slots (several rounds); every channel split; both weight layouts --
+    against a float64 gather + matmul, bitwise against itself, and against the dense kernel it replaces."""
+    from nerf_downstream_amd._lib import lib
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(n_out * 7 + K + cin + int(pure))
+    n_in = max(4, n_out // 3 + 5)
+    nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
+    cls = torch.randint(0, 8, (n_out,), generator=g)
+    if pure:  # class c keeps a fixed set of <= 8 offsets, each present with probability 0.7
+        keep = torch.zeros(8, K, dtype=torch.bool)
+        for c in range(8):
+            keep[c, torch.randperm(K, generator=g)[: 1 + c]] = True
+        nbr[~keep[cls]] = -1
+        nbr[torch.rand(n_out, K, generator=g) < 0.3] = -1
+    else:
+        nbr[torch.rand(n_out, K, generator=g) < 0.5] = -1
+    # permutation: rows grouped by class, every segment padded with -1 to a multiple of 128 (mink_class_partition's form)
+    segs = []
+    for c in range(8):
+        rows = torch.nonzero(cls == c).flatten().to(torch.int32)
+        pad = (-len(rows)) % 128
+        segs += [rows, torch.full((pad,), -1, dtype=torch.int32)]
+    perm = torch.cat(segs)
+    x = torch.randn(n_in, cin, generator=g)
+    w = torch.randn(K, cin, cout, generator=g) * 0.1
+    wk = w.transpose(1, 2).contiguous() if transposed else w
+    ref = torch.zeros(n_out, cout, dtype=torch.float64)
+    for k in range(K):
+        sel = nbr[:, k] >= 0
+        ref[sel] += x[nbr[sel, k].long()].double() @ w[k].double()
+    xd, wd, nd, pd = x.to(dev), wk.to(dev), nbr.to(dev), perm.to(dev)
+    scale = float(ref.abs().max()) + 1e-30
+    L = lib()
+    ncc = cin // 32
+    assert 1 <= L.mink_conv_plan(perm.numel(), K, cin, cout, 1) <= ncc, "the planner must hand this shape to the permuted compacted kernel"
+    try:
+        for zs in sorted({1, 2, ncc // 2 or 1, ncc, min(K, ncc + 3)}):
+            Fn._FORCE_KSPLIT = zs
+            y = Fn.gather_gemm(xd, wd, nd, cout, w_transposed=transposed, row_perm=pd)
+            err = float((y.cpu().double() - ref).abs().max()) / scale
+            assert err < 2e-6, (zs, err)
+            assert torch.equal(y, Fn.gather_gemm(xd, wd, nd, cout, w_transposed=transposed, row_perm=pd)), zs
+            L.mink_conv_set_stagger(-(1 << 31))  # bit 31: the dense class-permuted kernel
+            Fn._FORCE_KSPLIT = 1
+            y3 = Fn.gather_gemm(xd, wd, nd, cout, w_transposed=transposed, row_perm=pd)
+            L.mink_conv_set_stagger(0)
+            assert float((y3 - y).abs().max()) / scale < 4e-6, zs  # (two fp32 summation orders, each within 2e-6 of float64)
+    finally:
+        Fn._FORCE_KSPLIT = 0
+        L.mink_conv_set_stagger(0)
