@@ -10,7 +10,7 @@ rows = list(csv.DictReader(open(f)))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-marks = [r["s"] for r in rows if "wgrad_stream_kernel" in r["Kernel_Name"]]
+marks = [r["s"] for r in rows if "wgrad_stream" in r["Kernel_Name"]]
 n = min(8, len(marks) - 1)
 t0, t1 = marks[-1 - n], marks[-1]
 seg = [r for r in rows if t0 <= r["s"] < t1]

@@ -9,7 +9,7 @@ import sys
 d, steps = sys.argv[1], int(sys.argv[2])
 f = (glob.glob(f"{d}/*/*kernel_trace.csv") + glob.glob(f"{d}/*kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
-ends = [int(r["End_Timestamp"]) for r in rows if "wgrad_stream_kernel" in r["Kernel_Name"]]
+ends = [int(r["End_Timestamp"]) for r in rows if "wgrad_stream" in r["Kernel_Name"]]
 if ends and steps == 0:  # bench.py trace: count the training steps and drop the forward-only phase after them
     steps = len(ends)
     rows = [r for r in rows if int(r["Start_Timestamp"]) <= max(ends)]
