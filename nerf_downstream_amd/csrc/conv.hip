@@ -273,6 +273,20 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
 // otherwise indices are read straight from the table one offset ahead.
 #define MINK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+// raw buffer loads with a per-lane byte offset (VGPR) and a per-item byte offset (SGPR): no address arithmetic per load
+__device__ f32x4 raw_load_v4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float raw_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ int raw_load_i32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
+// descriptor of a raw buffer of `bytes` bytes: a load at byte offset >= bytes touches no memory and returns 0
+__device__ __forceinline__ i32x4 raw_rsrc(const void *ptr, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)ptr;
+  i32x4 r;
+  r.x = (int)(unsigned)a, r.y = (int)((a >> 32) & 0xFFFFu), r.z = (int)bytes, r.w = 0x00020000;
+  return r;
+}
+
 // FLAT > 0 (== cin, not a multiple of 32; forward weights only): the reduction runs over the
 // flattened (offset, channel) axis K*cin in 32-wide items that may straddle two offsets, so no
 // MFMA step is spent on channel padding (stem: 756 = 27*28 -> 24 items instead of 27).
@@ -372,38 +386,42 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
     return *reinterpret_cast<const uint4 *>(base + (ok ? off : 0));
   };
   int gj = 0;  // FLAT: item counter of the global-load stage
+  // FLAT (the stem): every operand comes through a raw buffer load whose out-of-range offsets return 0 without touching
+  // memory, so nothing is selected or masked per load (the fp32 MFMA rate equals the vector-ALU rate and the two share
+  // issue slots: the selects, masks and 64-bit address arithmetic of the guarded form were ~3 VALU instructions per
+  // MFMA).  A missing neighbour (-1) is row 0xFFFFFF of a descriptor that ends right there; an item column past the
+  // flattened axis, a table row of a padding tile row and a weight column past cout get bit 31 in their offset.  The
+  // launcher checks ldx <= 32 (so the sums stay below 2^32) and fewer than 2^24 - 1 input rows.
+  const unsigned ldx4 = 4u * (unsigned)p.ldx;
+  const i32x4 rfx = raw_rsrc(p.x, FLAT ? 0xFFFFFFu * ldx4 : 0u);
+  const i32x4 rfw = raw_rsrc(p.w, FLAT ? 4u * (unsigned)K * (unsigned)FLAT * (unsigned)p.cout : 0u);
+  const i32x4 rfn = raw_rsrc(p.nbr, FLAT ? 4u * (unsigned)p.n_out * (unsigned)K : 0u);
+  unsigned tab_off[4], fb_off[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tab_off[i] = my_orow[i] >= 0 ? 4u * (unsigned)my_orow[i] * (unsigned)K : 0x80000000u;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)  // row b_kk + 16 i of the flattened [K*cin][cout] weight matrix, item 0; one item further per gload
+    fb_off[i] = (n0 + 4 * b_n4 < p.cout ? 4u * (unsigned)(n0 + 4 * b_n4) : 0x80000000u) + 4u * (unsigned)(b_kk + 16 * i) * (unsigned)p.cout;
   auto flat_idx = [&](int j, int (&idx)[4]) {  // neighbour rows for flat item j (per-thread offset)
     const int off = (BK * j + 4 * a_cc) / (FLAT ? FLAT : 1);
-    const int offq = min(off, K - 1);
-    const unsigned dead = off >= K ? 0xFFFFFFFFu : 0u;
+    const unsigned ko = 4u * (unsigned)min(off, K - 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned v = (unsigned)p.nbr[(int64_t)max(my_orow[i], 0) * K + offq];
-      idx[i] = (int)(v | dead | (my_orow[i] < 0 ? 0xFFFFFFFFu : 0u));
-    }
+    for (int i = 0; i < 4; ++i) idx[i] = raw_load_i32(rfn, (int)(tab_off[i] + ko), 0, 0);  // (a padding row reads as row 0: never stored)
   };
   auto gload_flat = [&]() {
     int idx_n[4];
     flat_idx(gj + 1, idx_n);
     const int kf = BK * gj + 4 * a_cc;
     const int off = kf / (FLAT ? FLAT : 1);
-    const int ch = kf - off * FLAT;
-    unsigned okb = 0u;
+    const unsigned chb = off < K ? 4u * (unsigned)(kf - off * FLAT) : 0x80000000u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = idx_g[i] >= 0;
-      ga[i] = ldraw(p.x, (int64_t)idx_g[i] * p.ldx + ch, ok);
-      okb |= ok ? (1u << i) : 0u;
-    }
-    const int n = n0 + 4 * b_n4;
+    for (int i = 0; i < 4; ++i)
+      ga[i] = __builtin_bit_cast(uint4, raw_load_v4(rfx, (int)(__umul24((unsigned)idx_g[i], ldx4) + chb), 0, 0));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int kk = BK * gj + b_kk + 16 * i;  // row of the flattened [K*cin][cout] weight matrix
-      const bool ok = kk < K * FLAT && n < p.cout;
-      gb[i] = ldraw(p.w, (int64_t)kk * p.cout + n, ok);
-      okb |= ok ? (16u << i) : 0u;
+      gb[i] = __builtin_bit_cast(uint4, raw_load_v4(rfw, (int)fb_off[i], 0, 0));
+      fb_off[i] += 4u * BK * (unsigned)p.cout;
     }
-    g_ok = okb;
     ++gj;
 #pragma unroll
     for (int i = 0; i < 4; ++i) idx_g[i] = idx_n[i];
@@ -460,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
   };
   auto sts = [&](int buf) {
     auto masked = [&](uint4 u, unsigned bit) {
+      if (FLAT) return u;  // (buffer loads: invalid words arrive as zeros)
       const unsigned m = (g_ok & bit) ? 0xFFFFFFFFu : 0u;
       return make_uint4(u.x & m, u.y & m, u.z & m, u.w & m);
     };
@@ -981,11 +1000,6 @@ constexpr int CLDC = BN + 4;         // row stride of the C tile (floats)
 constexpr int CKP = 9;               // offsets per workgroup the rulebook has room for
 constexpr int CD = 3;                // ring of global-load register sets (an item is requested CD - 1 items ahead; 4 sets spill at 128 VGPRs)
 constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * LDA + CKP * CM + 32) * 4 + CKP * CM + 4 * CM; }
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using i32x4 = __attribute__((ext_vector_type(4))) int;
-// raw buffer loads with a per-lane byte offset (VGPR) and a per-item byte offset (SGPR): no address arithmetic per load
-__device__ f32x4 raw_load_v4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ float raw_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 
 // CM: rows per tile.  64: 39 KB of LDS, four workgroups (16 waves) per CU -- the latency of an item's chain (barrier,
 // LDS stores, operand reads, scatter) is hidden by the other workgroups; 128: half the weight traffic.
@@ -2286,7 +2300,8 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   } else {
     const bool stage = row_perm != nullptr;
     if (vec && g_pipeline) {
-      const bool flat = cin == 28 && zs == 1 && !flip_k && !w_transposed && !stage && g_flat;
+      const bool flat = cin == 28 && zs == 1 && !flip_k && !w_transposed && !stage && g_flat && ldx <= 32 &&
+                        4ll * K * cin * cout < (1ll << 31);  // (the buffer-offset arithmetic of the flat path; rows < 2^24 - 1: 4 n K < 2^31 above)
 #define MINK_LAUNCH_GG2(M)                                                                          \
   do {                                                                                              \
     if (w_transposed && stage) gather_gemm2_kernel<true, true, 0, M><<<grid, 256, 0, st>>>(p);      \
