@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmink_hip.so")
+LIB_PATH = os.environ.get("MINK_HIP_LIB") or os.path.join(_HERE, "libmink_hip.so")  # (override: A/B builds of the same ABI)
 CSRC = os.path.join(_HERE, "csrc")
 
 _i32, _i64, _f32, _p = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
