@@ -1224,41 +1224,19 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], u1.z, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], u1.w, c, 0, 0, 0);
       };
-      auto mfma16 = [&](f32x4 &c, f32x4 &d, const float4 &u0, const float4 &u1, const float4 &v0, const float4 &v1) __attribute__((always_inline)) {
-        // two blocks, alternating accumulators: a dependent MFMA is two instructions away
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], v0.x, d, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], v0.y, d, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], u0.z, c, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], v0.z, d, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], u0.w, c, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], v0.w, d, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], u1.x, c, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], v1.x, d, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], u1.y, c, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], v1.y, d, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], u1.z, c, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], v1.z, d, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], u1.w, c, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], v1.w, d, 0, 0, 0);
-      };
       auto xr = [&](int blk, int half) __attribute__((always_inline)) { return *reinterpret_cast<const float4 *>(a + blk * 16 * LDA + 16 * half); };
-      // blocks in pairs; the operands of the next pair are read before this pair's MFMAs (rows past the compacted count
-      // hold stale data that is read but never multiplied)
-      float4 x[4] = {xr(0, 0), xr(0, 1), xr(1, 0), xr(1, 1)};
+      // The operands of every block are read up front (rows past the compacted count hold stale data that is read but
+      // never multiplied), then one accumulation chain per block that exists.  Each accumulator is written in ONE
+      // place per item: the paired form (two blocks' MFMAs alternating, a single-block tail) made the compiler keep
+      // the merged accumulators in other registers and copy them back -- 32 v_mov_b64 per item beside 24 MFMAs, on a
+      // part where every vector-ALU instruction is a slot the matrix pipe loses; the 8-cycle gap between dependent
+      // 16x16x4 MFMAs of one chain is filled by the other three waves of the SIMD.
+      float4 u[NBLK][2];
 #pragma unroll
-      for (int b = 0; b < NBLK; b += 2) {
-        if (b < nb) {  // uniform
-          float4 y[4];
-          const int nx = b + 2 < NBLK ? b + 2 : b;
-          y[0] = xr(nx, 0), y[1] = xr(nx, 1), y[2] = xr(nx + 1, 0), y[3] = xr(nx + 1, 1);
-          if (b + 1 < nb) mfma16(acc[b], acc[b + 1], x[0], x[1], x[2], x[3]);
-          else mfma8(acc[b], x[0], x[1]);
+      for (int b = 0; b < NBLK; ++b) u[b][0] = xr(b, 0), u[b][1] = xr(b, 1);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = y[e];
-        }
-      }
+      for (int b = 0; b < NBLK; ++b)
+        if (b < nb) mfma8(acc[b], u[b][0], u[b][1]);  // uniform
       if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
         cc = 0, ++ka;
         auto scatter = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
