@@ -1214,6 +1214,11 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       float wf[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) wf[e] = gw[slot][e];
+      // item it + CD takes the registers of item it NOW, not after the MFMAs: the compiler's s_waitcnt before the next
+      // step's LDS stores is vmcnt(0..9) where the ring would allow 18 (it merges the loop-carried load scores
+      // conservatively), so a load issued at the end of a step was waited for a few hundred cycles later; issued here
+      // it has this step's MFMAs to arrive
+      gload(slot);
       auto mfma8 = [&](f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
@@ -1264,7 +1269,6 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
           if (nb > 6) scatter(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
         }
       }
-      gload(slot);  // item it + CD takes the registers of item it
       MINK_LDS_BARRIER();
     };
     for (int base = 0; base < n_items; base += CD) {
