@@ -1334,7 +1334,8 @@ struct WgradParams {
   float *out;  // dw (nsplit == 1) or workspace [nsplit][K][cin][cout]
   int64_t n_out, rows_per_split;
   int ldx, cin, ldy, cout, K, ct_tiles, ngroups, ablate;
-  unsigned x_bytes, dy_bytes, nbr_bytes;  // streaming kernel only (buffer descriptors)
+  unsigned x_bytes, dy_bytes, nbr_bytes;  // buffer descriptors (streaming kernels; tiled kernel when buf_ok)
+  int buf_ok;                             // every byte size < 2^31 and n_in < 2^24: 32-bit offset arithmetic is safe
   // streaming kernel, FUSE: `dy` is the batch-norm INPUT y and the B operand is recomputed on the fly as the
   // input gradient of  pool(relu(bn(y)))  from the pooled gradient -- that gradient is never materialised
   const float *dyp;   // [n_pool][cout] gradient of the pooled output
@@ -1349,8 +1350,13 @@ struct WgradParams {
 // Software pipeline per tile: all G pair lists are built up front from one nbr load per row;
 // then for each offset the x gather of offset g+1 is in flight (registers) while the MFMAs
 // of offset g run from LDS.
-template <int G, bool NARROW, bool VEC>
+// BUF (VEC operands whose byte sizes fit 31 bits, fewer than 2^24 input rows): table, dy and gathered x rows come through
+// raw buffer loads -- a missing neighbour / a row past the end / a column past the width is an out-of-range offset that
+// returns zeros, so a load costs one 24-bit multiply-add instead of a 64-bit address, a select and (as the guarded form
+// compiled) a branch around every load.
+template <int G, bool NARROW, bool VEC, bool BUF = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
+  static_assert(!BUF || VEC, "buffer loads are 16 bytes wide");
   constexpr int XW = NARROW ? 32 : 64;      // x tile width (floats)
   constexpr int XLD = XW + 4;               // LDS row stride
   constexpr int XC4 = XW / 4;               // float4 columns per x row
@@ -1383,8 +1389,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   for (int g = 0; g < G; ++g) acc[g] = (f32x16){0};
 
   float4 rx[XNI] = {};
+  const i32x4 bx = raw_rsrc(p.x, BUF ? p.x_bytes : 0u), bd = raw_rsrc(p.dy, BUF ? p.dy_bytes : 0u), bn = raw_rsrc(p.nbr, BUF ? p.nbr_bytes : 0u);
+  const unsigned ldx4 = 4u * (unsigned)p.ldx, ldy4 = 4u * (unsigned)p.ldy, K4 = 4u * (unsigned)p.K;
+  const unsigned x_coff = ci0 + 4 * x_c4 < p.cin ? 4u * (unsigned)(ci0 + 4 * x_c4) : 0x80000000u;
+  const unsigned d_coff = co0 + 4 * d_c4 < p.cout ? 4u * (unsigned)(co0 + 4 * d_c4) : 0x80000000u;
   auto gather = [&](int g) {  // x rows of the compacted pairs of offset g -> registers
     if (p.ablate & 64) return;
+    if constexpr (BUF) {
+      // (list entries behind the padded pair count are stale rows of an earlier offset: loaded, stored, never multiplied;
+      //  the tail pairs carry -1 = row 0xFFFFFF, beyond x)
+#pragma unroll
+      for (int i = 0; i < XNI; ++i)
+        rx[i] = __builtin_bit_cast(float4, raw_load_v4(bx, (int)(__umul24((unsigned)s_src[g * LL + x_rr + XRP * i], ldx4) + x_coff), 0, 0));
+      return;
+    }
     const int m = s_cnt[2 * g] + s_cnt[2 * g + 1];
     const int mpad = (m + 15) & ~15;
 #pragma unroll
@@ -1410,8 +1428,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     int nb[G], rank[G];
     if (tid < WROWS) {
       const int64_t row = r0 + tid;
+      if constexpr (BUF) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) nb[g] = (row < rend && g < ng) ? p.nbr[row * p.K + k0 + g] : -1;
+        for (int g = 0; g < G; ++g) {
+          const bool ok = row < rend && g < ng;
+          const int v = raw_load_i32(bn, (int)(ok ? (unsigned)row * K4 + 4u * (unsigned)(k0 + g) : 0x80000000u), 0, 0);
+          nb[g] = ok ? v : -1;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) nb[g] = (row < rend && g < ng) ? p.nbr[row * p.K + k0 + g] : -1;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1419,7 +1446,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       const int64_t row = r0 + r;
       const int co = co0 + 4 * d_c4;
       float4 v;
-      if (VEC)
+      if constexpr (BUF)
+        v = __builtin_bit_cast(float4, raw_load_v4(bd, (int)((row < rend ? (unsigned)row * ldy4 : 0x80000000u) + d_coff), 0, 0));
+      else if (VEC)
         v = ld4_sel(p.dy, row * p.ldy + co, row < rend && co < p.cout);
       else
         v = row < rend ? ld4_guard(p.dy + row * p.ldy + co, p.cout - co, false) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1969,11 +1998,14 @@ static WgradPlan wgrad_plan(int64_t n_out, int K, int cin, int cout) {
 template <int G>
 static void launch_wgrad(const WgradParams &p, dim3 grid, hipStream_t st) {
   const bool vec = (((uintptr_t)p.x | (uintptr_t)p.dy) & 15) == 0 && ((p.ldx | p.ldy | p.cin | p.cout) & 3) == 0;
+  static const int buf_on = getenv("MINK_WGRAD_BUF") ? atoi(getenv("MINK_WGRAD_BUF")) : 1;  // A/B hook
   if (p.cin <= 32) {
-    if (vec) wgrad_kernel<G, true, true><<<grid, 256, 0, st>>>(p);
+    if (vec && p.buf_ok && buf_on) wgrad_kernel<G, true, true, true><<<grid, 256, 0, st>>>(p);
+    else if (vec) wgrad_kernel<G, true, true><<<grid, 256, 0, st>>>(p);
     else wgrad_kernel<G, true, false><<<grid, 256, 0, st>>>(p);
   } else {
-    if (vec) wgrad_kernel<G, false, true><<<grid, 256, 0, st>>>(p);
+    if (vec && p.buf_ok && buf_on) wgrad_kernel<G, false, true, true><<<grid, 256, 0, st>>>(p);
+    else if (vec) wgrad_kernel<G, false, true><<<grid, 256, 0, st>>>(p);
     else wgrad_kernel<G, false, false><<<grid, 256, 0, st>>>(p);
   }
 }
@@ -2385,6 +2417,7 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
   const dim3 grid((unsigned)(pl.ngroups * cdiv(cin, WT) * p.ct_tiles), (unsigned)pl.nsplit);
   const int64_t xb = 4 * n_in * ldx, db = 4 * n_out * ldy, nb = 4 * n_out * K;
   p.x_bytes = (unsigned)xb, p.dy_bytes = (unsigned)db, p.nbr_bytes = (unsigned)nb;
+  p.buf_ok = xb < (1ll << 31) && db < (1ll << 31) && nb < (1ll << 31) && n_in < (1 << 24) && xb <= 0xFFFFFFll * 4 * ldx;
   const bool stream_ok = wgrad_stream_ok(n_in, ldx, cin, ldy, cout, n_out, K);
   const bool bf16_stream = g_math == 1 && g_wgrad_bf16 && !g_wgrad_bf16_off && pl.G == 9 && stream_ok && g_wgrad_stream;
   // flattened (offset, channel) tiling: 24 instead of 27 tiles when the axis fits three groups of 256 rows and the
