@@ -337,3 +337,20 @@ if which in ("l1", "l4", "all"):
         bench_layer(f"l@{ts}.c1", xin, keys[ts], keys[ts * 2], 3, cin, cout, 2)
         xin2 = torch.randn(m.levels[ts * 2].n, cout, device=dev)
         bench_layer(f"l@{ts*2}.c2", xin2, keys[ts * 2], keys[ts * 2], 3, cout, cout, 1)
+if which == "wmid":  # mid-layer weight gradient (tiled kernel): full, without the MFMA loop (128), without the x gathers (64), without both
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    for ts in (4, 8, 32):
+        c = chans[ts]
+        nbr, _ = m.kernel_table(keys[ts], keys[ts], 3, 1)
+        xin = torch.randn(nbr.shape[0], c, device=dev)
+        gy = torch.randn(nbr.shape[0], c, device=dev)
+        res = []
+        for ab in (0, 128, 64, 192):
+            lib().mink_conv_set_stagger(ab)
+            res.append((ab, timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, c, c)), reps) * 1e3))
+        lib().mink_conv_set_stagger(0)
+        print(f"l@{ts}.c2 wgrad rows={nbr.shape[0]} {c}->{c}: " + "  ".join(f"ablate {a}: {t:.1f} us" for a, t in res))
