@@ -1682,12 +1682,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
                                                                      //  and, with it, a copy of all 144 accumulators per trip)
     return c_ga * c_is * (g - c_dbn - xh * c_dgn);
   };
+  // FLAT: the lane's table entries of the pair whose x values are requested NEXT, read from the staging slot one stage
+  // ahead (right behind the stash that fills it) -- read where they are used, every gather stood behind an LDS round trip
+  unsigned nbn[G];
+  auto read_entries = [&](int slot) {
+    if constexpr (FLAT) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) nbn[g] = sN[wave][slot][h][kidx[g]];
+    }
+  };
   auto load_xs = [&](int s, int slot, int q, auto &&between) {  // the nine x values of pair q
     if constexpr (FLAT) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         between(g);
-        xa[s][g] = buf_load(rx, __umul24(sN[wave][slot][h][kidx[g]], ldx4) + xoff[g]);
+        xa[s][g] = buf_load(rx, __umul24(nbn[g], ldx4) + xoff[g]);
       }
       return;
     }
@@ -1713,6 +1722,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
 #pragma unroll
     for (int s = 0; s < D; ++s) {  // same load order as the loop body: the vmcnt waits there are FIFO distances
       stash(s, s & 1, s);
+      read_entries(s & 1);
       load_xs(s, s & 1, s, [](int) {});
       load_dy(s, s);
       load_raw(s, s + D);
@@ -1720,6 +1730,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     stash(0, 0, D);  // pair D
+    read_entries(0);
     for (int q0 = 0; q0 < nq; q0 += D) {
 #pragma unroll
       for (int s = 0; s < D; ++s) {  // pair q0 + s from slot s; pairs past nq were loaded as zeros
@@ -1732,6 +1743,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
         });
         load_dy(s, q0 + s + D);
         stash((s + 1) % D, (s + 1) & 1, q0 + s + D + 1);  // pair q0 + s + D + 1, loaded D - 1 pairs ago
+        read_entries((s + 1) & 1);
         load_raw(s, q0 + s + 2 * D);
         load_i2o(s, q0 + s + 2 * D);
 #pragma unroll
