@@ -1610,9 +1610,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   constexpr int ng = G;
   const int64_t rbeg = (int64_t)ss.split * p.rows_per_split;
   const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rd = make_rsrc(p.dy, p.dy_bytes),
-                               rn = make_rsrc(p.nbr, p.nbr_bytes);
   const unsigned ldx4 = 4u * p.ldx, ldy4 = 4u * p.ldy, K4 = 4u * p.K;
+  // The descriptors of everything indexed by the OUTPUT row end at this split's last row: a row past the end reads zeros
+  // (table entry 0, dy 0, parent 0) without a test per load -- its dy operand is zero (FUSE: forced below), so whatever x
+  // row its entries name contributes nothing.
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rd = make_rsrc(p.dy, (unsigned)rend * ldy4),
+                               rn = make_rsrc(p.nbr, (unsigned)rend * K4);
   // lanes beyond cin / cout only feed rows / columns of the product that are never stored
   const unsigned xcol = 4u * min(col, p.cin - 1);
   const unsigned dcol = 4u * min(co0 + 32 * wn + col, p.cout - 1);
@@ -1631,10 +1634,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   // FUSE: per-lane constants of this lane's output channel
   const int cco = min(co0 + 32 * wn + col, p.cout - 1);
   const __amdgpu_buffer_rsrc_t rp = make_rsrc(FUSE ? (const void *)p.dyp : (const void *)p.dy, FUSE ? p.dyp_bytes : 0u),
-                               ri = make_rsrc(FUSE ? (const void *)p.in2out : (const void *)p.nbr, FUSE ? p.i2o_bytes : 0u);
+                               ri = make_rsrc(FUSE ? (const void *)p.in2out : (const void *)p.nbr, FUSE ? (unsigned)rend * 4u : 0u);
   const float c_mu = FUSE ? p.mean[cco] : 0.f, c_is = FUSE ? p.invstd[cco] : 0.f, c_ga = FUSE ? p.gamma[cco] : 0.f,
               c_be = FUSE ? p.beta[cco] : 0.f, c_dgn = FUSE ? p.dgamma[cco] * p.inv_n : 0.f,
               c_dbn = FUSE ? p.dbeta[cco] * p.inv_n : 0.f;
+  const float c_nmu = -c_mu * c_is, c_a = c_ga * c_is;
   float dp[D];        // FUSE: pooled gradient of the row's parent
   unsigned i2or[D];   // FUSE: parent row of a pair whose operands are still to be requested
 
@@ -1657,30 +1661,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
   auto rel_of = [&](int q) { return 2 * (2 * q + wa) + h; };
   auto load_raw = [&](int s, int q) {  // rows past the end read as entry 0; their x offset is forced out of range below
     const int r = rel_of(q);
-    nraw[s] = __builtin_amdgcn_raw_buffer_load_b32(rn, (int)(r < nrel ? __umul24(r, K4) + nbase : OOB), 0, 0);
+    nraw[s] = __builtin_amdgcn_raw_buffer_load_b32(rn, (int)(__umul24(r, K4) + nbase), 0, 0);
   };
   auto stash = [&](int s, int slot, int q) {
-    // lanes col >= NK store padding: no exec-mask branch in the loop.  FLAT: a row past the end stages "no neighbour"
-    // (the column offsets are per tile there, so the row test cannot ride on them as it does below)
-    sN[wave][slot][h][col] = FLAT && rel_of(q) >= nrel ? 0xFFFFFFFFu : nraw[s];
+    sN[wave][slot][h][col] = nraw[s];  // lanes col >= NK store padding: no exec-mask branch in the loop
   };
   auto load_i2o = [&](int s, int q) {  // (a row past the end reads parent 0: its x operand is zero anyway)
     if (FUSE) {
       const int r = rel_of(q);
-      i2or[s] = __builtin_amdgcn_raw_buffer_load_b32(ri, (int)(r < nrel ? 4u * r + ibase : OOB), 0, 0);
+      i2or[s] = __builtin_amdgcn_raw_buffer_load_b32(ri, (int)(4u * r + ibase), 0, 0);
     }
   };
   auto load_dy = [&](int s, int q) {
     const int r = rel_of(q);
-    db[s] = buf_load(rd, r < nrel ? __umul24(r, ldy4) + dbase : OOB);
+    db[s] = buf_load(rd, __umul24(r, ldy4) + dbase);
     if (FUSE) dp[s] = buf_load(rp, __umul24(i2or[s], ldy4) + dcol);  // the pooled gradient has the same row pitch
   };
-  auto b_operand = [&](int s) {
+  auto b_operand = [&](int s, int q) {
     if (!FUSE) return db[s];
-    const float xh = (db[s] - c_mu) * c_is;
-    const float g = dp[s] * (xh * c_ga + c_be > 0.f ? 1.f : 0.f);  // (a select of the loaded value itself became an exec branch
-                                                                     //  and, with it, a copy of all 144 accumulators per trip)
-    return c_ga * c_is * (g - c_dbn - xh * c_dgn);
+    const float xh = fmaf(db[s], c_is, c_nmu);
+    const float m = fmaf(xh, c_ga, c_be) > 0.f ? 1.f : 0.f;  // (a select of the loaded value itself became an exec branch
+                                                              //  and, with it, a copy of all 144 accumulators per trip)
+    const float v = fmaf(-c_dgn, xh, fmaf(dp[s], m, -c_dbn));
+    return (rel_of(q) < nrel ? c_a : 0.f) * v;  // a row past the end: zero
   };
   // FLAT: the lane's table entries of the pair whose x values are requested NEXT, read from the staging slot one stage
   // ahead (right behind the stash that fills it) -- read where they are used, every gather stood behind an LDS round trip
@@ -1704,11 +1707,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
     const uint4 n1 = *reinterpret_cast<const uint4 *>(&sN[wave][slot][h][4]);
     const unsigned n2 = sN[wave][slot][h][8];
     const unsigned nbv[9] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2};
-    const unsigned xbase = rel_of(q) < nrel ? xcol : OOB;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       between(g);
-      xa[s][g] = buf_load(rx, __umul24(nbv[g], ldx4) + xbase);
+      xa[s][g] = buf_load(rx, __umul24(nbv[g], ldx4) + xcol);
     }
   };
 
@@ -1734,7 +1736,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
     for (int q0 = 0; q0 < nq; q0 += D) {
 #pragma unroll
       for (int s = 0; s < D; ++s) {  // pair q0 + s from slot s; pairs past nq were loaded as zeros
-        const float b = b_operand(s);
+        const float b = b_operand(s, q0 + s);
         float a[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) a[g] = xa[s][g];
