@@ -1808,9 +1808,8 @@ __device__ __forceinline__ bf16x8v pack_bf16x8(const float (&v)[8]) {
 template <bool FUSE>
 __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p) {
   constexpr int G = 9, SB = 1;           // offsets per group, offsets per sub-batch (gathers run one sub-batch ahead)
-  constexpr unsigned OOB = 0x80000000u;  // beyond any descriptor this kernel is launched with
   __shared__ float sR[2 * 16 * 64];
-  __shared__ __attribute__((aligned(16))) unsigned sN[4][2][16][12];  // [wave][slot][row of the block][offset (9 used)]
+  __shared__ __attribute__((aligned(16))) unsigned sN[4][2][12][16];  // [wave][slot][offset (9 used)][row of the block]: a lane's eight rows of one offset are two 16-byte reads
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wa = wave >> 1, h = lane >> 5, col = lane & 31;
@@ -1823,16 +1822,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
   const int nrel = (int)(rend - rbeg);
   const int nblocks = (nrel + 15) >> 4;
   const int nq = (nblocks + 1 - wa) >> 1;  // this wave's blocks: b = 2 q + wa
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rd = make_rsrc(p.dy, p.dy_bytes), rn = make_rsrc(p.nbr, p.nbr_bytes);
-  const __amdgpu_buffer_rsrc_t rp = make_rsrc(FUSE ? (const void *)p.dyp : (const void *)p.dy, FUSE ? p.dyp_bytes : 0u),
-                               ri = make_rsrc(FUSE ? (const void *)p.in2out : (const void *)p.nbr, FUSE ? p.i2o_bytes : 0u);
   const unsigned ldx4 = 4u * p.ldx, ldy4 = 4u * p.ldy, K4 = 4u * p.K;
+  // (as in the fp32 kernel: what is indexed by the output row ends at this split's last row -- rows past it read zeros)
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rd = make_rsrc(p.dy, (unsigned)rend * ldy4), rn = make_rsrc(p.nbr, p.nbr_bytes);
+  const __amdgpu_buffer_rsrc_t rp = make_rsrc(FUSE ? (const void *)p.dyp : (const void *)p.dy, FUSE ? p.dyp_bytes : 0u),
+                               ri = make_rsrc(FUSE ? (const void *)p.in2out : (const void *)p.nbr, FUSE ? (unsigned)rend * 4u : 0u);
   const unsigned xcol = 4u * min(col, p.cin - 1);
   const unsigned dcol = 4u * min(co0 + 32 * wn + col, p.cout - 1);
   const int cco = min(co0 + 32 * wn + col, p.cout - 1);
   const float c_mu = FUSE ? p.mean[cco] : 0.f, c_is = FUSE ? p.invstd[cco] : 0.f, c_ga = FUSE ? p.gamma[cco] : 0.f,
               c_be = FUSE ? p.beta[cco] : 0.f, c_dgn = FUSE ? p.dgamma[cco] * p.inv_n : 0.f,
               c_dbn = FUSE ? p.dbeta[cco] * p.inv_n : 0.f;
+  const float c_nmu = -c_mu * c_is, c_a = c_ga * c_is;
   const unsigned nbase = (unsigned)rbeg * K4, ibase = (unsigned)rbeg * 4u, dbase = (unsigned)rbeg * ldy4 + dcol;
 
   f32x16 acc[G];
@@ -1854,7 +1855,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
     auto stash_table = [&](int slot) __attribute__((always_inline)) {
       if (t_part < 3) {
 #pragma unroll
-        for (int e = 0; e < 3; ++e) sN[wave][slot][t_row][3 * t_part + e] = traw[e];
+        for (int e = 0; e < 3; ++e) sN[wave][slot][3 * t_part + e][t_row] = traw[e];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private slot: in-order LDS, visible to the reads below
     };
@@ -1864,7 +1865,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int r = 16 * (2 * q + wa) + 8 * h + j;
-          par[j] = (q < nq && r < nrel) ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ri, (int)(4u * r + ibase), 0, 0) : 0u;
+          par[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ri, (int)(4u * r + ibase), 0, 0);  // (past the end: parent 0)
         }
       }
     };
@@ -1873,9 +1874,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = 16 * (2 * q + wa) + 8 * h + j;
-        const bool ok = q < nq && r < nrel;
-        braw[j] = buf_load(rd, ok ? __umul24(r, ldy4) + dbase : OOB);
-        if (FUSE) bpool[j] = buf_load(rp, ok ? __umul24(par[j], ldy4) + dcol : OOB);
+        braw[j] = buf_load(rd, __umul24(r, ldy4) + dbase);
+        if (FUSE) bpool[j] = buf_load(rp, __umul24(par[j], ldy4) + dcol);
       }
     };
     auto b_fragment = [&](int q) __attribute__((always_inline)) {
@@ -1886,10 +1886,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
           v[j] = braw[j];
         } else {
           const int r = 16 * (2 * q + wa) + 8 * h + j;
-          const float xh = (braw[j] - c_mu) * c_is;
-          const float g = bpool[j] * (xh * c_ga + c_be > 0.f ? 1.f : 0.f);
-          const float d = c_ga * c_is * (g - c_dbn - xh * c_dgn);
-          v[j] = r < nrel ? d : 0.f;  // a row past the end must not contribute (its x operand is zero too)
+          const float xh = fmaf(braw[j], c_is, c_nmu);
+          const float m = fmaf(xh, c_ga, c_be) > 0.f ? 1.f : 0.f;
+          v[j] = (r < nrel ? c_a : 0.f) * fmaf(-c_dgn, xh, fmaf(bpool[j], m, -c_dbn));  // a row past the end must not contribute
         }
       }
       return pack_bf16x8(v);
@@ -1898,11 +1897,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
     auto load_x = [&](int buf, int slot, int sb) __attribute__((always_inline)) {  // the x gathers of one sub-batch (three offsets x eight rows)
 #pragma unroll
       for (int g = 0; g < SB; ++g) {
+        const uint4 n0 = *reinterpret_cast<const uint4 *>(&sN[wave][slot][SB * sb + g][8 * h]);
+        const uint4 n1 = *reinterpret_cast<const uint4 *>(&sN[wave][slot][SB * sb + g][8 * h + 4]);
+        const unsigned nbv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const unsigned nb = sN[wave][slot][8 * h + j][SB * sb + g];
-          xraw[buf][g][j] = buf_load(rx, (nb & 0x80000000u) ? OOB : __umul24(nb, ldx4) + xcol);
-        }
+        for (int j = 0; j < 8; ++j)
+          xraw[buf][g][j] = buf_load(rx, __umul24(nbv[j], ldx4) + xcol);  // (-1 is row 0xFFFFFF: beyond x, reads as zero)
       }
     };
     // ---- prologue: table of block 0 staged, of block 1 in flight; B operands and first x sub-batch of block 0 in flight
