@@ -1166,15 +1166,23 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
     int g_ka = 0, g_cc = 0;  // iterator of the global-load stage
     // every call issues the same NA + (W_T ? 2 : 8) loads, whatever the item: the vmcnt distances of the ring are static
     // (a conditional load would make every wait a wait for ALL loads in flight); past the end the last item is re-read
-    auto gload = [&](int slot) __attribute__((always_inline)) {
+    // the two halves of an item's request: the gathered rows (gload_a, at the start of a step) and the weight fragment
+    // (gload_w, behind the step's MFMAs, which read the previous fragment in place -- requested early, the registers would
+    // have to be copied out first: eight v_mov beside 24 MFMAs); gload_w steps the iterator
+    auto gload_a = [&](int slot) __attribute__((always_inline)) {
+      const int ga_ = min(g_ka, na - 1);
+      const int j = nib(act_lo, act_hi, ga_);
+      const int c0 = (cbeg + g_cc) * BK;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        ga[slot][i] = *reinterpret_cast<const f32x4 *>(xcol + (int64_t)s_src[j * CM + a_r + 32 * i] * p.ldx + c0);
+    };
+    auto gload_w = [&](int slot) __attribute__((always_inline)) {
       const int ga_ = min(g_ka, na - 1);
       const int j = nib(act_lo, act_hi, ga_);
       const int k = kof(ga_, j);
       const int kw = p.flip_k ? K - 1 - k : k;
       const int c0 = (cbeg + g_cc) * BK;
-#pragma unroll
-      for (int i = 0; i < NA; ++i)
-        ga[slot][i] = *reinterpret_cast<const f32x4 *>(xcol + (int64_t)s_src[j * CM + a_r + 32 * i] * p.ldx + c0);
       if (!W_T) {
         const int so = 4 * ((kw * p.cin + c0) * p.cout + n0);
 #pragma unroll
@@ -1201,7 +1209,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
     static_assert(CD == 3, "the steady-state loop is unrolled by hand");
     // items 0 .. CD - 1 requested (slot = item % CD), item 0 -> LDS
     if (n_items > 0) {  // uniform
-      gload(0), gload(1), gload(2);
+      gload_a(0), gload_w(0), gload_a(1), gload_w(1), gload_a(2), gload_w(2);
       sts(0, 0);
     }
     MINK_LDS_BARRIER();
@@ -1211,14 +1219,12 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const int j = nib(act_lo, act_hi, ka), nb = nib(nbs_lo, nbs_hi, ka);  // nb >= 1
       sts(decltype(nslot_c)::value, (it + 1) & 1);  // item it + 1 (after the last item: a re-read copy nobody multiplies)
       const float *a = sA + (it & 1) * CM * LDA + n * LDA + 4 * kq;
-      float wf[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) wf[e] = gw[slot][e];
+      const float (&wf)[8] = gw[slot];
       // item it + CD takes the registers of item it NOW, not after the MFMAs: the compiler's s_waitcnt before the next
       // step's LDS stores is vmcnt(0..9) where the ring would allow 18 (it merges the loop-carried load scores
       // conservatively), so a load issued at the end of a step was waited for a few hundred cycles later; issued here
       // it has this step's MFMAs to arrive
-      gload(slot);
+      gload_a(slot);
       auto mfma8 = [&](f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
@@ -1269,6 +1275,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
           if (nb > 6) scatter(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
         }
       }
+      gload_w(slot);
       MINK_LDS_BARRIER();
     };
     for (int base = 0; base < n_items; base += CD) {
