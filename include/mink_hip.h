@@ -188,7 +188,10 @@ int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *bat
  *                                            kernel and swap cin/cout)
  *   flip_k             : use w[K-1-k] for table column k (dgrad of a stride-1 conv
  *                        re-uses the forward table: nbr_t[i][k] == nbr[i][K-1-k])
- *   nbr[n_out][K]      : neighbour table;  y[n_out][ldy] receives cout columns
+ *   nbr[n_out][K]      : neighbour table;  y[n_out][ldy] receives cout columns.  (cin == 28, the flattened-K
+ *                        stem path: x must have fewer than 2^24 - 1 rows -- its rows are addressed with a
+ *                        24-bit multiply; the library checks n_out, which equals the row count of x for the
+ *                        stride-1 convolution that path serves.)
  *   bias[cout] or NULL
  *   row_perm/n_virtual : optional row permutation (NULL/0 = identity): tile row v computes
  *                        output row row_perm[v], -1 entries are padding (mink_class_partition)

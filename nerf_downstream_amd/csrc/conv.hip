@@ -2335,8 +2335,10 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   } else {
     const bool stage = row_perm != nullptr;
     if (vec && g_pipeline) {
+      // the flat path addresses x rows with a 24-bit multiply: the table must not name a row >= 2^24 - 1.  x's row count is
+      // not an argument here; a convolution this path is meant for (stride 1, same map) has as many input as output rows
       const bool flat = cin == 28 && zs == 1 && !flip_k && !w_transposed && !stage && g_flat && ldx <= 32 &&
-                        4ll * K * cin * cout < (1ll << 31);  // (the buffer-offset arithmetic of the flat path; rows < 2^24 - 1: 4 n K < 2^31 above)
+                        4ll * K * cin * cout < (1ll << 31) && n_out < (1 << 24) - 1;
 #define MINK_LAUNCH_GG2(M)                                                                          \
   do {                                                                                              \
     if (w_transposed && stage) gather_gemm2_kernel<true, true, 0, M><<<grid, 256, 0, st>>>(p);      \
