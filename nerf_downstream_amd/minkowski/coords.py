@@ -13,6 +13,8 @@ Accessors mirror the ones the reference touches: ``stride(key, stride)``
 (sparse_conv.py:403-405), ``kernel_map(in_key, out_key, stride, kernel_size, dilation)``
 -> ``{k: IntTensor[2,n]}`` (sparse_conv.py:90-96,124-143), ``size(key)`` (sparse_conv.py:80).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -34,6 +36,9 @@ def _as_int(v):
 
 
 _OFFSET_CACHE = {}
+
+
+_ONDEMAND_HASH = os.environ.get("MINK_ONDEMAND_HASH", "0") != "0"  # on-demand tables through the per-voxel hash (A/B, tests)
 
 
 def kernel_offsets(kernel_size, in_ts, dilation=1):
@@ -375,7 +380,12 @@ class CoordinateManager:
         self.trace.append(("ktable",) + kk + (bool(transposed),))
         self._sync_lazy()
         ent = self.tables.get(kk)
-        if ent is None or (transposed and ent[1] is None):
+        if (ent is None or (transposed and ent[1] is None)) and not _ONDEMAND_HASH:
+            # a table asked for outside a prepared plan (first batches, tools): the same block-index builder, for one table
+            self._build_tables_batched([("ktable",) + kk + (bool(transposed),)])
+            ent = self.tables[kk]
+            self._note_lazy(*ent)
+        elif ent is None or (transposed and ent[1] is None):  # MINK_ONDEMAND_HASH=1: the per-voxel hash look-up (mink_kernel_map)
             lin, lout = self.levels[in_key.ts], self.levels[out_key.ts]
             off = kernel_offsets(ks, in_key.ts, dil)
             K = off.shape[0]
