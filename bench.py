@@ -125,7 +125,12 @@ def pmc_traffic(tag, meta):
     passes; 2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md).  None if no matching entry."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    import re
+
+    def natural(path):  # r02_v10 after r02_v9
+        return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=natural)
     if not files:
         return None
     stem_wgrad = tag.startswith("wgrad") and meta["cin"] <= 32 and meta["K"] == 27
