@@ -38,6 +38,7 @@ struct GemmParams {
   int ldx, cin, ldy, cout, K, flip_k, kper, stagger;
   int accumulate;  // y += result instead of y = result (un-split launches whose rows are visited at most once)
   float *stats;  // optional [row tiles][2][cout]: per-tile column (sum, sum of squares) of y (un-split launches only)
+  int swz_x, swz_y, swz_z;  // compact_gemm_kernel: > 0 = XCD-aware one-dimensional launch over (row tiles, column tiles, slices)
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float *p, int valid, bool vec) {
@@ -1027,13 +1028,25 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
   const int tid = threadIdx.x, lane = tid & 63;
   const int cs = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = column strip
   const int kq = lane >> 4, n = lane & 15;
-  const int64_t o0 = (int64_t)blockIdx.x * CM;
-  const int n0 = blockIdx.y * BN;
+  // Workgroup -> (row tile bx, column tile by, slice bz).  Plain: the launch grid.  Swizzled (p.swz_x > 0; deep layers, a
+  // one-dimensional launch): workgroups are dealt to the eight XCDs round-robin in launch order, and every row tile of a
+  // (column tile, slice) reads the SAME weight slice -- 262 KB at l4.conv2, where the eight row tiles of a slice landed on
+  // eight XCDs and each L2 fetched it for itself (PMC: 250 MB of HBM traffic for 30 MB of weights).  Here a run of
+  // 8 * swz_x launch slots serves eight slices, one per XCD, whose swz_x row tiles follow each other on that XCD.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, gz = gridDim.z;
+  if (p.swz_x > 0) {  // uniform
+    const unsigned X = (unsigned)p.swz_x, Y = (unsigned)p.swz_y, Z = (unsigned)p.swz_z;
+    const unsigned L = blockIdx.x, slice = 8u * (L / (8u * X)) + (L & 7u);
+    if (slice >= Y * Z) return;  // (the launch is padded to whole runs)
+    bx = (L % (8u * X)) >> 3, by = slice % Y, bz = slice / Y, gz = Z;
+  }
+  const int64_t o0 = (int64_t)bx * CM;
+  const int n0 = by * BN;
   const int K = p.K;
-  const int kbeg = PERM ? 0 : blockIdx.z * p.kper, nk = PERM ? K : min(K, kbeg + p.kper) - kbeg;
+  const int kbeg = PERM ? 0 : bz * p.kper, nk = PERM ? K : min(K, kbeg + p.kper) - kbeg;
   const int rows_here = (int)min((int64_t)CM, (PERM ? p.n_virtual : p.n_out) - o0);
   const int ncc_all = p.cin / BK;
-  const int cbeg = PERM ? blockIdx.z * p.kper : 0;                       // first channel chunk of this slice
+  const int cbeg = PERM ? bz * p.kper : 0;                               // first channel chunk of this slice
   const int ncc = PERM ? min(ncc_all, cbeg + p.kper) - cbeg : ncc_all;   // channel chunks of this slice
 
   // ---- prologue: table entries of the slice (a wave takes offsets cs, cs + 4, ...; they are requested together,
@@ -1224,7 +1237,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       // step's LDS stores is vmcnt(0..9) where the ring would allow 18 (it merges the loop-carried load scores
       // conservatively), so a load issued at the end of a step was waited for a few hundred cycles later; issued here
       // it has this step's MFMAs to arrive
-      gload_a(slot);
+      if (!(p.stagger & 16)) gload_a(slot);
       auto mfma8 = [&](f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
@@ -1275,7 +1288,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
           if (nb > 6) scatter(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
         }
       }
-      gload_w(slot);
+      if (!(p.stagger & 16)) gload_w(slot);
       MINK_LDS_BARRIER();
     };
     for (int base = 0; base < n_items; base += CD) {
@@ -1287,8 +1300,8 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
   }
 
   // ---- epilogue: y / slab = C (+ bias), column statistics of the tile for the batch norm that follows
-  const bool direct = gridDim.z == 1;
-  float *dst = direct ? p.y : p.ws + (int64_t)blockIdx.z * p.n_out * p.cout;
+  const bool direct = gz == 1;
+  float *dst = direct ? p.y : p.ws + (int64_t)bz * p.n_out * p.cout;
   const int ldd = direct ? p.ldy : p.cout;
   const int c4 = tid & 15, rg = tid >> 4;
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1315,7 +1328,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const int which = tid >> 6, c = tid & 63;
       float t = 0.f;
       for (int g = 0; g < 16; ++g) t += red[(g * 2 + which) * BN + c];
-      p.stats[((int64_t)blockIdx.x * 2 + which) * p.cout + n0 + c] = t;
+      p.stats[((int64_t)bx * 2 + which) * p.cout + n0 + c] = t;
     }
   }
 }
@@ -2183,6 +2196,18 @@ int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_cl
   return best;
 }
 
+// XCD-aware launch of compact_gemm_kernel for the layers whose weights do not stay in one L2 (4 MB): few row tiles, many
+// (column tile, slice) pairs.  Turns the three-dimensional grid into the padded one-dimensional one the kernel decodes.
+static int g_compact_swz = getenv("MINK_COMPACT_SWIZZLE") ? atoi(getenv("MINK_COMPACT_SWIZZLE")) : 1;  // A/B hook
+static void compact_swizzle(GemmParams &p, dim3 &grid, int cin, int cout, int K) {
+  p.swz_x = p.swz_y = p.swz_z = 0;
+  const int64_t wbytes = 4ll * K * cin * cout;
+  const unsigned slices = grid.y * grid.z;
+  if (!g_compact_swz || wbytes <= (2ll << 20) || grid.x > 64 || slices < 16) return;
+  p.swz_x = (int)grid.x, p.swz_y = (int)grid.y, p.swz_z = (int)grid.z;
+  grid = dim3((unsigned)(cdiv(slices, 8) * 8 * grid.x), 1, 1);
+}
+
 // compact_gemm_kernel (fp32, no row permutation): 64-row tiles, four workgroups per CU, at most CKP offsets per workgroup.
 // kbench ksweep on the ResNet layers: the best split is the largest one that keeps the launch within two resident rounds
 // (2 x 1024 workgroups), capped at 14 slabs -- l2.conv2 83 us at 7 slabs against 94 at the 3 the older rule picks.
@@ -2255,6 +2280,7 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   p.accumulate = (flip_k >> 1) & 1;
   p.kper = (int)cdiv(K, ksplit);
   p.stats = nullptr;
+  p.swz_x = p.swz_y = p.swz_z = 0;
   const int zs = (int)cdiv(K, p.kper);
   const dim3 grid((unsigned)cdiv(n_virtual, BM), (unsigned)cdiv(cout, BN), (unsigned)zs);
   hipStream_t st = (hipStream_t)stream;
@@ -2303,7 +2329,8 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
     const int ncc = cin / BK;
     p.kper = (int)cdiv(ncc, ksplit);  // channel chunks per slice
     const int zc = (int)cdiv(ncc, p.kper);
-    const dim3 cgrid((unsigned)cdiv(n_virtual, CMT), grid.y, (unsigned)zc);
+    dim3 cgrid((unsigned)cdiv(n_virtual, CMT), grid.y, (unsigned)zc);
+    compact_swizzle(p, cgrid, cin, cout, K);
     if (w_transposed) compact_gemm_kernel<true, CMT, true><<<cgrid, 256, smem, st>>>(p);
     else compact_gemm_kernel<false, CMT, true><<<cgrid, 256, smem, st>>>(p);
     MINK_CHECK_LAUNCH();
@@ -2328,10 +2355,11 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
                                  smem) == hipSuccess;
     }();
     MINK_REQUIRE(attr_ok, "gather_gemm: %d bytes of LDS per workgroup refused", smem);
-    const dim3 cgrid((unsigned)cdiv(n_out, CMT), grid.y, grid.z);
+    dim3 cgrid((unsigned)cdiv(n_out, CMT), grid.y, grid.z);
+    tiles_x = cgrid.x;
+    compact_swizzle(p, cgrid, cin, cout, K);
     if (w_transposed) compact_gemm_kernel<true, CMT><<<cgrid, 256, smem, st>>>(p);
     else compact_gemm_kernel<false, CMT><<<cgrid, 256, smem, st>>>(p);
-    tiles_x = cgrid.x;
   } else {
     const bool stage = row_perm != nullptr;
     if (vec && g_pipeline) {

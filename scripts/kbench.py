@@ -354,3 +354,20 @@ if which == "wmid":  # mid-layer weight gradient (tiled kernel): full, without t
             res.append((ab, timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, c, c)), reps) * 1e3))
         lib().mink_conv_set_stagger(0)
         print(f"l@{ts}.c2 wgrad rows={nbr.shape[0]} {c}->{c}: " + "  ".join(f"ablate {a}: {t:.1f} us" for a, t in res))
+if which == "cab":  # compact kernel with (0) and without (16) its steady-state global loads: how much of an item is waiting for memory
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    for ts in (4, 8, 16, 32):
+        c = chans[ts]
+        nbr, _ = m.kernel_table(keys[ts], keys[ts], 3, 1)
+        xin = torch.randn(nbr.shape[0], c, device=dev)
+        w = torch.randn(27, c, c, device=dev) * 0.05
+        res = []
+        for ab in (0, 16, 0, 16):
+            lib().mink_conv_set_stagger(ab)
+            res.append(timeit(lambda: Fn.gather_gemm(xin, w, nbr, c), reps) * 1e3)
+        lib().mink_conv_set_stagger(0)
+        print(f"l@{ts}.c2 fwd rows={nbr.shape[0]} {c}->{c}: full {res[0]:.1f} / {res[2]:.1f} us, without steady-state loads {res[1]:.1f} / {res[3]:.1f} us")
