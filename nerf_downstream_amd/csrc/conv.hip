@@ -2230,17 +2230,18 @@ static int compact_plan(int64_t n_rows, int K, int cout) {
 }
 
 // compact_gemm_kernel<.., PERM> (fp32, rows grouped by parity class: the data gradient of a strided convolution): the split
-// is over 32-channel chunks, a power of two that divides their number; kbench psweep: the largest that keeps the launch
-// within one resident round of 1024 workgroups.
+// is over 32-channel chunks; kbench ksweep: the largest that keeps the launch within ~800 workgroups (l2.conv1 three slices 51 us
+// against 57 at two or four, l3.conv1 five 53 against 57 at seven).
 static bool compact_perm_shape(int64_t n_rows, int K, int cin, int cout, int row_classes) {
   return g_compact && g_compact_perm && g_math == 0 && row_classes && K >= 8 && cin >= 64 && cin % BK == 0 && cout % BN == 0 && n_rows >= 1;
 }
 static int compact_perm_plan(int64_t n_rows, int cin, int cout) {
-  static const int cap = getenv("MINK_PERM_SPLIT_CAP") ? atoi(getenv("MINK_PERM_SPLIT_CAP")) : 1024;  // tuning hook
+  static const int cap = getenv("MINK_PERM_SPLIT_CAP") ? atoi(getenv("MINK_PERM_SPLIT_CAP")) : 850;  // tuning hook
   const int ncc = cin / BK;
-  const int64_t tiles = cdiv(n_rows, 64) * cdiv(cout, BN);
+  // (n_rows is the padded length of the class permutation: up to 127 padding rows per class, whose tiles exit at once)
+  const int64_t tiles = cdiv(std::max<int64_t>(n_rows - 512, 64), 64) * cdiv(cout, BN);
   int best = 1;
-  for (int zs = 2; zs <= ncc && ncc % zs == 0; zs *= 2) {
+  for (int zs = 2; zs <= std::min(ncc, 5); ++zs) {  // (a split that does not divide the chunk count just has a shorter last slice)
     if (tiles * zs > cap || zs * 4 * n_rows * cout > (128ll << 20)) break;
     best = zs;
   }
