@@ -247,9 +247,11 @@ if which == "wsweep":
                     if z > -(-nbr.shape[0] // 128):
                         continue
                     lib().mink_conv_set_stagger((gcode << 12) | (z << 16))
+                    Fn._PLAN_CACHE.clear()  # (the slab workspace is sized from the cached plan: a forced split needs its own)
                     t = timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, ci, cout)), reps) * 1e3
                     out.append((t, G, z))
             lib().mink_conv_set_stagger(0)
+            Fn._PLAN_CACHE.clear()
             out.sort()
             print(f"{name} wgrad n_out={nbr.shape[0]} {ci}->{cout} planner={t0:.1f}us best: " + " ".join(f"G{G}z{z}:{t:.0f}" for t, G, z in out[:6]))
 if which == "sparsity":
