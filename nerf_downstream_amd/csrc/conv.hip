@@ -2012,14 +2012,13 @@ static WgradPlan wgrad_plan(int64_t n_out, int K, int cin, int cout) {
   else if (K >= 3 && tiles * cdiv(K, 3) * row_tiles >= 1024) pl.G = 3;
   const bool tiny = row_tiles <= 4 && tiles * K >= 512;  // few rows, many weight tiles: one workgroup per (tile, offset), no slabs
   if (tiny) pl.G = 1;
-  // one 64 x 64 weight tile and many rows (layer1): since the buffer-load form one offset per workgroup and three times the
-  // workgroups win (kbench wsweep: l1.conv2 G1 z64 89 us against G3 z48 101, l1.conv1 83 against 90)
-  const bool wide = !tiny && pl.G == 3 && tiles == 1 && K == 27 && row_tiles >= 128;
-  if (wide) pl.G = 1;
+  // (layer1, one 64 x 64 weight tile and many rows: alone, one offset per workgroup and three times the workgroups win --
+  //  kbench wsweep: l1.conv2 G1 z64 89 us against G3 z48 101 -- but inside a step, beside the data-gradient chain, the 1296
+  //  workgroups take 208 us where the 432 take 125: the plan stays)
   if (g_wgrad_force & 0xF) pl.G = (g_wgrad_force & 0xF) == 1 ? 1 : (g_wgrad_force & 0xF) == 2 ? 3 : 9;  // tuning hook
   pl.ngroups = (int)cdiv(K, pl.G);
   const int64_t xy = tiles * pl.ngroups;
-  int64_t z = cdiv(wide ? 1536 : 512, xy);  // ~2 resident workgroups per CU: fewer partial slabs to write and reduce
+  int64_t z = cdiv(512, xy);  // ~2 resident workgroups per CU: fewer partial slabs to write and reduce
   if (tiny) z = 1;
   if (g_wgrad_force >> 4) z = g_wgrad_force >> 4;
   if (z > row_tiles) z = row_tiles;
