@@ -2221,12 +2221,13 @@ static bool compact_shape(int64_t n_rows, int K, int cin, int cout, int row_clas
   return zmin == 1 || zmin * 4 * n_rows * cout <= (128ll << 20);
 }
 static int compact_plan(int64_t n_rows, int K, int cout) {
+  static const int wg_cap = getenv("MINK_COMPACT_WG_CAP") ? atoi(getenv("MINK_COMPACT_WG_CAP")) : 2048;  // tuning hook (in-step sweeps)
   const int64_t tiles = cdiv(n_rows, 64) * cdiv(cout, BN);
   const int64_t slab_cap = std::max<int64_t>(1, (128ll << 20) / (4 * n_rows * cout));
   int best = (int)cdiv(K, CKP);
   for (int kper = CKP; kper >= 1; --kper) {
     const int zs = (int)cdiv(K, kper);
-    if (zs > 14 || tiles * zs > 2048 || (zs > 1 && zs > slab_cap)) break;
+    if (zs > 14 || tiles * zs > wg_cap || (zs > 1 && zs > slab_cap)) break;
     best = zs;
   }
   return best;
