@@ -131,6 +131,34 @@ def table_to_lists(nbr):
     return out
 
 
+def transpose_table(nbr, n_in):
+    """nbr_t[i, k] = the output row o with nbr[o, k] == i (or -1): the kernel map read from the input side, which the
+    data gradient of a strided convolution gathers through.  Each (input row, offset) pair has at most one output."""
+    nbr = np.asarray(nbr)
+    nbr_t = np.full((int(n_in), nbr.shape[1]), -1, np.int32)
+    for k in range(nbr.shape[1]):
+        o = np.nonzero(nbr[:, k] >= 0)[0]
+        assert np.unique(nbr[o, k]).size == o.size, "an (input row, offset) pair reaches two outputs"
+        nbr_t[nbr[o, k], k] = o.astype(np.int32)
+    return nbr_t
+
+
+def class_partition(coords, ts, pad):
+    """Row order used by the data gradient of stride-2 convolutions: rows grouped by the parity of coordinate / ts per
+    axis (class = px | py << 1 | pz << 2), input order kept inside a class, every class segment padded with -1 to a
+    multiple of `pad` rows; total length n + 8 (pad - 1), the tail -1.  Derived data of this design (no ME counterpart):
+    all rows of one class reach their outputs through the same kernel offsets."""
+    c = np.asarray(coords, dtype=np.int64)
+    cls = ((c[:, 1] // ts) & 1) | (((c[:, 2] // ts) & 1) << 1) | (((c[:, 3] // ts) & 1) << 2)
+    out = np.full(c.shape[0] + 8 * (pad - 1), -1, np.int32)
+    pos = 0
+    for k in range(8):
+        rows = np.nonzero(cls == k)[0].astype(np.int32)
+        out[pos : pos + rows.size] = rows
+        pos += -(-rows.size // pad) * pad
+    return out
+
+
 # ----------------------------------------------------------------------------- brute force
 def unique_bruteforce(coords):
     seen, ui, inv = {}, [], []

@@ -361,12 +361,20 @@ class MinkowskiBatchNorm(nn.Module):
         return SparseTensor(self.bn(input.F), input.coordinate_map_key, input._manager)
 
 
+# Test hook: when set, MinkowskiReLU calls RELU_HOOK(z) instead of torch.relu(z).  The full-size parity test uses it to
+# evaluate the network with the branch decisions (z > 0) of the implementation under test imposed -- the gradient of a
+# ReLU network is only defined up to the branch taken where a pre-activation is zero to rounding, so two correct fp32
+# implementations may legitimately differ there (tests/test_gpu_parity_full.py).
+RELU_HOOK = None
+
+
 class MinkowskiReLU(nn.Module):
     def __init__(self, inplace=False):
         super().__init__()
 
     def forward(self, input):
-        return SparseTensor(torch.relu(input.F), input.coordinate_map_key, input._manager)
+        f = torch.relu(input.F) if RELU_HOOK is None else RELU_HOOK(input.F)
+        return SparseTensor(f, input.coordinate_map_key, input._manager)
 
 
 def _pointwise(name, fn, arg=None, default=None):

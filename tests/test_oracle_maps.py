@@ -106,3 +106,33 @@ def test_c_restatement_is_clean_under_asan_ubsan(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="4"))
     assert r.returncode == 0 and "sanitize_driver ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("negative", [False, True])
+def test_derived_maps_transpose_and_class_partition(oracle_maps, negative):
+    """The two derived structures the data gradient of a strided convolution reads (no ME counterpart): pinned by their
+    definitions, row by row, on a scene with negative coordinates as well (floor, not truncation, decides the parity)."""
+    c1 = _coords(5, negative=negative)
+    c2, _ = oracle_maps.stride_map(c1, 2)
+    nbr = oracle_maps.kernel_map_table(c1, c2, oracle_maps.kernel_offsets(3, 1))
+    nbr_t = oracle_maps.transpose_table(nbr, len(c1))
+    assert nbr_t.shape == (len(c1), 27)
+    pairs = {(int(nbr[o, k]), k): o for o in range(len(c2)) for k in range(27) if nbr[o, k] >= 0}
+    assert (nbr_t >= 0).sum() == len(pairs)
+    for (i, k), o in pairs.items():
+        assert nbr_t[i, k] == o
+    for ts, c in ((1, c1), (2, c2)):
+        pad = 16
+        perm = oracle_maps.class_partition(c, ts, pad)
+        assert perm.shape == (len(c) + 8 * (pad - 1),)
+        rows = perm[perm >= 0]
+        assert sorted(rows.tolist()) == list(range(len(c)))  # a permutation of the rows
+        cls = [(int(np.floor(r[1] / ts)) & 1) | ((int(np.floor(r[2] / ts)) & 1) << 1) | ((int(np.floor(r[3] / ts)) & 1) << 2) for r in c]
+        pos = 0
+        for k in range(8):
+            want = [i for i in range(len(c)) if cls[i] == k]  # input order kept inside a class
+            seg = perm[pos : pos + -(-len(want) // pad) * pad]
+            assert seg[: len(want)].tolist() == want and np.all(seg[len(want):] == -1)
+            assert pos % pad == 0
+            pos += len(seg)
+        assert np.all(perm[pos:] == -1)
