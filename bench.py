@@ -275,6 +275,10 @@ def main():
 
     _lib.lib()  # fail loudly if the HIP backend is missing
     Fn.set_conv_math(args.math)
+    if os.environ.get("BENCH_COMPUTE_STREAM", "0") != "0":
+        # compute on a stream of its own instead of the legacy default stream: a CU-subset stream
+        # (hipExtStreamCreateWithCUMask has no non-blocking flag) synchronises implicitly with the default stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
     torch.manual_seed(777)  # same initial weights on every rank (reference: pl.seed_everything)
     model = get_model(args.model, args.in_channel, args.num_classes).to(dev)

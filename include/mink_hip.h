@@ -260,6 +260,15 @@ int mink_conv_wgrad_bn_relu_pool(const float *x, int64_t n_in, int32_t ldx, int3
                                  const float *dgamma, const float *dbeta, const int32_t *nbr, int64_t n_out,
                                  int32_t K, float *dw, void *workspace, void *stream);
 
+/* Data gradient of a 1x1x1 convolution as a plain GEMM: y[n][N] = x[n][Kd] @ W^T with the FORWARD kernel W[N = cin][Kd = cout]
+ * (the `downsample` convolution of a residual block, models/mink/resnet.py:120-128), one fp32 MFMA accumulator chain per
+ * element, k ascending -- the same sum mink_conv_gather_gemm forms for a one-column table.  Kd a multiple of 4. */
+int mink_dense_xwt(const float *x, const float *w, int64_t n, int32_t Kd, int32_t N, float *y, void *stream);
+/* dst[idx[r]][0..C) += src[r][0..C) for every r < n_src with idx[r] >= 0; the idx values must be distinct (no atomics).
+ * With idx = the forward table of a kernel-volume-1 strided convolution this adds the shortcut's data gradient into the
+ * rows of the block-input gradient it reaches (about one in eight). */
+int mink_rows_scatter_add(const float *src, const int32_t *idx, int64_t n_src, int32_t C, float *dst, void *stream);
+
 /* ------------------------------------------------------------------ pooling / reductions
  * MinkowskiSumPooling(k=2,s=2) (resnet.py:62-64): out[o] = sum_k in[nbr[o][k]] with the
  * 2^3 children table; backward dIn[i] = dOut[in2out[i]].
@@ -501,6 +510,17 @@ int mink_stem_forward(const MinkStem *s, const MinkExec *ex);
 int mink_stem_backward(const MinkStem *s, const MinkExec *ex);
 int mink_block_forward(const MinkBasicBlock *b, const MinkExec *ex);
 int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex);
+
+/* ------------------------------------------------------------------ streams confined to a CU subset
+ * A HIP stream whose kernels may only run on compute units [first_cu, first_cu + n_cus) of the device's
+ * `total_cus` (hipExtStreamCreateWithCUMask; on a multi-XCD part consecutive mask bits go round the XCDs, so a
+ * contiguous range is spread evenly over them).  The training step keeps several streams busy at once -- the
+ * data-gradient chain, the weight gradients beside it, the next batch's coordinate maps (ME builds those on the
+ * stream it computes on: models/mink/resnet.py:164 -> CoordinateMapManager) -- and an auxiliary stream that may
+ * take every CU slows the kernels of the chain it runs beside; confined to a few CUs it still finishes in the
+ * shadow of the chain.  The caller owns the stream. */
+int mink_stream_create_cu_subset(int32_t first_cu, int32_t n_cus, int32_t total_cus, void **stream_out);
+int mink_stream_destroy(void *stream);
 
 /* ------------------------------------------------------------------ kernel timing (measurement only)
  * bench.py reports the roofline of the dominant convolution kernel from HIP events recorded on the stream each

@@ -111,6 +111,8 @@ SIGNATURES = {
         ctypes.c_int,
         [_p, _i64, _i32, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p],
     ),
+    "mink_dense_xwt": (ctypes.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
+    "mink_rows_scatter_add": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
     "mink_pool_sum_fwd": (ctypes.c_int, [_p, _i32, _i32, _p, _i64, _i32, _p, _p]),
     "mink_pool_sum_bwd": (ctypes.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "mink_pool_max_fwd": (ctypes.c_int, [_p, _i32, _p, _i64, _i32, _p, _p, _p]),
@@ -137,6 +139,8 @@ SIGNATURES = {
     "mink_stem_backward": (ctypes.c_int, [_p, _p]),
     "mink_block_forward": (ctypes.c_int, [_p, _p]),
     "mink_block_backward": (ctypes.c_int, [_p, _p]),
+    "mink_stream_create_cu_subset": (ctypes.c_int, [_i32, _i32, _i32, _p]),
+    "mink_stream_destroy": (ctypes.c_int, [_p]),
     "mink_conv_timing": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "mink_conv_timing_fetch": (_i64, [_p, _i64]),
 }

@@ -38,7 +38,7 @@ class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
             import torch
 
             if self._side is None:
-                self._side = torch.cuda.Stream()
+                self._side = self._new_prepare_stream(torch.device("cuda", torch.cuda.current_device()))
             self._side.wait_event(gate)
         if "links" in batch:  # compact PeRFception batch: de-quantise + links -> coordinates on the device
             with self._prepare_stream_ctx(batch["links"], fence=batch.get("h2d_event", True)):
@@ -92,12 +92,18 @@ class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
         if not (self.prepare_ahead and t.is_cuda):
             return contextlib.nullcontext()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=t.device)
+            self._side = self._new_prepare_stream(t.device)
         if fence is True:
             self._side.wait_stream(torch.cuda.current_stream(t.device))
         elif fence:
             self._side.wait_event(fence)
         return torch.cuda.stream(self._side)
+
+    def _new_prepare_stream(self, device):
+        new_stream = getattr(getattr(self._ME, "functional", None), "new_stream", None)
+        import torch
+
+        return new_stream(device, "prepare") if new_stream is not None else torch.cuda.Stream(device=device)
 
     @staticmethod
     def finish_input(field):

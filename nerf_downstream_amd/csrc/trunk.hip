@@ -79,9 +79,10 @@ struct Lane {  // a stream and what is left of its scratch buffer
 };
 
 // gy (complete on data.st) -> dW on weight.st, dX (optional) on data.st
+// (ev_slot < 0: the caller has already ordered weight.st after gy)
 int conv_backward(const MinkConvLayer &c, const float *x, int64_t n_in, int64_t n_out, const float *gy, float *gx, Lane data,
                   Lane weight, int ev_slot) {
-  TRY(order_after(weight.st, data.st, ev_slot));
+  if (ev_slot >= 0) TRY(order_after(weight.st, data.st, ev_slot));
   {
     Scratch ws(weight.ws, weight.bytes);
     const int64_t need = mink_conv_wgrad_workspace_bytes(n_out, c.K, c.cin, c.cout);
@@ -127,6 +128,22 @@ int check_norm(const MinkNormLayer &n, const char *what, bool backward) {
 using namespace mink;
 
 extern "C" {
+
+int mink_stream_create_cu_subset(int32_t first_cu, int32_t n_cus, int32_t total_cus, void **stream_out) {
+  MINK_REQUIRE(stream_out && total_cus >= 1 && total_cus <= 1024 && first_cu >= 0 && n_cus >= 1 && first_cu + n_cus <= total_cus,
+               "stream_create_cu_subset: bad compute-unit range %d + %d of %d", first_cu, n_cus, total_cus);
+  uint32_t mask[32] = {0};
+  for (int i = first_cu; i < first_cu + n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t st = nullptr;
+  MINK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)((total_cus + 31) / 32), mask));
+  *stream_out = (void *)st;
+  return MINK_OK;
+}
+
+int mink_stream_destroy(void *stream) {
+  if (stream) MINK_HIP(hipStreamDestroy((hipStream_t)stream));
+  return MINK_OK;
+}
 
 int64_t mink_block_workspace_bytes(int64_t n_in, int64_t n_out, int32_t cin, int32_t cout) {
   // generous upper bound of what any single operator of the block carves from one stream's scratch:
@@ -238,31 +255,45 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
   // out = relu(norm2(y2) + shortcut)
   TRY(mink_bn_bwd(b->g_out, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, 1, g_y2, g_res,
                   b->norm2.dgamma, b->norm2.dbeta, compute.ws, st));
-  if (down) {  // shortcut branch beside the main one: its norm and its weight gradient
+  // ONE event on the compute stream hands g_y2 / g_res to both auxiliary streams (every event record or wait on the
+  // compute stream is a barrier packet in the chain of small dependent kernels)
+  const bool aux = wst != st || (down && br != st);
+  if (aux) MINK_HIP(hipEventRecord(g_ev[2], st));
+  if (wst != st) MINK_HIP(hipStreamWaitEvent(wst, g_ev[2], 0));
+  float *g_sc = nullptr;  // [n_out][cin]: the shortcut's data gradient per OUTPUT row (dense), scattered into g_x at the end
+  if (down) {  // shortcut branch beside the main one: its norm, its weight gradient, its data gradient
     TRY(check_conv(b->down, "block_backward downsample", true));
     TRY(check_norm(b->normd, "block_backward downsample norm", true));
     MINK_REQUIRE(b->yd && branch.ws, "block_backward: bad downsample path");
-    TRY(order_after(br, st, 2));  // g_res is ready
+    MINK_REQUIRE(b->down.K == 1, "block_backward: the shortcut convolution must have kernel volume 1");
+    if (br != st) MINK_HIP(hipStreamWaitEvent(br, g_ev[2], 0));
     // (on one stream the branch shares the compute scratch: its batch-norm partials sit behind the main chain's)
     const Lane bl = br == st ? branch.after(bn_bytes) : branch;
     TRY(mink_bn_bwd(g_res, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
                     b->normd.dgamma, b->normd.dbeta, bl.ws, br));
-    TRY(conv_backward(b->down, b->x, b->n_in, b->n_out, g_yd, nullptr, bl.after(bn_bytes), weight, 3));
+    Lane rest_b = bl.after(bn_bytes);
+    if (want_gx) {
+      // The shortcut convolution (kernel volume 1, stride 2) reaches only the input voxels that sit on an output
+      // coordinate -- about one row in eight.  Its data gradient is a plain GEMM over the OUTPUT rows, computed here
+      // beside the main branch; what is left on the compute stream is adding those rows into g_x (below).
+      Scratch ws(rest_b.ws, rest_b.bytes);
+      g_sc = (float *)ws.take(4ll * b->n_out * cin);
+      MINK_REQUIRE(g_sc, "block_backward: scratch too small for the shortcut's data gradient");
+      TRY(mink_dense_xwt(g_yd, b->down.w, b->n_out, C, cin, g_sc, br));
+      rest_b = rest_b.after(4ll * b->n_out * cin);
+      if (br != st) MINK_HIP(hipEventRecord(g_ev[6], br));
+    }
+    TRY(conv_backward(b->down, b->x, b->n_in, b->n_out, g_yd, nullptr, rest_b, weight, br == wst ? -1 : 3));
   }
   const Lane rest = compute.after(2 * bn_bytes);
-  TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, 4));
+  TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, -1));
   TRY(mink_bn_bwd(g_h1, b->y1, b->h1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr,
                   b->norm1.dgamma, b->norm1.dbeta, compute.ws, st));
   TRY(conv_backward(b->conv1, b->x, b->n_in, b->n_out, g_y1, want_gx ? (down ? b->g_x : g_xa) : nullptr, rest, weight, 5));
   if (!want_gx) return MINK_OK;
   if (!down) return mink_eltwise(g_xa, g_res, ni, 2, b->g_x, st);
-  // The shortcut convolution (kernel volume 1, stride 2) reaches only the input voxels that sit on an output
-  // coordinate -- about one row in eight.  Its data gradient is ADDED into those rows of g_x: tile row v = output row
-  // o, written row = the input row under it (the forward table's only column), gathered operand = g_yd[o].
-  MINK_REQUIRE(b->down.K == 1 && b->down.nbr_t, "block_backward: the shortcut convolution must have kernel volume 1");
-  TRY(order_after(st, br, 6));
-  return mink_conv_gather_gemm(g_yd, C, C, b->down.w, 1, /*accumulate*/ 2, b->down.nbr_t, b->n_in, 1, b->down.nbr, b->n_out, b->g_x,
-                               cin, cin, nullptr, 1, nullptr, st);
+  if (br != st) MINK_HIP(hipStreamWaitEvent(st, g_ev[6], 0));
+  return mink_rows_scatter_add(g_sc, b->down.nbr, b->n_out, cin, b->g_x, st);
 }
 
 }  // extern "C"

@@ -234,12 +234,34 @@ def _plan_ksplit(L, n_rows, K, cin, cout, classes):
 
 _OVERLAP_WGRAD = True  # weight gradients on a side stream, joined at the end of backward (B=16 ResNet14: 5.11 -> 4.84 ms/step)
 _SIDE_STREAMS = {}
+_CU_STREAMS = []  # (raw handle) of the CU-subset streams created here: they live as long as the process
+
+
+def new_stream(device, role):
+    """A HIP stream for one of the auxiliary roles ("prepare": the next batch's coordinate maps, "wgrad": the weight
+    gradients, "branch": the shortcut branch).  MINK_CUS_<ROLE>="first:count" (or "count") confines it to that range
+    of compute units (mink_stream_create_cu_subset): what runs on it then cannot take execution slots from the
+    kernels of the compute stream on the other CUs."""
+    spec = os.environ.get("MINK_CUS_" + role.upper(), _CU_DEFAULTS.get(role, ""))
+    if not spec or spec == "0":
+        return torch.cuda.Stream(device=device)
+    first, _, count = spec.rpartition(":")
+    total = torch.cuda.get_device_properties(device).multi_processor_count
+    first, count = int(first or 0), int(count)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        check(lib().mink_stream_create_cu_subset(first, count, total, ctypes.byref(h)))
+    _CU_STREAMS.append(h.value)
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
+_CU_DEFAULTS = {}
 
 
 def _side_stream(device):
     s = _SIDE_STREAMS.get(device.index)
     if s is None:
-        s = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        s = _SIDE_STREAMS[device.index] = new_stream(device, "wgrad")
     return s
 
 
@@ -363,7 +385,7 @@ def branch_stream(device, home=None):
     not fill the chip on their own).  `home`: the stream the caller forks from."""
     s = _BRANCH_STREAMS.get(device.index)
     if s is None:
-        s = _BRANCH_STREAMS[device.index] = torch.cuda.Stream(device=device)
+        s = _BRANCH_STREAMS[device.index] = new_stream(device, "branch")
         quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
         if quiet is not None:  # parameters of the branch get their gradient from this stream on purpose
             quiet(False)
