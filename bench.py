@@ -292,6 +292,8 @@ def main():
     batches = make_batches(2, args.batch, rank, args.num_classes, args.grid, args.in_channel)
     batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
     vox_per_step = [int(b["coordinates"].shape[0]) for b in batches]
+    labels_dev = [b["labels"].long() for b in batches]
+    from nerf_downstream_amd.co3d_3d.src.modules.classification_training import cross_entropy
 
     if "BENCH_WGRAD_OVERLAP" in os.environ:
         Fn.set_wgrad_overlap(os.environ["BENCH_WGRAD_OVERLAP"] != "0")
@@ -323,7 +325,7 @@ def main():
             Fn.log_phase("pyramid_begin", side)
             nxt = model.process_input(batches[(i + 1) % len(batches)], defer=True, gate=Fn.phase_event("stem_forward"))
             Fn.log_phase("pyramid_end", side)
-        loss = F.cross_entropy(out, batches[i % len(batches)]["labels"].long())
+        loss = cross_entropy(out, labels_dev[i % len(batches)])  # the trainer's own loss call (classification_training.py)
         loss.backward()
         Fn.log_phase("backward_queued", torch.cuda.current_stream())
         Fn.log_phase("maps_begin", side)

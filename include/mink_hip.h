@@ -285,6 +285,22 @@ int mink_global_avg_fwd(const float *x, int32_t C, const int32_t *batch_offsets,
 int mink_global_avg_bwd(const float *dy, int32_t C, const int32_t *batch_offsets, int32_t B, int64_t n,
                         float *dx, void *stream);
 
+/* Classifier head in one launch each way: logits[b] = mean_{rows of batch b} x[row] @ W + bias, i.e.
+ * MinkowskiGlobalAvgPooling followed by the kernel-volume-1 `final` convolution with bias (models/mink/resnet.py:15-22,
+ * 93-99,175-177; W is ME's (Cin, Cout) kernel of a `use_mm` convolution, bias (1, Cout) or NULL).  pooled[B][C] is an
+ * output the backward pass reads.  Backward: dx[n][C] (may be NULL), dw[C][ncls], dbias[ncls] (may be NULL). */
+int mink_head_forward(const float *x, const int32_t *batch_offsets, int32_t B, int32_t C, const float *w, const float *bias,
+                      int32_t ncls, float *pooled, float *logits, void *stream);
+int mink_head_backward(const float *dlogits, const float *pooled, const float *w, const int32_t *batch_offsets, int32_t B,
+                       int32_t C, int32_t ncls, float *dw, float *dbias, float *dx, void *stream);
+/* torch.nn.functional.cross_entropy(logits, labels) with its defaults (mean over the batch; reference
+ * modules/classification_training.py:33) as one launch each way.  labels: int64 [B]; prob[B][ncls] (softmax) is kept for
+ * backward; *loss a device scalar; a label outside [0, ncls) makes the loss NaN.  grad_loss: device scalar. */
+int mink_softmax_ce_forward(const float *logits, const int64_t *labels, int32_t B, int32_t ncls, float *prob, float *loss,
+                            void *stream);
+int mink_softmax_ce_backward(const float *prob, const int64_t *labels, const float *grad_loss, int32_t B, int32_t ncls,
+                             float *dlogits, void *stream);
+
 /* TensorField.sparse() feature averaging (ME UNWEIGHTED_AVERAGE, resnet.py:164):
  * y[u] = mean_{j in [seg[u],seg[u+1])} x[members[j]] (members sorted by input row). */
 int mink_segment_mean(const float *x, int32_t ldx, int32_t C, const int32_t *members, const int32_t *seg,

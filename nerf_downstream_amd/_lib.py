@@ -119,6 +119,10 @@ SIGNATURES = {
     "mink_pool_max_bwd": (ctypes.c_int, [_p, _p, _i32, _p, _i64, _i32, _p, _p]),
     "mink_global_avg_fwd": (ctypes.c_int, [_p, _i32, _p, _i32, _p, _p]),
     "mink_global_avg_bwd": (ctypes.c_int, [_p, _i32, _p, _i32, _i64, _p, _p]),
+    "mink_head_forward": (ctypes.c_int, [_p, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p]),
+    "mink_head_backward": (ctypes.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p]),
+    "mink_softmax_ce_forward": (ctypes.c_int, [_p, _p, _i32, _i32, _p, _p, _p]),
+    "mink_softmax_ce_backward": (ctypes.c_int, [_p, _p, _p, _i32, _i32, _p, _p]),
     "mink_segment_mean": (ctypes.c_int, [_p, _i32, _i32, _p, _p, _i64, _p, _p]),
     "mink_bn_workspace_bytes": (_i64, [_i64, _i32]),
     "mink_bn_stats": (ctypes.c_int, [_p, _i64, _i32, _f32, _f32, _p, _p, _p, _p, _p, _p]),

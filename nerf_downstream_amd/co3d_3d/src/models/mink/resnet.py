@@ -106,7 +106,7 @@ class ResNetBase(MinkowskiBaseModel):
                 fork = getattr(self.layer1[0], "_fork", False) and trunk.Fn.branch_fork_enabled()
                 feats = trunk.TrunkFunction.apply(xs.F, self._trunk_plan, xs.coordinate_manager, fork, *self._trunk_plan.params)
                 out = self._ME.SparseTensor(feats, trunk.out_key_of(self._trunk_plan), xs.coordinate_manager)
-                return self.final(self.glob_avg(out)).F
+                return self._head(out)
             x = _Presparsed(xs)
         if self._fused:  # bn1 -> relu -> pool in one pass over the finest-level activation; its
             # statistics come out of the stem convolution's epilogue (no extra pass over 825 k x 64)
@@ -116,6 +116,15 @@ class ResNetBase(MinkowskiBaseModel):
         else:
             out = self.pool(self.relu(self.bn1(self.conv1(x.sparse()))))
         out = self.layer4(self.layer3(self.layer2(self.layer1(out))))
+        return self._head(out)
+
+    def _head(self, out):
+        """glob_avg -> final -> .F (reference resnet.py:175-177).  HIP backend: one launch each way instead of the
+        pooling kernel + library GEMM + bias add (and five launches backward) on the latency-bound end of the chain."""
+        fin = self.final
+        if self._fused and out.F.is_cuda and getattr(fin, "use_mm", False) and out.F.dtype == torch.float32:
+            m = out.coordinate_manager
+            return self._ME.functional.global_avg_linear(out.F, m.batch_offsets(out.coordinate_map_key), fin.kernel, fin.bias)
         return self.final(self.glob_avg(out)).F
 
 

@@ -7,6 +7,15 @@ import torch
 import torch.nn.functional as F
 
 
+def cross_entropy(logits, labels):
+    """F.cross_entropy(logits, labels) (reference :33); device logits take the backend's one-launch kernels."""
+    if logits.is_cuda:
+        from nerf_downstream_amd.minkowski.functional import cross_entropy as hip_ce
+
+        return hip_ce(logits, labels)
+    return F.cross_entropy(logits, labels)
+
+
 @torch.no_grad()
 def accuracy(output, target, topk=(1,)):
     """Percent of samples whose label is among the k highest logits (reference :83-97)."""
@@ -29,7 +38,7 @@ class ClassificationTraining:
     def training_step(self, batch, field=None):
         out = self.forward(field if field is not None else batch)
         labels = batch["labels"].long()
-        return F.cross_entropy(out, labels), out
+        return cross_entropy(out, labels), out
 
     @staticmethod
     def check_finite(loss_float):
@@ -40,7 +49,7 @@ class ClassificationTraining:
     def validation_step(self, batch):
         logits = self.forward(batch)
         labels = batch["labels"].long()
-        loss = F.cross_entropy(logits, labels)
+        loss = cross_entropy(logits, labels)
         top = logits.topk(min(5, logits.shape[1]), 1).indices
         c1 = (top[:, 0] == labels).sum()
         c5 = (top == labels[:, None]).any(1).sum()

@@ -74,6 +74,150 @@ __global__ __launch_bounds__(256) void rows_scatter_add_kernel(const float *__re
   }
 }
 
+
+// ---------------------------------------------------------------------------------- classifier head
+// logits[b] = mean_{rows of batch b} x[row] @ W + bias  -- MinkowskiGlobalAvgPooling followed by the kernel-volume-1
+// `final` convolution (reference models/mink/resnet.py:15-22,93-99,175-177) in ONE launch; one workgroup per batch
+// element.  pooled[B][C] is kept for the backward pass.  Fixed summation orders (rows ascending per row lane, lanes
+// ascending; channels ascending per quarter, quarters ascending): bitwise reproducible.
+constexpr int HB = 256;
+
+__global__ __launch_bounds__(HB) void head_fwd_kernel(const float *__restrict__ x, const int *__restrict__ boff,
+                                                      const float *__restrict__ w, const float *__restrict__ bias,
+                                                      float *__restrict__ pooled, float *__restrict__ logits, int C,
+                                                      int ncls) {
+  extern __shared__ float sh[];  // [rlanes][C] partial column sums, then [C] pooled + [4][ncls] partial logits
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int r0 = boff[b], r1 = boff[b + 1];
+  const float inv = r1 > r0 ? 1.f / (float)(r1 - r0) : 0.f;
+  const int C4 = C >> 2;
+  const int rlanes = C4 >= HB ? 1 : HB / C4;
+  for (int c4 = t % C4; c4 < C4; c4 += HB) {  // (one trip unless C > 1024)
+    const int rl = C4 >= HB ? 0 : t / C4;
+    if (rl < rlanes) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int r = r0 + rl; r < r1; r += rlanes) {
+        const float4 v = ld4g(x + (int64_t)r * C + 4 * c4);
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+      }
+      float *d = sh + (int64_t)rl * C + 4 * c4;
+      d[0] = s.x, d[1] = s.y, d[2] = s.z, d[3] = s.w;
+    }
+  }
+  __syncthreads();
+  float *sp = sh + (int64_t)rlanes * C;  // pooled row
+  for (int c = t; c < C; c += HB) {
+    float s = 0.f;
+    for (int rl = 0; rl < rlanes; ++rl) s += sh[(int64_t)rl * C + c];
+    s *= inv;
+    sp[c] = s;
+    pooled[(int64_t)b * C + c] = s;
+  }
+  __syncthreads();
+  float *sl = sp + C;  // [4][ncls]
+  const int part = t >> 6, lane = t & 63, cq = (C + 3) / 4;
+  for (int j = lane; j < ncls; j += 64) {
+    float s = 0.f;
+    const int c1 = min(C, (part + 1) * cq);
+    for (int c = part * cq; c < c1; ++c) s = fmaf(sp[c], w[(int64_t)c * ncls + j], s);
+    sl[part * ncls + j] = s;
+  }
+  __syncthreads();
+  for (int j = t; j < ncls; j += HB)
+    logits[(int64_t)b * ncls + j] = ((sl[j] + sl[ncls + j]) + sl[2 * ncls + j]) + sl[3 * ncls + j] + (bias ? bias[j] : 0.f);
+}
+
+// Backward of the above in one launch.  Workgroups [0, B): dx[row] = (1 / N_b) * dl[b] @ W^T for every row of batch b.
+// Workgroups [B, B + ceil(C / 8)): dW[c][j] = sum_b pooled[b][c] dl[b][j] for eight channels each; the first of them
+// also db[j] = sum_b dl[b][j].  b ascending everywhere.
+__global__ __launch_bounds__(HB) void head_bwd_kernel(const float *__restrict__ dl, const float *__restrict__ pooled,
+                                                      const float *__restrict__ w, const int *__restrict__ boff,
+                                                      float *__restrict__ dw, float *__restrict__ db,
+                                                      float *__restrict__ dx, int B, int C, int ncls) {
+  extern __shared__ float sh[];
+  const int t = threadIdx.x;
+  if ((int)blockIdx.x < B) {
+    if (!dx) return;
+    const int b = blockIdx.x;
+    const int r0 = boff[b], r1 = boff[b + 1];
+    const float inv = r1 > r0 ? 1.f / (float)(r1 - r0) : 0.f;
+    float *sd = sh;       // dl[b][:]
+    float *sg = sh + ncls;  // dpooled[b][:] * inv
+    for (int j = t; j < ncls; j += HB) sd[j] = dl[(int64_t)b * ncls + j];
+    __syncthreads();
+    for (int c = t; c < C; c += HB) {
+      float s = 0.f;
+      for (int j = 0; j < ncls; ++j) s = fmaf(sd[j], w[(int64_t)c * ncls + j], s);
+      sg[c] = s * inv;
+    }
+    __syncthreads();
+    const int C4 = C >> 2;
+    for (int64_t i = t; i < (int64_t)(r1 - r0) * C4; i += HB) {
+      const int64_t r = r0 + i / C4;
+      const int c = (int)(i % C4) * 4;
+      *reinterpret_cast<float4 *>(dx + r * C + c) = make_float4(sg[c], sg[c + 1], sg[c + 2], sg[c + 3]);
+    }
+    return;
+  }
+  const int c0 = ((int)blockIdx.x - B) * 8;
+  for (int e = t; e < 8 * ncls; e += HB) {
+    const int c = c0 + e / ncls, j = e % ncls;
+    if (c >= C) break;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(pooled[(int64_t)b * C + c], dl[(int64_t)b * ncls + j], s);
+    dw[(int64_t)c * ncls + j] = s;
+  }
+  if (c0 == 0 && db) {
+    for (int j = t; j < ncls; j += HB) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += dl[(int64_t)b * ncls + j];
+      db[j] = s;
+    }
+  }
+}
+
+// loss = mean_b ( logsumexp(logits[b]) - logits[b][label_b] )  (torch.nn.functional.cross_entropy with its defaults,
+// reference modules/classification_training.py:33); prob[B][ncls] = softmax, kept for the backward pass.  One workgroup,
+// a wave per row (rows wave, wave + 4, ...); a label outside [0, ncls) makes the loss NaN (torch raises a device assert).
+__global__ __launch_bounds__(HB) void ce_fwd_kernel(const float *__restrict__ logits, const long long *__restrict__ labels,
+                                                    int B, int ncls, float *__restrict__ prob, float *__restrict__ loss) {
+  extern __shared__ float sh[];  // [B] row losses
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int b = wave; b < B; b += HB / 64) {
+    const float *row = logits + (int64_t)b * ncls;
+    float mx = -INFINITY;
+    for (int j = lane; j < ncls; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float se = 0.f;
+    for (int j = lane; j < ncls; j += 64) se += expf(row[j] - mx);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) se += __shfl_xor(se, o, 64);
+    const float inv = 1.f / se;
+    for (int j = lane; j < ncls; j += 64) prob[(int64_t)b * ncls + j] = expf(row[j] - mx) * inv;
+    if (lane == 0) {
+      const long long y = labels[b];
+      sh[b] = (y >= 0 && y < ncls) ? (logf(se) + mx) - row[y] : NAN;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += sh[b];
+    *loss = s / (float)B;
+  }
+}
+
+// dlogits[b][j] = g * (prob[b][j] - [j == label_b]) / B,  g = the incoming gradient of the loss (a device scalar)
+__global__ __launch_bounds__(HB) void ce_bwd_kernel(const float *__restrict__ prob, const long long *__restrict__ labels,
+                                                    const float *__restrict__ g, int B, int ncls, float *__restrict__ dl) {
+  const float s = *g / (float)B;
+  for (int i = blockIdx.x * HB + threadIdx.x; i < B * ncls; i += gridDim.x * HB) {
+    const int b = i / ncls, j = i - b * ncls;
+    dl[i] = s * (prob[i] - (labels[b] == (long long)j ? 1.f : 0.f));
+  }
+}
+
 }  // namespace mink
 
 using namespace mink;
@@ -96,6 +240,48 @@ int mink_rows_scatter_add(const float *src, const int32_t *idx, int64_t n_src, i
   const int64_t work = n_src * (C >> 2);
   const unsigned grid = (unsigned)std::min<int64_t>(cdiv(work, 256), 8192);
   rows_scatter_add_kernel<<<dim3(grid), 256, 0, (hipStream_t)stream>>>(src, idx, dst, n_src, C >> 2);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+
+int mink_head_forward(const float *x, const int32_t *batch_offsets, int32_t B, int32_t C, const float *w, const float *bias,
+                      int32_t ncls, float *pooled, float *logits, void *stream) {
+  MINK_REQUIRE(B >= 1 && C >= 4 && (C & 3) == 0 && ncls >= 1, "head_forward: bad shape (B=%d, C=%d, classes=%d)", B, C, ncls);
+  MINK_REQUIRE(x && batch_offsets && w && pooled && logits && ((uintptr_t)x & 15) == 0, "head_forward: NULL or misaligned pointer");
+  const int C4 = C >> 2, rlanes = C4 >= HB ? 1 : HB / C4;
+  const size_t shm = sizeof(float) * ((size_t)rlanes * C + C + 4 * (size_t)ncls);
+  MINK_REQUIRE(shm <= 64 * 1024, "head_forward: %d channels x %d classes do not fit the workgroup's LDS", C, ncls);
+  head_fwd_kernel<<<dim3((unsigned)B), HB, shm, (hipStream_t)stream>>>(x, batch_offsets, w, bias, pooled, logits, C, ncls);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_head_backward(const float *dlogits, const float *pooled, const float *w, const int32_t *batch_offsets, int32_t B,
+                       int32_t C, int32_t ncls, float *dw, float *dbias, float *dx, void *stream) {
+  MINK_REQUIRE(B >= 1 && C >= 4 && (C & 3) == 0 && ncls >= 1, "head_backward: bad shape");
+  MINK_REQUIRE(dlogits && pooled && w && batch_offsets && dw && (((uintptr_t)dx) & 15) == 0, "head_backward: NULL or misaligned pointer");
+  const size_t shm = sizeof(float) * ((size_t)ncls + C);
+  MINK_REQUIRE(shm <= 64 * 1024, "head_backward: %d channels x %d classes do not fit the workgroup's LDS", C, ncls);
+  head_bwd_kernel<<<dim3((unsigned)(B + cdiv(C, 8))), HB, shm, (hipStream_t)stream>>>(dlogits, pooled, w, batch_offsets, dw, dbias,
+                                                                                      dx, B, C, ncls);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_softmax_ce_forward(const float *logits, const int64_t *labels, int32_t B, int32_t ncls, float *prob, float *loss,
+                            void *stream) {
+  MINK_REQUIRE(B >= 1 && B <= 8192 && ncls >= 1 && logits && labels && prob && loss, "softmax_ce_forward: bad arguments");
+  ce_fwd_kernel<<<dim3(1), HB, sizeof(float) * B, (hipStream_t)stream>>>(logits, (const long long *)labels, B, ncls, prob, loss);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_softmax_ce_backward(const float *prob, const int64_t *labels, const float *grad_loss, int32_t B, int32_t ncls,
+                             float *dlogits, void *stream) {
+  MINK_REQUIRE(B >= 1 && ncls >= 1 && prob && labels && grad_loss && dlogits, "softmax_ce_backward: bad arguments");
+  const unsigned grid = (unsigned)std::min<int64_t>(cdiv((int64_t)B * ncls, HB), 1024);
+  ce_bwd_kernel<<<dim3(grid), HB, 0, (hipStream_t)stream>>>(prob, (const long long *)labels, grad_loss, B, ncls, dlogits);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

@@ -161,8 +161,9 @@ int64_t mink_block_workspace_bytes(int64_t n_in, int64_t n_out, int32_t cin, int
 }
 
 int64_t mink_block_grad_scratch_floats(int64_t n_in, int64_t n_out, int32_t cin, int32_t cout, int32_t has_down) {
-  // g_y2, g_res, g_h1, g_y1 [n_out][cout]; identity shortcut: g_xa [n_in][cin]; with a down path: g_yd [n_out][cout]
-  return (4 + (has_down ? 1 : 0)) * n_out * cout + (has_down ? 0 : 1) * n_in * cin + 64;
+  // g_y2, g_res, g_h1, g_y1 [n_out][cout]; identity shortcut: g_xa [n_in][cin]; with a down path: g_yd [n_out][cout] and
+  // g_sc [n_out][cin] (the shortcut's data gradient per output row)
+  return (4 + (has_down ? 1 : 0)) * n_out * cout + (has_down ? n_out : n_in) * cin + 64;
 }
 
 int mink_stem_supported(int64_t n, int32_t cin, int32_t cout, int32_t K) {
@@ -271,16 +272,13 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
     const Lane bl = br == st ? branch.after(bn_bytes) : branch;
     TRY(mink_bn_bwd(g_res, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
                     b->normd.dgamma, b->normd.dbeta, bl.ws, br));
-    Lane rest_b = bl.after(bn_bytes);
+    const Lane rest_b = bl.after(bn_bytes);
     if (want_gx) {
       // The shortcut convolution (kernel volume 1, stride 2) reaches only the input voxels that sit on an output
       // coordinate -- about one row in eight.  Its data gradient is a plain GEMM over the OUTPUT rows, computed here
       // beside the main branch; what is left on the compute stream is adding those rows into g_x (below).
-      Scratch ws(rest_b.ws, rest_b.bytes);
-      g_sc = (float *)ws.take(4ll * b->n_out * cin);
-      MINK_REQUIRE(g_sc, "block_backward: scratch too small for the shortcut's data gradient");
+      g_sc = g_yd + no;  // (in the caller's gradient scratch: stream scratch is recycled by the launches that follow)
       TRY(mink_dense_xwt(g_yd, b->down.w, b->n_out, C, cin, g_sc, br));
-      rest_b = rest_b.after(4ll * b->n_out * cin);
       if (br != st) MINK_HIP(hipEventRecord(g_ev[6], br));
     }
     TRY(conv_backward(b->down, b->x, b->n_in, b->n_out, g_yd, nullptr, rest_b, weight, br == wst ? -1 : 3));

@@ -1001,3 +1001,71 @@ def segment_mean(x, members, seg, n_out):
         lib().mink_segment_mean(x.data_ptr(), x.stride(0), x.shape[1], members.data_ptr(), seg.data_ptr(), n_out, y.data_ptr(), _stream())
     )
     return y
+
+
+# ----------------------------------------------------------------------- classifier head
+class GlobalAvgLinearFunction(torch.autograd.Function):
+    """logits = MinkowskiGlobalAvgPooling(x) @ kernel + bias in one launch each way (mink_head_forward/backward):
+    the tail of the reference network, `self.final(self.glob_avg(out))` (models/mink/resnet.py:175-177)."""
+
+    @staticmethod
+    def forward(ctx, x, boff, kernel, bias):
+        x = _f32c(x)
+        B, C, ncls = boff.numel() - 1, x.shape[1], kernel.shape[1]
+        pooled = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        logits = torch.empty(B, ncls, dtype=torch.float32, device=x.device)
+        w = kernel.contiguous()
+        check(lib().mink_head_forward(x.data_ptr(), boff.data_ptr(), B, C, w.data_ptr(), _ptr(bias), ncls, pooled.data_ptr(),
+                                      logits.data_ptr(), _stream()))
+        ctx.save_for_backward(pooled, w, boff)
+        ctx.n, ctx.has_bias, ctx.bias_shape = x.shape[0], bias is not None, None if bias is None else bias.shape
+        return logits
+
+    @staticmethod
+    def backward(ctx, gl):
+        pooled, w, boff = ctx.saved_tensors
+        gl = _f32c(gl)
+        B, C = pooled.shape
+        ncls = w.shape[1]
+        gx = torch.empty(ctx.n, C, dtype=torch.float32, device=gl.device) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(ctx.bias_shape, dtype=torch.float32, device=gl.device) if ctx.has_bias else None
+        check(lib().mink_head_backward(gl.data_ptr(), pooled.data_ptr(), w.data_ptr(), boff.data_ptr(), B, C, ncls, gw.data_ptr(),
+                                       _ptr(gb), _ptr(gx), _stream()))
+        return gx, None, gw, gb
+
+
+def global_avg_linear(x, batch_offsets, kernel, bias=None):
+    return GlobalAvgLinearFunction.apply(x, batch_offsets, kernel, bias)
+
+
+class SoftmaxCrossEntropyFunction(torch.autograd.Function):
+    """F.cross_entropy(logits, labels) with its defaults (mean over the batch) as one launch each way."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = _f32c(logits)
+        labels = labels.contiguous()
+        assert labels.dtype == torch.int64 and labels.shape == (logits.shape[0],), "labels: int64 [B]"
+        B, ncls = logits.shape
+        prob = torch.empty_like(logits)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        check(lib().mink_softmax_ce_forward(logits.data_ptr(), labels.data_ptr(), B, ncls, prob.data_ptr(), loss.data_ptr(), _stream()))
+        ctx.save_for_backward(prob, labels)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        prob, labels = ctx.saved_tensors
+        g = _f32c(g)
+        dl = torch.empty_like(prob)
+        check(lib().mink_softmax_ce_backward(prob.data_ptr(), labels.data_ptr(), g.data_ptr(), prob.shape[0], prob.shape[1],
+                                             dl.data_ptr(), _stream()))
+        return dl, None
+
+
+def cross_entropy(logits, labels):
+    """Mean softmax cross-entropy; HIP kernels for device logits, torch otherwise (CPU oracle runs of the same trainer)."""
+    if logits.is_cuda and logits.dim() == 2 and labels.dim() == 1:
+        return SoftmaxCrossEntropyFunction.apply(logits, labels)
+    return torch.nn.functional.cross_entropy(logits, labels)

@@ -589,3 +589,79 @@ def test_row_compacted_kernel_over_permuted_rows_against_float64(n_out, K, cin, 
     finally:
         Fn._FORCE_KSPLIT = 0
         L.mink_conv_set_stagger(0)
+
+
+@pytest.mark.parametrize("B,C,ncls,rows", [(16, 512, 51, 33), (3, 2048, 40, 5), (5, 64, 7, 1), (2, 96, 130, 40)])
+def test_classifier_head_matches_torch(B, C, ncls, rows):
+    """mink_head_forward/backward (global average pooling + the kernel-volume-1 `final` convolution with bias, reference
+    resnet.py:175-177) and mink_softmax_ce_* (F.cross_entropy, classification_training.py:33) against float64 torch,
+    including an EMPTY batch element (zero rows -> pooled 0, logits = bias) and ragged row counts."""
+    import torch.nn.functional as F
+
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(B * 1000 + C + ncls)
+    counts = torch.randint(1, 2 * rows + 1, (B,), generator=g)
+    if B > 2:
+        counts[1] = 0
+    boff = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]).to(torch.int32)
+    n = int(boff[-1])
+    x = torch.randn(n, C, generator=g)
+    w = torch.randn(C, ncls, generator=g) * 0.05
+    bias = torch.randn(1, ncls, generator=g) * 0.1
+    labels = torch.randint(0, ncls, (B,), generator=g)
+    xd, wd, bd = (t.to(dev).requires_grad_() for t in (x, w, bias))
+    logits = Fn.global_avg_linear(xd, boff.to(dev), wd, bd)
+    loss = Fn.cross_entropy(logits, labels.to(dev))
+    loss.backward()
+    x64, w64, b64 = (t.double().requires_grad_() for t in (x, w, bias))
+    pooled = torch.stack([x64[boff[b]:boff[b + 1]].mean(0) if counts[b] > 0 else torch.zeros(C, dtype=torch.float64) for b in range(B)])
+    logits64 = pooled @ w64 + b64
+    loss64 = F.cross_entropy(logits64, labels)
+    loss64.backward()
+    assert float((logits.detach().cpu().double() - logits64.detach()).abs().max()) < 1e-5
+    assert abs(float(loss.detach()) - float(loss64.detach())) < 1e-5
+    for got, want, name in ((xd.grad, x64.grad, "dx"), (wd.grad, w64.grad, "dw"), (bd.grad, b64.grad, "db")):
+        err = float((got.cpu().double() - want).norm() / want.norm().clamp_min(1e-30))
+        assert err < 1e-5, (name, err)
+    # an upstream factor on the loss, and bitwise repeatability
+    xd.grad = None
+    logits2 = Fn.global_avg_linear(xd, boff.to(dev), wd, bd)
+    assert torch.equal(logits2, logits)
+    (3.0 * Fn.cross_entropy(logits2, labels.to(dev))).backward()
+    assert float((xd.grad.cpu().double() - 3.0 * x64.grad).norm() / x64.grad.norm()) < 1e-5
+    # a label outside [0, classes) must not pass silently
+    bad = labels.clone()
+    bad[0] = ncls
+    assert torch.isnan(Fn.cross_entropy(logits.detach(), bad.to(dev)))
+
+
+def test_shortcut_data_gradient_pieces():
+    """mink_dense_xwt (y = x @ W^T on the fp32 matrix cores, ragged shapes) and mink_rows_scatter_add (distinct
+    destination rows, -1 entries skipped) against float64 torch; together they must equal, BIT FOR BIT, what the
+    gather-GEMM's accumulate form computed for the 1x1x1 strided shortcut (same accumulation chain per element)."""
+    from nerf_downstream_amd._lib import check, lib
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    for n, Kd, N in ((1000, 128, 64), (37, 64, 64), (513, 512, 256), (70, 20, 12)):
+        x = torch.randn(n, Kd, generator=g)
+        w = torch.randn(N, Kd, generator=g) * 0.1
+        y = torch.empty(n, N, device=dev)
+        xd, wd = x.to(dev), w.to(dev)
+        check(lib().mink_dense_xwt(xd.data_ptr(), wd.data_ptr(), n, Kd, N, y.data_ptr(), None))
+        ref = x.double() @ w.double().t()
+        assert float((y.cpu().double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())), (n, Kd, N)
+        # scatter: every other source row goes to a distinct destination row, the rest nowhere
+        n_dst = 3 * n + 5
+        idx = torch.full((n,), -1, dtype=torch.int32)
+        sel = torch.randperm(n, generator=g)[: n // 2]
+        idx[sel] = torch.randperm(n_dst, generator=g)[: sel.numel()].to(torch.int32)
+        if N % 4 == 0:
+            dst0 = torch.randn(n_dst, N, generator=g)
+            dst, idxd = dst0.to(dev), idx.to(dev)
+            check(lib().mink_rows_scatter_add(y.data_ptr(), idxd.data_ptr(), n, N, dst.data_ptr(), None))
+            want = dst0.clone()
+            want[idx[sel].long()] += y.cpu()[sel]
+            assert torch.equal(dst.cpu(), want)
