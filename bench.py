@@ -317,6 +317,7 @@ def main():
             reducer.zero_grad()
         else:
             opt.zero_grad(set_to_none=True)
+        Fn.log_phase("grads_cleared", torch.cuda.current_stream())
         out = model(tf)
         if gated:  # the next batch's preparation starts once this batch's stem convolution is done (Fn.mark_phase)
             Fn.log_phase("forward_queued", torch.cuda.current_stream())

@@ -46,7 +46,7 @@ class BasicBlock(nn.Module):
         Fn.stream_wait(br, cur)
         Fn.skew(br)
         with torch.cuda.stream(br):
-            shortcut = self.downsample(x)
+            shortcut = self._shortcut(x)
         x.F.record_stream(br)
 
         def join():
@@ -54,6 +54,14 @@ class BasicBlock(nn.Module):
             shortcut.F.record_stream(cur)
 
         return shortcut, join
+
+    def _shortcut(self, x):
+        """downsample(x) = norm(conv(x)) (reference resnet.py:120-128); on the fused backend the convolution hands the
+        column statistics of its output to the norm, as conv1 / conv2 do (and as the native trunk sequences it)."""
+        ds = self.downsample
+        if self._fused and self.training and len(ds) == 2:
+            return ds[1](ds[0](x, bn_stats=True))
+        return ds(x)
 
     def _may_fork(self, x):
         if not (self._fused and self._fork and self.downsample is not None and x.F.is_cuda):
@@ -69,7 +77,7 @@ class BasicBlock(nn.Module):
             h = self.conv2(self.norm1(self.conv1(x, bn_stats=st), relu=True), bn_stats=st)
             join()
             return self.norm2(h, relu=True, residual=shortcut)
-        shortcut = x if self.downsample is None else self.downsample(x)
+        shortcut = x if self.downsample is None else self._shortcut(x)
         if self._fused:
             st = self.training
             h = self.norm1(self.conv1(x, bn_stats=st), relu=True)
@@ -108,7 +116,7 @@ class Bottleneck(BasicBlock):
         if self._may_fork(x):
             shortcut, join = self._forked_shortcut(x)
         else:
-            shortcut = x if self.downsample is None else self.downsample(x)
+            shortcut = x if self.downsample is None else self._shortcut(x)
         if self._fused:
             st = self.training
             h = self.norm1(self.conv1(x), relu=True)

@@ -96,8 +96,16 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(const float *__restrict__ 
     const int rl = C4 >= HB ? 0 : t / C4;
     if (rl < rlanes) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int r = r0 + rl; r < r1; r += rlanes) {
-        const float4 v = ld4g(x + (int64_t)r * C + 4 * c4);
+      const float *px = x + 4 * c4;
+      int r = r0 + rl;
+      for (; r + 3 * rlanes < r1; r += 4 * rlanes) {  // four independent loads in flight; summed in row order
+        const float4 v0 = ld4g(px + (int64_t)r * C), v1 = ld4g(px + (int64_t)(r + rlanes) * C),
+                     v2 = ld4g(px + (int64_t)(r + 2 * rlanes) * C), v3 = ld4g(px + (int64_t)(r + 3 * rlanes) * C);
+        s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x, s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
+        s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z, s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+      }
+      for (; r < r1; r += rlanes) {
+        const float4 v = ld4g(px + (int64_t)r * C);
         s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
       }
       float *d = sh + (int64_t)rl * C + 4 * c4;
@@ -114,12 +122,21 @@ __global__ __launch_bounds__(HB) void head_fwd_kernel(const float *__restrict__ 
     pooled[(int64_t)b * C + c] = s;
   }
   __syncthreads();
+  // logits: thread (part, lane) sums channels part, part + 4, ... of class j = lane (+64 ...): the loads of eight
+  // consecutive trips are independent and issued together; one accumulator, channel order ascending within a part
   float *sl = sp + C;  // [4][ncls]
-  const int part = t >> 6, lane = t & 63, cq = (C + 3) / 4;
+  const int part = t >> 6, lane = t & 63;
   for (int j = lane; j < ncls; j += 64) {
     float s = 0.f;
-    const int c1 = min(C, (part + 1) * cq);
-    for (int c = part * cq; c < c1; ++c) s = fmaf(sp[c], w[(int64_t)c * ncls + j], s);
+    int c = part;
+    for (; c + 28 < C; c += 32) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = w[(int64_t)(c + 4 * u) * ncls + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s = fmaf(sp[c + 4 * u], wv[u], s);
+    }
+    for (; c < C; c += 4) s = fmaf(sp[c], w[(int64_t)c * ncls + j], s);
     sl[part * ncls + j] = s;
   }
   __syncthreads();
@@ -147,7 +164,16 @@ __global__ __launch_bounds__(HB) void head_bwd_kernel(const float *__restrict__ 
     __syncthreads();
     for (int c = t; c < C; c += HB) {
       float s = 0.f;
-      for (int j = 0; j < ncls; ++j) s = fmaf(sd[j], w[(int64_t)c * ncls + j], s);
+      const float *wr = w + (int64_t)c * ncls;
+      int j = 0;
+      for (; j + 7 < ncls; j += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = wr[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = fmaf(sd[j + u], wv[u], s);
+      }
+      for (; j < ncls; ++j) s = fmaf(sd[j], wr[j], s);
       sg[c] = s * inv;
     }
     __syncthreads();

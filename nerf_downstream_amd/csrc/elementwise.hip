@@ -113,9 +113,26 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
 // channel c to lane 0 of its wave.  All loads of a lane are independent, so the pass costs one
 // memory round trip instead of nblk / 16 dependent ones.
 constexpr int kFinCh = 4;  // channels per finalize workgroup
+// WIDE: the whole workgroup sums ONE channel (thread t takes partial rows t, t + 256, ...; waves combined through LDS in
+// wave order) -- for the 2048-row partials of the finest level, where a single wave per channel needs 32 dependent-issue
+// loads per lane (26 us for the stem's batch-norm backward; 6 us this way).
+template <bool WIDE = false>
 __device__ __forceinline__ bool finalize_sums(const double *__restrict__ partial, int nblk, int C, int &c, double &s,
                                               double &ss) {
   const int lane = threadIdx.x & 63;
+  if constexpr (WIDE) {
+    __shared__ double s_fin[2][4];
+    c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int blk = threadIdx.x; blk < nblk; blk += 256) a += partial[(int64_t)blk * 2 * C + c], b += partial[(int64_t)blk * 2 * C + C + c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64), b += __shfl_xor(b, off, 64);
+    if (lane == 0) s_fin[0][threadIdx.x >> 6] = a, s_fin[1][threadIdx.x >> 6] = b;
+    __syncthreads();
+    s = ((s_fin[0][0] + s_fin[0][1]) + s_fin[0][2]) + s_fin[0][3];
+    ss = ((s_fin[1][0] + s_fin[1][1]) + s_fin[1][2]) + s_fin[1][3];
+    return threadIdx.x == 0;
+  }
   c = blockIdx.x * kFinCh + (threadIdx.x >> 6);
   if (c >= C) return false;  // whole wave
   double a = 0.0, b = 0.0;
@@ -125,6 +142,7 @@ __device__ __forceinline__ bool finalize_sums(const double *__restrict__ partial
   s = a, ss = b;
   return lane == 0;
 }
+constexpr int kWideFinalizeRows = 512;  // partial rows from which the wide form is used
 
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double *__restrict__ partial, int nblk, int64_t n,
                                                                 int C, float eps, float momentum,
@@ -145,12 +163,13 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double *__
   }
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblk, int C,
                                                               const float *__restrict__ gamma,
                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
   int c;
   double s, ss;
-  if (!finalize_sums(partial, nblk, C, c, s, ss)) return;
+  if (!finalize_sums<WIDE>(partial, nblk, C, c, s, ss)) return;
   dbeta[c] = (float)s;
   dgamma[c] = (float)ss;
 }
@@ -522,6 +541,14 @@ using namespace mink;
 
 extern "C" {
 
+static void launch_bwd_finalize(const double *partial, int nblk, int C, const float *gamma, float *dgamma, float *dbeta,
+                                hipStream_t st) {
+  if (nblk >= kWideFinalizeRows)
+    bn_bwd_finalize_kernel<true><<<dim3((unsigned)C), 256, 0, st>>>(partial, nblk, C, gamma, dgamma, dbeta);
+  else
+    bn_bwd_finalize_kernel<false><<<dim3((unsigned)cdiv(C, kFinCh)), 256, 0, st>>>(partial, nblk, C, gamma, dgamma, dbeta);
+}
+
 int64_t mink_bn_workspace_bytes(int64_t n, int32_t C) { return (int64_t)kRedBlocks * 2 * C * sizeof(double); }
 
 static int launch_colreduce(int mode, const float *a, const float *b, const float *yrelu, int64_t n, int C,
@@ -616,8 +643,7 @@ int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int3
   int nblk = 0;
   int rc = launch_colreduce(1, dy, x, yr, n, C, mean, invstd, (double *)workspace, st, &nblk);
   if (rc) return rc;
-  bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, kFinCh)), 256, 0, st>>>((const double *)workspace, nblk, C, gamma, dgamma,
-                                                                     dbeta);
+  launch_bwd_finalize((const double *)workspace, nblk, C, gamma, dgamma, dbeta, st);
   MINK_CHECK_LAUNCH();
   const int64_t n4 = n * (C >> 2);
   bn_bwd_apply_kernel<<<dim3(ew_grid(n4)), EB, 0, st>>>(dy, x, yr, n4, C >> 2, 1.f / (float)n, mean, invstd, gamma,
@@ -701,8 +727,7 @@ int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32
   colreduce_kernel<2><<<dim3((unsigned)nblk), EB, shm, st>>>(dy_pool, x, nullptr, n, C, mean, invstd, (double *)workspace,
                                                             in2out, gamma, beta);
   MINK_CHECK_LAUNCH();
-  bn_bwd_finalize_kernel<<<dim3((unsigned)cdiv(C, kFinCh)), 256, 0, st>>>((const double *)workspace, (int)nblk, C, gamma,
-                                                                     dgamma, dbeta);
+  launch_bwd_finalize((const double *)workspace, (int)nblk, C, gamma, dgamma, dbeta, st);
   MINK_CHECK_LAUNCH();
   if (!dx) return MINK_OK;
   const int64_t n4 = n * (C >> 2);

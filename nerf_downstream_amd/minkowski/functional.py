@@ -183,6 +183,14 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, ro
     return (y, partial) if stats else y
 
 
+def dense_xwt(x, w):
+    """x [n, Kd] @ w[N, Kd]^T on the fp32 matrix cores (mink_dense_xwt)."""
+    x, w = _f32c(x), _f32c(w)
+    y = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+    check(lib().mink_dense_xwt(x.data_ptr(), w.data_ptr(), x.shape[0], x.shape[1], w.shape[0], y.data_ptr(), _stream()))
+    return y
+
+
 def conv_wgrad(x, dy, nbr, kernel_shape, out=None, on=None):
     """dW[k] = X[nbr[:, k]]^T dY.  `out`: write into this contiguous fp32 tensor (a slice of a
     data-parallel reducer's flat gradient buffer) instead of a fresh one.  `on`: launch on this torch
@@ -491,6 +499,13 @@ class ConvolutionFunction(torch.autograd.Function):
             # dgrad = the same gather-GEMM over the transposed map with W[k]^T (read in place)
             if ctx.same_map:  # stride 1: nbr_t[i][k] == nbr[i][K-1-k]
                 gx = gather_gemm(gy, w, ctx.nbr, w.shape[-2], w_transposed=True, flip_k=True)
+            elif w.shape[0] == 1 and w.shape[-1] % 4 == 0 and w.shape[-2] % 4 == 0:
+                # kernel volume 1, strided (the shortcut of a residual block): the product is a plain GEMM over the
+                # OUTPUT rows, scattered to the input rows it reaches through the forward table -- the same two
+                # kernels the native trunk sequences (no transposed table, no class permutation)
+                gx = torch.zeros(x.shape[0], w.shape[-2], dtype=torch.float32, device=gy.device)
+                gsc = dense_xwt(gy, w[0])
+                check(lib().mink_rows_scatter_add(gsc.data_ptr(), ctx.nbr.data_ptr(), gsc.shape[0], gsc.shape[1], gx.data_ptr(), _stream()))
             else:
                 _, nbr_t, perm = ctx.table_fn(True)
                 gx = gather_gemm(gy, w, nbr_t, w.shape[-2], w_transposed=True, row_perm=perm)
@@ -1019,6 +1034,7 @@ class GlobalAvgLinearFunction(torch.autograd.Function):
                                       logits.data_ptr(), _stream()))
         ctx.save_for_backward(pooled, w, boff)
         ctx.n, ctx.has_bias, ctx.bias_shape = x.shape[0], bias is not None, None if bias is None else bias.shape
+        ctx.params = (kernel, bias) if (w is kernel and (bias is None or bias.is_contiguous())) else None
         return logits
 
     @staticmethod
@@ -1028,10 +1044,22 @@ class GlobalAvgLinearFunction(torch.autograd.Function):
         B, C = pooled.shape
         ncls = w.shape[1]
         gx = torch.empty(ctx.n, C, dtype=torch.float32, device=gl.device) if ctx.needs_input_grad[0] else None
-        gw = torch.empty_like(w)
-        gb = torch.empty(ctx.bias_shape, dtype=torch.float32, device=gl.device) if ctx.has_bias else None
+        # a data-parallel reducer's flat buffer as the gradient sink: the kernel writes dW / db in place (no accumulate launches)
+        views = None
+        if _GRAD_SINK is not None and ctx.params is not None:
+            views = _sink_views(*[p for p in ctx.params if p is not None])
+        if views is not None:
+            gw, gb = views[0], (views[1] if ctx.has_bias else None)
+        else:
+            gw = torch.empty_like(w)
+            gb = torch.empty(ctx.bias_shape, dtype=torch.float32, device=gl.device) if ctx.has_bias else None
         check(lib().mink_head_backward(gl.data_ptr(), pooled.data_ptr(), w.data_ptr(), boff.data_ptr(), B, C, ncls, gw.data_ptr(),
                                        _ptr(gb), _ptr(gx), _stream()))
+        if views is not None:
+            for p in ctx.params:
+                if p is not None:
+                    _GRAD_SINK.ready(p)
+            return gx, None, None, None
         return gx, None, gw, gb
 
 

@@ -212,6 +212,7 @@ class TrunkFunction(torch.autograd.Function):
         sd.norm.mean, sd.norm.invstd = a0 + 4 * (n0 + n1) * C0, a0 + 4 * ((n0 + n1) * C0 + C0)
         sd.nbr_pool, sd.in2out, sd.n, sd.n_pool = nbr_pool.data_ptr(), i2o.data_ptr(), n0, n1
         sd.x, sd.y, sd.out, sd.g_out = x.data_ptr(), a0, a0 + 4 * n0 * C0, None
+        Fn.log_phase("stem_forward_begin", cur)
         check(L.mink_stem_forward(ctypes.byref(sd), exp))
         Fn.mark_phase("stem_forward", cur)
         Fn.note_table(nbr0)
@@ -303,16 +304,15 @@ class TrunkFunction(torch.autograd.Function):
                     off += t.numel()
             d.conv1.dw, d.norm1.dgamma, d.norm1.dbeta = gs[0].data_ptr(), gs[1].data_ptr(), gs[2].data_ptr()
             d.conv2.dw, d.norm2.dgamma, d.norm2.dbeta = gs[3].data_ptr(), gs[4].data_ptr(), gs[5].data_ptr()
-            nbr1_t = nbrd_t = None
+            nbr1_t = None
             if st.stride == 2:
                 nbr1_t = _table(m, ts_in, ts_out, 3, transposed=True)[1]
                 perm1 = m.tables.get(("perm", ts_in, 128)) if m.prepared else None
                 if perm1 is None:
                     perm1 = m.class_perm(CoordinateMapKey(ts_in))
                 d.conv1.nbr_t, d.conv1.perm, d.conv1.n_perm = nbr1_t.data_ptr(), perm1.data_ptr(), perm1.numel()
-            if has_down:
-                nbrd_t = _table(m, ts_in, ts_out, 1, transposed=True)[1]
-                d.down.nbr_t, d.down.dw = nbrd_t.data_ptr(), gs[6].data_ptr()
+            if has_down:  # (its data gradient goes through the forward table: no transposed table)
+                d.down.dw = gs[6].data_ptr()
                 d.normd.dgamma, d.normd.dbeta = gs[7].data_ptr(), gs[8].data_ptr()
             # (the descriptor still holds this batch's forward fields: the activations it points at are kept in `saved`)
             if d.y1 != arena.data_ptr():  # another forward pass ran on this model in between: restore this batch's fields
@@ -324,7 +324,7 @@ class TrunkFunction(torch.autograd.Function):
             for s_ in skew:
                 Fn.skew(s_)
             check(L.mink_block_backward(ctypes.byref(d), exp))
-            Fn.note_table(nbr1, nbr2, nbrd, nbr1_t, nbrd_t)
+            Fn.note_table(nbr1, nbr2, nbrd, nbr1_t)
             _KEEPALIVE.append((g_buf, g))  # (never the gradients handed to autograd: a second reference makes it clone them at once)
             if views is not None:
                 for i in range(st.pidx, st.pidx + st.np):

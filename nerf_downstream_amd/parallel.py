@@ -218,3 +218,4 @@ class BucketedGradAllReduce:
         self._work.clear()
         if not self._avg:
             self.flat.mul_(1.0 / self.world)
+

@@ -27,3 +27,19 @@ def batch_scenes(seeds, **kw):
         cs.append(np.concatenate([np.full((c.shape[0], 1), j, np.float32), c], 1))
         fs.append(f)
     return torch.from_numpy(np.concatenate(cs)), torch.from_numpy(np.concatenate(fs))
+
+
+def trunk_node(out):
+    """The native-trunk autograd node (minkowski/trunk.py: TrunkFunction) in the graph of `out`, or None when the forward
+    pass went module by module.  (`model._trunk_plan` only says the model COULD take the native trunk: a stem too small for
+    the streaming weight-gradient kernel -- fewer than ~44 k voxels -- takes the module path.)"""
+    seen, stack = set(), [out.grad_fn]
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        if hasattr(fn, "saved") and hasattr(fn, "plan"):
+            return fn
+        stack += [f for f, _ in fn.next_functions]
+    return None

@@ -125,16 +125,9 @@ def _relu_masks_of_hip_run(out):
     """(z > 0) of every ReLU of the residual stages in forward order, as the native trunk decided it: the trunk keeps
     h1 = relu(norm1(conv1 x)) and out = relu(norm2(conv2 h1) + shortcut) of each stage for its backward pass
     (minkowski/trunk.py: arena = [y1 | h1 | y2 | out | ...]); a ReLU output is positive exactly where its branch was."""
-    seen, stack, node = set(), [out.grad_fn], None
-    while stack:
-        fn = stack.pop()
-        if fn is None or fn in seen:
-            continue
-        seen.add(fn)
-        if hasattr(fn, "saved") and hasattr(fn, "plan"):
-            node = fn
-            break
-        stack += [f for f, _ in fn.next_functions]
+    from helpers import trunk_node
+
+    node = trunk_node(out)
     assert node is not None, "no native-trunk node in the autograd graph"
     masks = []
     for st, sv in zip(node.plan.stages, node.saved[1:]):

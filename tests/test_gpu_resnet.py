@@ -169,15 +169,19 @@ def test_wgrad_side_stream_is_bitwise_identical(oracle_maps):
             assert torch.equal(a[k], b[k]), (passes, k)
 
 
-@pytest.mark.parametrize("name,cin,seeds", [("ResNet14", 28, (41, 42, 43)), ("ResNet18", 27, (44, 45)), ("ResNet34", 28, (46, 47))])
+@pytest.mark.parametrize("name,cin,seeds", [("ResNet14", 28, (41, 42, 43)), ("ResNet18", 27, (44, 45, 46)), ("ResNet34", 28, (46, 47, 48))])
 def test_native_trunk_is_bitwise_the_module_path(oracle_maps, name, cin, seeds):
     """The native trunk (one call per stage, minkowski/trunk.py) sequences the same kernels as the module-by-module
     path: logits, every parameter gradient and every batch-norm buffer must be equal bit for bit -- with the shortcut
     branch and the weight gradients on their own streams, and on a single stream.  ResNet18/34 add identity-shortcut
-    blocks; 27 input channels add the zero-padded column."""
+    blocks; 27 input channels add the zero-padded column.  64^3 scenes: the trunk is only taken when the stem is large
+    enough for the streaming weight-gradient kernel (>= ~44 k voxels; three scenes are ~63 k), and that it WAS taken is
+    asserted on the autograd graph."""
+    from helpers import trunk_node
+
     from nerf_downstream_amd.minkowski import functional as Fn
 
-    coords, feats = batch_scenes(list(seeds), grid=32, cin=cin)
+    coords, feats = batch_scenes(list(seeds), grid=64, cin=cin)
     batch = {"coordinates": coords.cuda(), "features": feats.cuda()}
     labels = (torch.arange(len(seeds)) * 7 + 1).cuda() % 51
 
@@ -190,15 +194,16 @@ def test_native_trunk_is_bitwise_the_module_path(oracle_maps, name, cin, seeds):
             for _ in range(2):  # second pass: the map plan of the first is replayed ahead (prepared manager -> forked shortcut)
                 hip.zero_grad(set_to_none=True)
                 out = hip(hip.process_input(batch))
+                used = trunk_node(out) is not None
                 F.cross_entropy(out, labels).backward()
                 outs.append(out.detach().clone())
             torch.cuda.synchronize()
         finally:
             Fn.set_wgrad_overlap(old)
-        used = hip._trunk_plan if native else None
         return outs, {k: p.grad.clone() for k, p in hip.named_parameters()}, {k: b.clone() for k, b in hip.named_buffers()}, used
 
-    ref_out, ref_g, ref_b, _ = run(False, False)
+    ref_out, ref_g, ref_b, used = run(False, False)
+    assert not used
     for overlap in (False, True):
         out, g, b, plan = run(True, overlap)
         assert plan, "the native trunk was not taken"

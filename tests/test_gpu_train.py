@@ -92,19 +92,23 @@ def _train_steps(model, batches, labels, steps, reducer=None):
     return torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
 
 
-def test_multi_stream_schedule_is_bitwise_single_stream():
+@pytest.mark.parametrize("grid,sink", [(32, False), (64, False), (64, True)])
+def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink):
     """Five training steps with every stream overlap on and the auxiliary streams skewed ==
-    the same five steps on a single stream, bit for bit (all kernels are deterministic)."""
+    the same five steps on a single stream, bit for bit (all kernels are deterministic).  32^3 scenes take the
+    module-by-module path, 64^3 scenes (~63 k voxels per batch) the native trunk -- asserted; `sink`: the flat gradient
+    buffer of a one-rank reducer as the gradient sink of the backward kernels, which is how bench.py and train.py run."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import batch_scenes
+    from helpers import batch_scenes, trunk_node
 
     from nerf_downstream_amd.co3d_3d.src.models import get_model
     from nerf_downstream_amd.minkowski import functional as Fn
+    from nerf_downstream_amd.parallel import BucketedGradAllReduce
 
     dev = torch.device("cuda", 0)
     batches, labels = [], []
     for j in range(2):
-        coords, feats = batch_scenes([70 + 3 * j, 71 + 3 * j, 72 + 3 * j], grid=32, cin=28)
+        coords, feats = batch_scenes([70 + 3 * j, 71 + 3 * j, 72 + 3 * j], grid=grid, cin=28)
         batches.append({"coordinates": coords.to(dev), "features": feats.to(dev)})
         labels.append(torch.tensor([j, 1 + j, 2 + j], device=dev))
     out = {}
@@ -112,11 +116,16 @@ def test_multi_stream_schedule_is_bitwise_single_stream():
         for mode, (multi, lazy_fork) in {"single": (False, False), "multi": (True, False), "multi-lazy": (True, True)}.items():
             torch.manual_seed(5)
             m = get_model("ResNet14", 28, 5).to(dev)
+            reducer = BucketedGradAllReduce(m) if sink else None
             _schedule(m, multi, lazy_fork)
-            out[mode] = _train_steps(m, batches, labels, 5)
+            native = trunk_node(m(m.process_input(batches[0]))) is not None
+            assert native == (grid >= 64), (grid, native)
+            out[mode] = _train_steps(m, batches, labels, 5, reducer)
+            Fn.set_grad_sink(None)
     finally:
         Fn._SKEW = 0
         Fn.set_wgrad_overlap(True)
+        Fn.set_grad_sink(None)
     assert torch.isfinite(out["multi"]).all()
     assert torch.equal(out["single"], out["multi"])
     assert torch.equal(out["single"], out["multi-lazy"])
