@@ -120,9 +120,9 @@ def cpu_baseline(model_name, cin, num_classes, grid, state_dict, seconds_budget=
 
 
 def pmc_traffic(tag, meta):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary
-    (profiles/*_pmc.json, produced by scripts/pmc_summary.py from separate rocprofv3 --pmc
-    passes; 2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md).  None if no matching entry."""
+    """(HBM bytes per launch of the dominant kernel, {"profile", "git_head_of_profile"}) from the newest committed PMC
+    summary (profiles/*_pmc.json, produced by scripts/pmc_summary.py from separate rocprofv3 --pmc passes;
+    2*FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md).  (None, ...) if no matching entry."""
     import glob
 
     import re
@@ -132,7 +132,11 @@ def pmc_traffic(tag, meta):
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=natural)
     if not files:
-        return None
+        return None, None
+    source = {"profile": os.path.basename(files[-1]), "git_head_of_profile": "unknown"}
+    meta_file = files[-1].replace(".json", ".meta.json")
+    if os.path.exists(meta_file):
+        source["git_head_of_profile"] = json.load(open(meta_file)).get("git_head", "unknown")
     stem_wgrad = tag.startswith("wgrad") and meta["cin"] <= 32 and meta["K"] == 27
     want = "wgrad_stream_kernel" if stem_wgrad else "wgrad_kernel" if tag.startswith("wgrad") else "gather_gemm2_kernel"
     best = None
@@ -142,7 +146,7 @@ def pmc_traffic(tag, meta):
                 continue
             if best is None or e["hbm_traffic_bytes_per_launch"] > best:
                 best = e["hbm_traffic_bytes_per_launch"]
-    return best
+    return best, source
 
 
 def _conv_bytes(meta, pairs):
@@ -181,7 +185,10 @@ def roofline_from_timings(timings, pair_table):
         "peak": MFMA_F32_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-        "traffic": pmc_traffic(g["tags"][0], g["meta"]),
+        "traffic": pmc_traffic(g["tags"][0], g["meta"])[0],
+        # `traffic` is NOT measured in this run: it is read from the newest committed PMC profile, named here with the
+        # commit it was taken at -- compare with the head this line was produced from before trusting it
+        "traffic_source": pmc_traffic(g["tags"][0], g["meta"])[1],
         "avg_ms": avg_ms,
         "launches": n,
         "flops_per_launch": g["flops"] / n,

@@ -15,7 +15,10 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
  *     enqueued asynchronously on it, nothing here synchronises the device;
  *   - the caller owns every buffer (no hidden allocations, no global state) so the
- *     library is safe to call from a graph-captured or multi-stream host;
+ *     library is safe to call from a graph-captured or multi-stream host; every scratch
+ *     buffer is passed WITH ITS SIZE (`workspace_bytes`, ABI version 2): the size a launch needs can depend on a
+ *     plan (split factors, row splits), so the library checks it against the plan it is about to launch and returns
+ *     MINK_EINVAL instead of writing past the end of a buffer sized for another plan;
  *   - return value 0 = success, otherwise a negative MINK_E* code and
  *     mink_last_error() (thread-local) describes the failure;
  *   - coordinates are int32 rows (batch, x, y, z); row counts are int64; feature
@@ -83,7 +86,7 @@ int mink_coords_make_keys(const void *coords, int mode, int64_t n, int32_t out_t
  */
 int mink_coords_unique(const uint64_t *keys, int64_t n, uint64_t *table_keys, int32_t *table_vals,
                        int64_t cap, int32_t *out_coords, int32_t *unique_index, int32_t *inverse,
-                       int32_t *n_unique, void *workspace, void *stream);
+                       int32_t *n_unique, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* The whole coordinate pyramid of one batch in ONE call and with NO host synchronisation:
  * level 0 = insert_and_map of the input rows (mode as in mink_coords_make_keys, floored to
@@ -104,7 +107,7 @@ int mink_coords_build_levels(const void *coords, int mode, int64_t n, int32_t nl
                              const int32_t *out_ts_host, uint64_t *const *table_keys,
                              int32_t *const *table_vals, int64_t cap, int32_t *const *out_coords,
                              int32_t *const *index_a, int32_t *const *index_b, int32_t *meta,
-                             void *workspace, void *stream);
+                             void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Kernel map as a neighbour table: for every output row o and offset k probe the INPUT
  * map at out_coords[o] + offsets[k].  offsets_host[K][3] are already scaled by
@@ -157,7 +160,7 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *descs, void *strea
  */
 int64_t mink_rulebook_workspace_bytes(int64_t n_out, int32_t K);
 int mink_rulebook(const int32_t *nbr, int64_t n_out, int32_t K, int32_t *counts, int32_t *pairs_in,
-                  int32_t *pairs_out, void *workspace, void *stream);
+                  int32_t *pairs_out, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Parity-class permutation of the rows of a tensor-stride-`ts` map: rows grouped by the parity
  * of (coordinate / ts) per axis (8 classes), each class segment padded to a multiple of `pad`
@@ -167,7 +170,7 @@ int mink_rulebook(const int32_t *nbr, int64_t n_out, int32_t K, int32_t *counts,
 int64_t mink_class_partition_rows(int64_t n, int32_t pad);
 int64_t mink_class_partition_workspace_bytes(int64_t n);
 int mink_class_partition(const int32_t *coords, int64_t n, int32_t ts, int32_t pad, int32_t *perm,
-                         void *workspace, void *stream);
+                         void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Row ranges of each batch index in a coordinate list whose batch column is
  * non-decreasing (guaranteed by ME.utils.sparse_collate, data/utils.py:25-30).
@@ -182,16 +185,15 @@ int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *bat
  */
 
 /* Output-stationary gather-GEMM on the fp32 matrix cores.
- *   x[.. ][ldx], cin   : gathered operand
+ *   x[n_in][ldx], cin  : gathered operand (every table entry is -1 or < n_in)
  *   w                  : w_transposed == 0:  w[K][cin][cout]   (forward)
  *                        w_transposed == 1:  w[K][cout][cin]   (dgrad: pass the forward
  *                                            kernel and swap cin/cout)
  *   flip_k             : use w[K-1-k] for table column k (dgrad of a stride-1 conv
  *                        re-uses the forward table: nbr_t[i][k] == nbr[i][K-1-k])
  *   nbr[n_out][K]      : neighbour table;  y[n_out][ldy] receives cout columns.  (cin == 28, the flattened-K
- *                        stem path: x must have fewer than 2^24 - 1 rows -- its rows are addressed with a
- *                        24-bit multiply; the library checks n_out, which equals the row count of x for the
- *                        stride-1 convolution that path serves.)
+ *                        stem path: taken only when n_in < 2^24 - 1 -- its rows are addressed with a 24-bit
+ *                        multiply; larger inputs take the general path.)
  *   bias[cout] or NULL
  *   row_perm/n_virtual : optional row permutation (NULL/0 = identity): tile row v computes
  *                        output row row_perm[v], -1 entries are padding (mink_class_partition)
@@ -223,11 +225,11 @@ int mink_conv_plan(int64_t n_rows, int32_t K, int32_t cin, int32_t cout, int32_t
  * forward table); bit 1 = ACCUMULATE, y[row] += result instead of y[row] = result -- for an un-split launch whose
  * row_perm visits every output row at most once (rows it does not visit are left untouched): the data gradient of
  * the 1x1x1 strided shortcut convolution is added into the main branch's gradient at the 1/8 of the rows it reaches. */
-int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
+int mink_conv_gather_gemm(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
                           int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K,
                           const int32_t *row_perm, int64_t n_virtual, float *y, int32_t ldy,
                           int32_t cout, const float *bias, int32_t ksplit, float *workspace,
-                          void *stream);
+                          int64_t workspace_bytes, void *stream);
 /* Forward convolution that also emits the column statistics of its output for the batch norm that
  * follows (reference resnet_block.py:53-60: every 3x3x3 convolution feeds a norm): the un-split
  * kernel sums its tile in the epilogue, the split-K reduce sums while it adds the slabs -- y is
@@ -235,10 +237,10 @@ int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float 
  * 0 when this launch shape cannot produce them (the caller then calls mink_bn_stats);
  * stats_ws >= mink_conv_stats_workspace_bytes(n_out, cout). */
 int64_t mink_conv_stats_workspace_bytes(int64_t n_out, int32_t cout);
-int mink_conv_gather_gemm_stats(const float *x, int32_t ldx, int32_t cin, const float *w, const int32_t *nbr,
+int mink_conv_gather_gemm_stats(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *w, const int32_t *nbr,
                                 int64_t n_out, int32_t K, float *y, int32_t ldy, int32_t cout,
-                                const float *bias, int32_t ksplit, float *workspace, double *stats_out,
-                                int32_t *stats_rows, void *stats_ws, void *stream);
+                                const float *bias, int32_t ksplit, float *workspace, int64_t workspace_bytes,
+                                double *stats_out, int32_t *stats_rows, void *stats_ws, int64_t stats_ws_bytes, void *stream);
 
 /* Weight gradient dW[k] = X[nbr[.][k]]^T @ dY, split over row blocks and reduced
  * deterministically (no atomics).  x has n_in rows (every nbr entry is -1 or in [0, n_in)).
@@ -246,7 +248,7 @@ int mink_conv_gather_gemm_stats(const float *x, int32_t ldx, int32_t cin, const 
 int64_t mink_conv_wgrad_workspace_bytes(int64_t n_out, int32_t K, int32_t cin, int32_t cout);
 int mink_conv_wgrad(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *dy, int32_t ldy,
                     int32_t cout, const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace,
-                    void *stream);
+                    int64_t workspace_bytes, void *stream);
 /* Weight gradient of a convolution whose output y feeds  pool(relu(bn(y)))  (the stem of the
  * reference ResNets, resnet.py:58-64) and whose input needs no gradient: the gradient with respect
  * to y is recomputed from (y, pooled gradient, batch statistics, dgamma, dbeta -- mink_bn_relu_pool_bwd
@@ -258,7 +260,7 @@ int mink_conv_wgrad_bn_relu_pool(const float *x, int64_t n_in, int32_t ldx, int3
                                  const float *dy_pool, int64_t n_pool, const int32_t *in2out, const float *mean,
                                  const float *invstd, const float *gamma, const float *beta,
                                  const float *dgamma, const float *dbeta, const int32_t *nbr, int64_t n_out,
-                                 int32_t K, float *dw, void *workspace, void *stream);
+                                 int32_t K, float *dw, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Data gradient of a 1x1x1 convolution as a plain GEMM: y[n][N] = x[n][Kd] @ W^T with the FORWARD kernel W[N = cin][Kd = cout]
  * (the `downsample` convolution of a residual block, models/mink/resnet.py:120-128), one fp32 MFMA accumulator chain per
@@ -316,7 +318,7 @@ int64_t mink_bn_workspace_bytes(int64_t n, int32_t C);
 /* Batch statistics: mean[C], invstd[C] = 1/sqrt(biased var + eps); if running_mean !=
  * NULL also updates running stats with `momentum` (unbiased variance, torch semantics). */
 int mink_bn_stats(const float *x, int64_t n, int32_t C, float eps, float momentum, float *mean,
-                  float *invstd, float *running_mean, float *running_var, void *workspace,
+                  float *invstd, float *running_mean, float *running_var, void *workspace, int64_t workspace_bytes,
                   void *stream);
 
 /* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
@@ -329,7 +331,7 @@ int mink_bn_apply(const float *x, int64_t n, int32_t C, const float *mean, const
  * column reads) and is not provided. */
 int mink_bn_fwd(const float *x, int64_t n, int32_t C, float eps, float momentum, const float *gamma,
                 const float *beta, const float *residual, int32_t relu, float *y, float *mean, float *invstd,
-                float *running_mean, float *running_var, void *workspace, void *stream);
+                float *running_mean, float *running_var, void *workspace, int64_t workspace_bytes, void *stream);
 /* Statistics from column partials [rows][2][C] (sum, sum of squares; double) that the producer of
  * x already computed -- mink_conv_gather_gemm_stats -- instead of a reduction pass over x. */
 int mink_bn_stats_from_partials(const double *partial, int32_t rows, int64_t n, int32_t C, float eps,
@@ -340,14 +342,14 @@ int mink_bn_stats_from_partials(const double *partial, int32_t rows, int64_t n, 
  * dgamma[C], dbeta[C]; dx[n][C]; dresidual (may be NULL) receives the masked grad. */
 int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int32_t C, const float *mean,
                 const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual,
-                float *dgamma, float *dbeta, void *workspace, void *stream);
+                float *dgamma, float *dbeta, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Split form for MinkowskiSyncBatchNorm (train.py:106-107): per-channel sums stay on the device
  * as doubles so the host can all-reduce them (RCCL) between the passes.
  *   mink_bn_reduce mode 0: sums = [sum x | sum x^2];  mode 1: [sum g | sum g*xhat] (g masked by y>0
  *   when y != NULL).  n_total: device double (rows over all ranks). */
 int mink_bn_reduce(int32_t mode, const float *a, const float *b, const float *y, int64_t n, int32_t C,
-                   const float *mean, const float *invstd, double *sums, void *workspace, void *stream);
+                   const float *mean, const float *invstd, double *sums, void *workspace, int64_t workspace_bytes, void *stream);
 int mink_bn_stats_from_sums(const double *sums, const double *n_total, int32_t C, float eps, float momentum,
                             float *mean, float *invstd, float *running_mean, float *running_var,
                             void *stream);
@@ -366,7 +368,7 @@ int mink_bn_relu_pool_fwd(const float *x, int32_t C, const float *mean, const fl
 int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32_t C, const float *mean,
                           const float *invstd, const float *gamma, const float *beta,
                           const int32_t *in2out, float *dx, float *dgamma, float *dbeta,
-                          void *workspace, void *stream);
+                          void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Max pooling over a neighbour table whose windows may overlap -- the 3x3 stride-2 pooling of the dense 2-D
  * comparison network (torchvision ResNet, reference co3d_2d/src/model/models.py:18-23), also ME.MinkowskiMaxPooling.
@@ -395,13 +397,16 @@ int mink_activation(const float *x, const float *gy, const float *slope, int32_t
  * `density[n]`, `sh_q[n][27]` uint8, per scene b (rows scene_offsets[b] .. scene_offsets[b+1])
  * `sh_scale[b][27]`, `sh_min[b][27]`.  Writes coords int32 [n][4] = (b, x, y, z) and the selected
  * feature columns: density at col_density, the 27 de-quantised SH coefficients at col_sh, ones at
- * col_ones (-1 = not selected; the columns must tile 0..C-1).  sh = float(sh_q) * scale + min with
- * separate multiply and add, bit-identical to the numpy expression of the reference. */
+ * col_ones, the three "xyzs" columns at col_xyzs (-1 = not selected; the columns must tile 0..C-1).
+ * sh = float(sh_q) * scale + min with separate multiply and add, bit-identical to the numpy expression of
+ * the reference.  xyzs (co3d.py:209-214, `configs/feature_coord.gin`): every point minus the mean of its own
+ * three coordinates, divided by the largest such norm of its scene -- a per-scene reduction, done in a
+ * first pass into scene_scratch[n_scenes] (required when col_xyzs >= 0); every operation rounded separately. */
 int mink_decode_plenoxel(const int32_t *links, const float *density, const uint8_t *sh_q,
                          const int32_t *scene_offsets, int32_t n_scenes, const float *sh_scale,
                          const float *sh_min, int64_t n, int32_t reso_y, int32_t reso_z, int32_t col_density,
-                         int32_t col_sh, int32_t col_ones, int32_t C, int32_t *coords, float *feats, int32_t ldf,
-                         void *stream);
+                         int32_t col_sh, int32_t col_ones, int32_t col_xyzs, float *scene_scratch, int32_t C,
+                         int32_t *coords, float *feats, int32_t ldf, void *stream);
 
 /* ------------------------------------------------------------------ scene augmentation
  * The reference augments every scene on the CPU in its DataLoader workers (co3d.py:216-219 applies
@@ -451,7 +456,7 @@ int64_t mink_augment_workspace_bytes(int64_t n, int32_t n_scenes);
 int mink_augment_scenes(const void *coords, int32_t coords_are_int32, const float *feats, int64_t ldf, int32_t C, int64_t n,
                         const int32_t *scene_offsets, int32_t n_scenes, const float *params,
                         const uint32_t *streams, uint64_t seed, const int32_t *raw_cols, float *out_coords,
-                        float *out_feats, int64_t ldo, int32_t *n_kept, void *workspace, void *stream);
+                        float *out_feats, int64_t ldo, int32_t *n_kept, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ whole residual blocks
  * One call = the complete launch sequence of one stage of the reference network, so the host pays one FFI call per

@@ -73,22 +73,22 @@ SIGNATURES = {
     "mink_table_capacity": (_i64, [_i64]),
     "mink_unique_workspace_bytes": (_i64, [_i64]),
     "mink_coords_make_keys": (ctypes.c_int, [_p, ctypes.c_int, _i64, _i32, _p, _p, _p]),
-    "mink_coords_unique": (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "mink_coords_unique": (ctypes.c_int, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
     "mink_levels_workspace_bytes": (_i64, [_i64]),
-    "mink_coords_build_levels": (ctypes.c_int, [_p, ctypes.c_int, _i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "mink_coords_build_levels": (ctypes.c_int, [_p, ctypes.c_int, _i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
     "mink_kernel_map": (ctypes.c_int, [_p, _p, _i64, _p, _i64, _p, _i32, _p, _p, _p]),
     "mink_kernel_map_batch": (ctypes.c_int, [_i32, _p, _p]),
     "mink_rulebook_workspace_bytes": (_i64, [_i64, _i32]),
-    "mink_rulebook": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "mink_rulebook": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "mink_class_partition_rows": (_i64, [_i64, _i32]),
     "mink_class_partition_workspace_bytes": (_i64, [_i64]),
-    "mink_class_partition": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _p]),
+    "mink_class_partition": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p, _i64, _p]),
     "mink_batch_offsets": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p]),
-    "mink_decode_plenoxel": (ctypes.c_int, [_p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p]),
+    "mink_decode_plenoxel": (ctypes.c_int, [_p, _p, _p, _p, _i32, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p]),
     "mink_augment_workspace_bytes": (_i64, [_i64, _i32]),
     "mink_augment_scenes": (
         ctypes.c_int,
-        [_p, _i32, _p, _i64, _i32, _i64, _p, _i32, _p, _p, ctypes.c_uint64, _p, _p, _p, _i64, _p, _p, _p],
+        [_p, _i32, _p, _i64, _i32, _i64, _p, _i32, _p, _p, ctypes.c_uint64, _p, _p, _p, _i64, _p, _p, _i64, _p],
     ),
     "mink_conv_set_stagger": (ctypes.c_int, [ctypes.c_int]),
     "mink_conv_set_math": (ctypes.c_int, [ctypes.c_int]),
@@ -96,20 +96,20 @@ SIGNATURES = {
     "mink_conv_plan": (ctypes.c_int, [_i64, _i32, _i32, _i32, _i32]),
     "mink_conv_gather_gemm": (
         ctypes.c_int,
-        [_p, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _p, _i32, _p, _p],
+        [_p, _i64, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _p, _i32, _p, _i64, _p],
     ),
     "mink_conv_stats_workspace_bytes": (_i64, [_i64, _i32]),
     "mink_conv_gather_gemm_stats": (
         ctypes.c_int,
-        [_p, _i32, _i32, _p, _p, _i64, _i32, _p, _i32, _i32, _p, _i32, _p, _p, _p, _p, _p],
+        [_p, _i64, _i32, _i32, _p, _p, _i64, _i32, _p, _i32, _i32, _p, _i32, _p, _i64, _p, _p, _p, _i64, _p],
     ),
     "mink_bn_stats_from_partials": (ctypes.c_int, [_p, _i32, _i64, _i32, _f32, _f32, _p, _p, _p, _p, _p]),
     "mink_conv_wgrad_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32]),
-    "mink_conv_wgrad": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _p, _p]),
+    "mink_conv_wgrad": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _p, _i64, _p]),
     "mink_conv_wgrad_bn_relu_pool_supported": (ctypes.c_int, [_i64, _i32, _i32, _i64, _i32, _i32]),
     "mink_conv_wgrad_bn_relu_pool": (
         ctypes.c_int,
-        [_p, _i64, _i32, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p],
+        [_p, _i64, _i32, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _p],
     ),
     "mink_dense_xwt": (ctypes.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "mink_rows_scatter_add": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
@@ -125,15 +125,15 @@ SIGNATURES = {
     "mink_softmax_ce_backward": (ctypes.c_int, [_p, _p, _p, _i32, _i32, _p, _p]),
     "mink_segment_mean": (ctypes.c_int, [_p, _i32, _i32, _p, _p, _i64, _p, _p]),
     "mink_bn_workspace_bytes": (_i64, [_i64, _i32]),
-    "mink_bn_stats": (ctypes.c_int, [_p, _i64, _i32, _f32, _f32, _p, _p, _p, _p, _p, _p]),
+    "mink_bn_stats": (ctypes.c_int, [_p, _i64, _i32, _f32, _f32, _p, _p, _p, _p, _p, _i64, _p]),
     "mink_bn_apply": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p]),
-    "mink_bn_fwd": (ctypes.c_int, [_p, _i64, _i32, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p]),
-    "mink_bn_bwd": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
-    "mink_bn_reduce": (ctypes.c_int, [_i32, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p]),
+    "mink_bn_fwd": (ctypes.c_int, [_p, _i64, _i32, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "mink_bn_bwd": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _p]),
+    "mink_bn_reduce": (ctypes.c_int, [_i32, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "mink_bn_stats_from_sums": (ctypes.c_int, [_p, _p, _i32, _f32, _f32, _p, _p, _p, _p, _p]),
     "mink_bn_bwd_from_sums": (ctypes.c_int, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "mink_bn_relu_pool_fwd": (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
-    "mink_bn_relu_pool_bwd": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "mink_bn_relu_pool_bwd": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "mink_eltwise": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
     "mink_activation": (ctypes.c_int, [_p, _p, _p, _i32, _i64, _i32, _f32, _p, _p]),
     "mink_block_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),

@@ -14,6 +14,7 @@ import sys
 import torch
 
 from nerf_downstream_amd import gin_lite as gin
+from nerf_downstream_amd.safe_load import load_checkpoint_file
 from nerf_downstream_amd.co3d_2d.src.data.loader import DataModule
 from nerf_downstream_amd.co3d_2d.src.modules.classification import LitModel, lr_at
 
@@ -41,7 +42,7 @@ def run(ckpt_path, resume_training, seed, run_name="resnet18", num_gpus=1, log_e
     opt = model.configure_optimizers()
     step, epoch0 = 0, 0
     if resume_training and ckpt_path:
-        ck = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        ck = load_checkpoint_file(ckpt_path)
         model.load_state_dict(ck["state_dict"])
         opt.load_state_dict(ck["optimizer"])
         step, epoch0 = ck["global_step"], ck["epoch"]

@@ -19,13 +19,13 @@ scale of every scene.  A sample, as in the reference (:585-653):
 The reference's CPU augmentations for this data set (RandomCrop, ElasticDistortion, ...) are outside this path's scope;
 only an empty transformation list is accepted."""
 import os
-import pickle
 
 import numpy as np
 import torch
 from torch.utils.data import Dataset
 
 from nerf_downstream_amd import gin_lite as gin
+from nerf_downstream_amd.safe_load import load_plain_pickle
 
 CLASS_LABELS = ("wall", "floor", "cabinet", "bed", "chair", "sofa", "table", "door", "window", "bookshelf", "picture", "counter",
                 "desk", "curtain", "refrigerator", "shower curtain", "toilet", "sink", "bathtub", "otherfurniture")
@@ -72,8 +72,7 @@ class PlenoxelScannetDataset(Dataset):
         for raw, v in label_map.items():
             if 0 <= raw < self.NUM_LABELS:
                 self._lut[raw] = v
-        with open(os.path.join(split, "scene_scales.data"), "rb") as f:
-            self.scene_scales = pickle.load(f)
+        self.scene_scales = load_plain_pickle(os.path.join(split, "scene_scales.data"))  # {scene: scale}: plain data only
         self.NUM_CLASSES = len(self.CLASS_LABELS)
 
     def load_data(self, inst_id):

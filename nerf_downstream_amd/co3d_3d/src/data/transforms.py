@@ -147,6 +147,32 @@ class RandomFeatureJitter(_Gated):
             stages.append(("feature_jitter", float(self.std), int(self.start_ind), int(self.feature_dim)))
 
 
+@gin.configurable()
+class DensityBasedSample:
+    """Keep the voxels whose density exceeds the scene's `percentile`-th percentile (reference transforms.py:655-682:
+    `np.percentile(density, percentile)`, i.e. a value in PERCENT -- the 0.95 bound by configs/co3d_aug3.gin:13 keeps
+    99 % of a scene -- and a strict `>`).  A deterministic row filter of one scene: it needs the scene's own density
+    column, so it is applied where the sample is loaded (DataLoader worker, on the raw sample in either its decoded or
+    its compact on-disk form), not in the per-batch GPU program.  It commutes with every coordinate transform and with
+    the SH jitter, hence it may stand anywhere in a recipe BEFORE CoordinateDropout (after it the percentile would be
+    taken over a random subset: not supported)."""
+
+    prefilter = True
+
+    def __init__(self, percentile=0.95, density_dim=3):
+        assert density_dim > 0, f"density_dim should be larger than 0, but got {density_dim}"
+        self.percentile, self.density_dim = percentile, density_dim
+        if density_dim != RAW_COLUMNS["density"][0]:
+            raise NotImplementedError("DensityBasedSample filters on the density column (raw column 3, co3d.py:205-214)")
+
+    def mask(self, density):
+        d = np.asarray(density, dtype=np.float32).reshape(-1)
+        return d > np.percentile(d, self.percentile)
+
+    def draw(self, stages):  # nothing for the GPU program
+        return None
+
+
 def compile_program(stages):
     """Fold one scene's drawn stage list into a MINK_AUG_* parameter row (float32 [PARAMS]).  Everything
     before the flip becomes (A, a), everything after it (B, b); BJ carries the linear stages that follow
@@ -210,6 +236,20 @@ class Compose:
 
     def __init__(self, transforms):
         self.transforms = list(transforms)
+        self.prefilters = [t for t in self.transforms if getattr(t, "prefilter", False)]
+        seen_dropout = False
+        for t in self.transforms:
+            seen_dropout = seen_dropout or isinstance(t, CoordinateDropout)
+            if seen_dropout and getattr(t, "prefilter", False):
+                raise NotImplementedError(f"{type(t).__name__} after CoordinateDropout: the filter would see a random subset")
+
+    def row_mask(self, density):
+        """AND of the recipe's per-scene row filters (None without any): applied by the dataset to the raw sample."""
+        m = None
+        for t in self.prefilters:
+            k = t.mask(density)
+            m = k if m is None else (m & k)
+        return m
 
     def draw(self):
         stages = []

@@ -41,6 +41,7 @@ from nerf_downstream_amd.co3d_3d.src.modules.segmentation_training import Segmen
 TRAINING_MODULES = {"ClassificationTraining": ClassificationTraining, "SegmentationTraining": SegmentationTraining}
 from nerf_downstream_amd.co3d_3d.src.modules.optim import get_optimizer, get_scheduler
 from nerf_downstream_amd.parallel import BucketedGradAllReduce
+from nerf_downstream_amd.safe_load import load_checkpoint_file
 
 logger = logging.getLogger(__name__)
 
@@ -105,7 +106,7 @@ def save_checkpoint(path, model, optimizer, scheduler, step, epoch, best, batch_
 
 
 def load_checkpoint(path, model, optimizer=None, scheduler=None, weights_only=False):
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    ckpt = load_checkpoint_file(path)  # this trainer's checkpoints and the reference's (Lightning layout): tensors and plain containers only
     sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in ckpt["state_dict"].items()}
     model.load_state_dict(sd)
     if not weights_only:

@@ -298,7 +298,10 @@ int64_t mink_augment_workspace_bytes(int64_t n, int32_t n_scenes) {
 int mink_augment_scenes(const void *coords, int32_t coords_are_int32, const float *feats, int64_t ldf, int32_t C, int64_t n,
                         const int32_t *scene_offsets, int32_t n_scenes, const float *params, const uint32_t *streams,
                         uint64_t seed, const int32_t *raw_cols, float *out_coords, float *out_feats, int64_t ldo,
-                        int32_t *n_kept, void *workspace, void *stream) {
+                        int32_t *n_kept, void *workspace, int64_t workspace_bytes, void *stream) {
+  MINK_REQUIRE(workspace_bytes >= mink_augment_workspace_bytes(n, n_scenes) || n == 0,
+               "augment_scenes: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+               (long long)mink_augment_workspace_bytes(n, n_scenes));
   MINK_REQUIRE(n >= 0 && n < (int64_t)1 << 31 && n_scenes >= 1 && C >= 1 && C <= MINK_AUG_MAX_CHANNELS && ldf >= C &&
                    ldo >= C,
                "augment_scenes: bad shape (n %lld, scenes %d, C %d, ldf %lld, ldo %lld; at most %d channels)", (long long)n,

@@ -2262,21 +2262,28 @@ int mink_conv_plan(int64_t n_rows, int32_t K, int32_t cin, int32_t cout, int32_t
 // stats_out (optional): double [<= 512][2][cout] column (sum, sum of squares) partials of y for the
 // batch norm that follows; *stats_rows receives how many partial rows were written (0: this
 // launch configuration cannot produce them and the caller reduces y itself).
-static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
+static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
                             int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, const int32_t *row_perm,
                             int64_t n_virtual, float *y, int32_t ldy, int32_t cout, const float *bias, int32_t ksplit,
-                            float *workspace, double *stats_out, int32_t *stats_rows, void *stats_ws, void *stream) {
+                            float *workspace, int64_t workspace_bytes, double *stats_out, int32_t *stats_rows, void *stats_ws,
+                            int64_t stats_ws_bytes, void *stream) {
   if (stats_rows) *stats_rows = 0;
   MINK_REQUIRE(K >= 1 && K <= KMAX, "gather_gemm: kernel volume %d unsupported", K);
-  MINK_REQUIRE(cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0, "gather_gemm: bad shape");
+  MINK_REQUIRE(cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0 && n_in >= 0, "gather_gemm: bad shape");
   MINK_REQUIRE(ksplit >= 1 && ksplit <= std::max(K, cin / BK), "gather_gemm: bad ksplit %d", ksplit);  // (offsets, or channel chunks: compact_perm_plan)
   MINK_REQUIRE(n_out * (int64_t)K < (1ll << 31), "gather_gemm: table too large");
   if (n_out == 0) return MINK_OK;
   MINK_REQUIRE(x && w && nbr && y, "gather_gemm: NULL pointer");
   MINK_REQUIRE(ksplit == 1 || workspace, "gather_gemm: split-K needs a workspace");
+  MINK_REQUIRE(ksplit == 1 || workspace_bytes >= 4ll * ksplit * n_out * cout,
+               "gather_gemm: workspace of %lld bytes, %lld needed for %d slabs of %lld x %d", (long long)workspace_bytes,
+               (long long)(4ll * ksplit * n_out * cout), ksplit, (long long)n_out, cout);
+  MINK_REQUIRE(!stats_ws || stats_ws_bytes >= mink_conv_stats_workspace_bytes(n_out, cout),
+               "gather_gemm: statistics workspace of %lld bytes, %lld needed", (long long)stats_ws_bytes,
+               (long long)mink_conv_stats_workspace_bytes(n_out, cout));
   if (!row_perm) n_virtual = n_out;
   MINK_REQUIRE(n_virtual >= n_out || (flip_k & 2), "gather_gemm: the row permutation must cover every output row");
-  ScopedTimer timer(w_transposed ? 1 : 0, /*n_in (rows of x) is not known here*/ -1, n_out, K, cin, cout, nbr, (hipStream_t)stream);
+  ScopedTimer timer(w_transposed ? 1 : 0, n_in, n_out, K, cin, cout, nbr, (hipStream_t)stream);
   GemmParams p;
   p.row_perm = row_perm, p.n_virtual = n_virtual;
   p.stagger = g_stagger;
@@ -2368,10 +2375,9 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   } else {
     const bool stage = row_perm != nullptr;
     if (vec && g_pipeline) {
-      // the flat path addresses x rows with a 24-bit multiply: the table must not name a row >= 2^24 - 1.  x's row count is
-      // not an argument here; a convolution this path is meant for (stride 1, same map) has as many input as output rows
+      // the flat path addresses x rows with a 24-bit multiply: the table must not name a row >= 2^24 - 1 (n_in bounds it)
       const bool flat = cin == 28 && zs == 1 && !flip_k && !w_transposed && !stage && g_flat && ldx <= 32 &&
-                        4ll * K * cin * cout < (1ll << 31) && n_out < (1 << 24) - 1;
+                        4ll * K * cin * cout < (1ll << 31) && n_in < (1 << 24) - 1;
 #define MINK_LAUNCH_GG2(M)                                                                          \
   do {                                                                                              \
     if (w_transposed && stage) gather_gemm2_kernel<true, true, 0, M><<<grid, 256, 0, st>>>(p);      \
@@ -2411,25 +2417,25 @@ static int gather_gemm_impl(const float *x, int32_t ldx, int32_t cin, const floa
   return MINK_OK;
 }
 
-int mink_conv_gather_gemm(const float *x, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
+int mink_conv_gather_gemm(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
                           int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, const int32_t *row_perm,
                           int64_t n_virtual, float *y, int32_t ldy, int32_t cout, const float *bias, int32_t ksplit,
-                          float *workspace, void *stream) {
-  return gather_gemm_impl(x, ldx, cin, w, w_transposed, flip_k, nbr, n_out, K, row_perm, n_virtual, y, ldy, cout, bias,
-                          ksplit, workspace, nullptr, nullptr, nullptr, stream);
+                          float *workspace, int64_t workspace_bytes, void *stream) {
+  return gather_gemm_impl(x, n_in, ldx, cin, w, w_transposed, flip_k, nbr, n_out, K, row_perm, n_virtual, y, ldy, cout, bias,
+                          ksplit, workspace, workspace_bytes, nullptr, nullptr, nullptr, 0, stream);
 }
 
 int64_t mink_conv_stats_workspace_bytes(int64_t n_out, int32_t cout) {
   return (int64_t)cdiv(n_out > 0 ? n_out : 1, 64) * 2 * cout * sizeof(float);  // (row tiles of 64: compact_gemm_kernel)
 }
 
-int mink_conv_gather_gemm_stats(const float *x, int32_t ldx, int32_t cin, const float *w, const int32_t *nbr,
+int mink_conv_gather_gemm_stats(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *w, const int32_t *nbr,
                                 int64_t n_out, int32_t K, float *y, int32_t ldy, int32_t cout, const float *bias,
-                                int32_t ksplit, float *workspace, double *stats_out, int32_t *stats_rows,
-                                void *stats_ws, void *stream) {
+                                int32_t ksplit, float *workspace, int64_t workspace_bytes, double *stats_out,
+                                int32_t *stats_rows, void *stats_ws, int64_t stats_ws_bytes, void *stream) {
   MINK_REQUIRE(stats_out && stats_rows && stats_ws, "gather_gemm_stats: NULL statistics buffers");
-  return gather_gemm_impl(x, ldx, cin, w, 0, 0, nbr, n_out, K, nullptr, 0, y, ldy, cout, bias, ksplit, workspace,
-                          stats_out, stats_rows, stats_ws, stream);
+  return gather_gemm_impl(x, n_in, ldx, cin, w, 0, 0, nbr, n_out, K, nullptr, 0, y, ldy, cout, bias, ksplit, workspace,
+                          workspace_bytes, stats_out, stats_rows, stats_ws, stats_ws_bytes, stream);
 }
 
 int64_t mink_conv_wgrad_workspace_bytes(int64_t n_out, int32_t K, int32_t cin, int32_t cout) {
@@ -2450,8 +2456,8 @@ static bool wgrad_stream_ok(int64_t n_in, int32_t ldx, int32_t cin, int32_t ldy,
 }
 
 static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
-                      const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace, const WgradFuse *fuse,
-                      void *stream) {
+                      const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace, int64_t workspace_bytes,
+                      const WgradFuse *fuse, void *stream) {
   MINK_REQUIRE(K >= 1 && K <= KMAX && cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0 && n_in >= 0,
                "wgrad: bad shape");
   MINK_REQUIRE(dw, "wgrad: NULL dw");
@@ -2464,6 +2470,10 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
   ScopedTimer timer(2, n_in, n_out, K, cin, cout, nbr, st);
   const WgradPlan pl = wgrad_plan(n_out, K, cin, cout);
   MINK_REQUIRE(pl.nsplit == 1 || workspace, "wgrad: needs a workspace");
+  // (the slab count comes from the plan, which tuning knobs can change between the caller's size query and this launch)
+  MINK_REQUIRE(pl.nsplit == 1 || workspace_bytes >= (int64_t)pl.nsplit * K * cin * cout * 4,
+               "wgrad: workspace of %lld bytes, %lld needed for the %d row splits of this plan", (long long)workspace_bytes,
+               (long long)((int64_t)pl.nsplit * K * cin * cout * 4), pl.nsplit);
   WgradParams p;
   p.x = x, p.dy = dy, p.nbr = nbr, p.out = pl.nsplit > 1 ? (float *)workspace : dw;
   p.n_out = n_out, p.rows_per_split = pl.rows_per_split, p.ldx = ldx, p.cin = cin, p.ldy = ldy, p.cout = cout, p.K = K;
@@ -2509,8 +2519,9 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
 }
 
 int mink_conv_wgrad(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *dy, int32_t ldy, int32_t cout,
-                    const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace, void *stream) {
-  return wgrad_impl(x, n_in, ldx, cin, dy, ldy, cout, nbr, n_out, K, dw, workspace, nullptr, stream);
+                    const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace, int64_t workspace_bytes,
+                    void *stream) {
+  return wgrad_impl(x, n_in, ldx, cin, dy, ldy, cout, nbr, n_out, K, dw, workspace, workspace_bytes, nullptr, stream);
 }
 
 int mink_conv_wgrad_bn_relu_pool_supported(int64_t n_in, int32_t ldx, int32_t cin, int64_t n_out, int32_t K, int32_t cout) {
@@ -2522,11 +2533,11 @@ int mink_conv_wgrad_bn_relu_pool(const float *x, int64_t n_in, int32_t ldx, int3
                                  const float *dy_pool, int64_t n_pool, const int32_t *in2out, const float *mean,
                                  const float *invstd, const float *gamma, const float *beta, const float *dgamma,
                                  const float *dbeta, const int32_t *nbr, int64_t n_out, int32_t K, float *dw,
-                                 void *workspace, void *stream) {
+                                 void *workspace, int64_t workspace_bytes, void *stream) {
   MINK_REQUIRE(y && dy_pool && in2out && mean && invstd && gamma && beta && dgamma && dbeta && n_pool >= 1,
                "wgrad_bn_relu_pool: NULL pointer");
   const WgradFuse f = {dy_pool, in2out, n_pool, mean, invstd, gamma, beta, dgamma, dbeta};
-  return wgrad_impl(x, n_in, ldx, cin, y, cout, cout, nbr, n_out, K, dw, workspace, &f, stream);
+  return wgrad_impl(x, n_in, ldx, cin, y, cout, cout, nbr, n_out, K, dw, workspace, workspace_bytes, &f, stream);
 }
 
 }  // extern "C"

@@ -539,13 +539,56 @@ using namespace mink;
 // ------------------------------------------------------------------ PeRFception data.npz front-end
 // One thread per (voxel, group of four feature columns).  links -> (batch, x, y, z); features =
 // the selected columns of [density | sh_q * sh_scale + sh_min (27) | ones] in the caller's order.
+// "xyzs" feature of the reference loader (co3d.py:209-214): every point minus the mean of ITS OWN three coordinates (the
+// reference reduces over dim=1, not over the points -- kept as it is), divided by the largest norm of the scene.  Every
+// product, sum and the division are rounded separately, in the order ((x + y) + z) / 3 and sqrt((dx^2 + dy^2) + dz^2).
+__device__ __forceinline__ float xyz_centred(int x, int y, int z, float (&d)[3]) {
+  const float fx = (float)x, fy = (float)y, fz = (float)z;
+  float s = fx + fy;
+  asm volatile("" : "+v"(s));
+  s = s + fz;
+  asm volatile("" : "+v"(s));
+  const float m = __fdiv_rn(s, 3.f);
+  d[0] = fx - m, d[1] = fy - m, d[2] = fz - m;
+  return m;
+}
+
+// per-scene max of the centred norm, as float bits (non-negative floats order like unsigned integers: atomicMax is exact
+// and order-independent)
+__global__ __launch_bounds__(kBlock) void decode_xyz_maxnorm_kernel(const int *__restrict__ links,
+                                                                    const int *__restrict__ scene_offsets, int n_scenes,
+                                                                    int64_t n, int ry, int rz,
+                                                                    unsigned *__restrict__ scene_maxnorm) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int lo = 0, hi = n_scenes;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)scene_offsets[mid] <= i) lo = mid;
+    else hi = mid;
+  }
+  const int l = links[i];
+  const int yz = ry * rz;
+  const int x = l / yz, rem = l - x * yz;
+  const int y = rem / rz, z = rem - y * rz;
+  float d[3];
+  xyz_centred(x, y, z, d);
+  float a = d[0] * d[0], b2 = d[1] * d[1], c2 = d[2] * d[2];
+  asm volatile("" : "+v"(a), "+v"(b2), "+v"(c2));
+  float s = a + b2;
+  asm volatile("" : "+v"(s));
+  s = s + c2;
+  asm volatile("" : "+v"(s));
+  atomicMax(scene_maxnorm + lo, __float_as_uint(__fsqrt_rn(s)));
+}
+
 // The de-quantisation is a separate multiply and add (no fma): bit-identical to numpy's
 // `sh.astype(float32) * sh_scale + sh_min` of the reference loader (co3d.py:160-166).
 __global__ __launch_bounds__(kBlock) void decode_plenoxel_kernel(
     const int *__restrict__ links, const float *__restrict__ density, const unsigned char *__restrict__ sh_q,
     const int *__restrict__ scene_offsets, int n_scenes, const float *__restrict__ sh_scale,
-    const float *__restrict__ sh_min, int64_t n, int ry, int rz, int col_density, int col_sh, int col_ones, int C,
-    int *__restrict__ coords, float *__restrict__ feats, int ldf, bool vec) {
+    const float *__restrict__ sh_min, int64_t n, int ry, int rz, int col_density, int col_sh, int col_ones, int col_xyzs,
+    const float *__restrict__ scene_maxnorm, int C, int *__restrict__ coords, float *__restrict__ feats, int ldf, bool vec) {
   const int groups = (C + 3) >> 2;
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= n * groups) return;
@@ -558,12 +601,15 @@ __global__ __launch_bounds__(kBlock) void decode_plenoxel_kernel(
     else hi = mid;
   }
   const int b = lo;
-  if (gq == 0) {
-    const int l = links[i];
-    const int yz = ry * rz;
-    const int x = l / yz, rem = l - x * yz;
-    const int y = rem / rz, z = rem - y * rz;
-    *reinterpret_cast<int4 *>(coords + 4 * i) = make_int4(b, x, y, z);
+  const int l = links[i];
+  const int yz = ry * rz;
+  const int x = l / yz, rem = l - x * yz;
+  const int y = rem / rz, z = rem - y * rz;
+  if (gq == 0) *reinterpret_cast<int4 *>(coords + 4 * i) = make_int4(b, x, y, z);
+  float ctr[3] = {0.f, 0.f, 0.f};
+  if (col_xyzs >= 0) {
+    const float m = xyz_centred(x, y, z, ctr);
+    (void)m;
   }
   float out[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -578,6 +624,8 @@ __global__ __launch_bounds__(kBlock) void decode_plenoxel_kernel(
       v = prod + sh_min[b * 27 + j];
     } else if (c == col_density) {
       v = density[i];
+    } else if (col_xyzs >= 0 && c >= col_xyzs && c < col_xyzs + 3) {
+      v = __fdiv_rn(ctr[c - col_xyzs], scene_maxnorm[b]);
     } else {  // c == col_ones
       v = 1.f;
     }
@@ -596,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void decode_plenoxel_kernel(
 extern "C" {
 
 const char *mink_last_error(void) { return g_err; }
-int mink_abi_version(void) { return 1; }
+int mink_abi_version(void) { return 2; }  // 2: every scratch buffer is passed with its size
 
 int64_t mink_table_capacity(int64_t n) {
   int64_t cap = 64;
@@ -659,7 +707,7 @@ int mink_coords_make_keys(const void *coords, int mode, int64_t n, int32_t out_t
 
 int mink_coords_unique(const uint64_t *keys, int64_t n, uint64_t *table_keys, int32_t *table_vals, int64_t cap,
                        int32_t *out_coords, int32_t *unique_index, int32_t *inverse, int32_t *n_unique,
-                       void *workspace, void *stream) {
+                       void *workspace, int64_t workspace_bytes, void *stream) {
   MINK_REQUIRE(n >= 0 && n < (1ll << 31) - 1, "unique: n out of range");
   MINK_REQUIRE(cap >= mink_table_capacity(n) && (cap & (cap - 1)) == 0, "unique: table capacity %lld too small for n=%lld",
                (long long)cap, (long long)n);
@@ -672,6 +720,8 @@ int mink_coords_unique(const uint64_t *keys, int64_t n, uint64_t *table_keys, in
     return MINK_OK;
   }
   MINK_REQUIRE(keys && out_coords && unique_index && inverse && workspace, "unique: NULL pointer");
+  MINK_REQUIRE(workspace_bytes >= mink_unique_workspace_bytes(n), "unique: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+               (long long)(mink_unique_workspace_bytes(n)));
   MINK_REQUIRE(((uintptr_t)out_coords & 15) == 0 && ((uintptr_t)workspace & 255) == 0, "unique: misaligned buffer");
   int rc = unique_launch(keys, n, nullptr, table_keys, table_vals, cap, out_coords, unique_index, inverse, n_unique,
                          workspace, st);
@@ -685,8 +735,10 @@ int64_t mink_levels_workspace_bytes(int64_t n) { return align_up(8 * (n > 0 ? n 
 int mink_coords_build_levels(const void *coords, int mode, int64_t n, int32_t nlev, const int32_t *out_ts_host,
                              uint64_t *const *table_keys, int32_t *const *table_vals, int64_t cap,
                              int32_t *const *out_coords, int32_t *const *index_a, int32_t *const *index_b,
-                             int32_t *meta, void *workspace, void *stream) {
+                             int32_t *meta, void *workspace, int64_t workspace_bytes, void *stream) {
   MINK_REQUIRE(n >= 1 && n < (1ll << 31) - 1 && nlev >= 1 && nlev <= 16, "build_levels: bad sizes");
+  MINK_REQUIRE(workspace_bytes >= mink_levels_workspace_bytes(n), "build_levels: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+               (long long)(mink_levels_workspace_bytes(n)));
   MINK_REQUIRE(coords && out_ts_host && table_keys && table_vals && out_coords && index_a && index_b && meta && workspace,
                "build_levels: NULL pointer");
   MINK_REQUIRE(cap >= mink_table_capacity(n) && (cap & (cap - 1)) == 0, "build_levels: table capacity too small");
@@ -817,7 +869,7 @@ int64_t mink_rulebook_workspace_bytes(int64_t n_out, int32_t K) {
 }
 
 int mink_rulebook(const int32_t *nbr, int64_t n_out, int32_t K, int32_t *counts, int32_t *pairs_in,
-                  int32_t *pairs_out, void *workspace, void *stream) {
+                  int32_t *pairs_out, void *workspace, int64_t workspace_bytes, void *stream) {
   MINK_REQUIRE(K >= 1 && K <= 27 && n_out >= 0 && counts, "rulebook: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (n_out == 0) {
@@ -825,6 +877,8 @@ int mink_rulebook(const int32_t *nbr, int64_t n_out, int32_t K, int32_t *counts,
     return MINK_OK;
   }
   MINK_REQUIRE(nbr && workspace && ((uintptr_t)workspace & 255) == 0, "rulebook: NULL/misaligned pointer");
+  MINK_REQUIRE(workspace_bytes >= mink_rulebook_workspace_bytes(n_out, K), "rulebook: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+               (long long)(mink_rulebook_workspace_bytes(n_out, K)));
   const int64_t nchunk = cdiv(n_out, kBlock);
   int *chunk_counts = (int *)workspace;
   int *chunk_offsets = (int *)((char *)workspace + align_up(4 * nchunk * K, 256));
@@ -852,8 +906,10 @@ int64_t mink_class_partition_workspace_bytes(int64_t n) {
 }
 
 int mink_class_partition(const int32_t *coords, int64_t n, int32_t ts, int32_t pad, int32_t *perm, void *workspace,
-                         void *stream) {
+                         int64_t workspace_bytes, void *stream) {
   MINK_REQUIRE(n >= 0 && ts >= 1 && pad >= 1 && perm, "class_partition: bad arguments");
+  MINK_REQUIRE(n == 0 || workspace_bytes >= mink_class_partition_workspace_bytes(n), "class_partition: workspace of %lld bytes, %lld needed",
+               (long long)workspace_bytes, (long long)mink_class_partition_workspace_bytes(n));
   hipStream_t st = (hipStream_t)stream;
   MINK_HIP(hipMemsetAsync(perm, 0xFF, sizeof(int32_t) * mink_class_partition_rows(n, pad), st));
   if (n == 0) return MINK_OK;
@@ -887,22 +943,29 @@ int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *bat
 
 int mink_decode_plenoxel(const int32_t *links, const float *density, const uint8_t *sh_q, const int32_t *scene_offsets,
                          int32_t n_scenes, const float *sh_scale, const float *sh_min, int64_t n, int32_t reso_y,
-                         int32_t reso_z, int32_t col_density, int32_t col_sh, int32_t col_ones, int32_t C, int32_t *coords,
-                         float *feats, int32_t ldf, void *stream) {
+                         int32_t reso_z, int32_t col_density, int32_t col_sh, int32_t col_ones, int32_t col_xyzs,
+                         float *scene_scratch, int32_t C, int32_t *coords, float *feats, int32_t ldf, void *stream) {
   MINK_REQUIRE(n >= 0 && n_scenes >= 1 && reso_y >= 1 && reso_z >= 1 && C >= 1 && ldf >= C, "decode_plenoxel: bad shape");
-  const int want = (col_density >= 0) + 27 * (col_sh >= 0) + (col_ones >= 0);
-  MINK_REQUIRE(want == C && col_density < C && col_ones < C && (col_sh < 0 || col_sh + 27 <= C),
-               "decode_plenoxel: the feature columns (density %d, sh %d, ones %d) do not tile %d channels", col_density,
-               col_sh, col_ones, C);
+  const int want = (col_density >= 0) + 27 * (col_sh >= 0) + (col_ones >= 0) + 3 * (col_xyzs >= 0);
+  MINK_REQUIRE(want == C && col_density < C && col_ones < C && (col_sh < 0 || col_sh + 27 <= C) && (col_xyzs < 0 || col_xyzs + 3 <= C),
+               "decode_plenoxel: the feature columns (density %d, sh %d, ones %d, xyzs %d) do not tile %d channels", col_density,
+               col_sh, col_ones, col_xyzs, C);
+  MINK_REQUIRE(col_xyzs < 0 || scene_scratch, "decode_plenoxel: the xyzs feature needs scene_scratch[n_scenes]");
   if (n == 0) return MINK_OK;
   MINK_REQUIRE(links && scene_offsets && coords && feats && (col_density < 0 || density) &&
                    (col_sh < 0 || (sh_q && sh_scale && sh_min)),
                "decode_plenoxel: NULL pointer");
   MINK_REQUIRE(((uintptr_t)coords & 15) == 0, "decode_plenoxel: coords must be 16-byte aligned");
   const int64_t threads = n * ((C + 3) / 4);
+  if (col_xyzs >= 0) {  // per-scene largest centred norm first (one extra pass over the links)
+    MINK_HIP(hipMemsetAsync(scene_scratch, 0, sizeof(float) * n_scenes, (hipStream_t)stream));
+    decode_xyz_maxnorm_kernel<<<dim3((unsigned)cdiv(n, kBlock)), kBlock, 0, (hipStream_t)stream>>>(
+        links, scene_offsets, n_scenes, n, reso_y, reso_z, (unsigned *)scene_scratch);
+    MINK_CHECK_LAUNCH();
+  }
   decode_plenoxel_kernel<<<dim3((unsigned)cdiv(threads, kBlock)), kBlock, 0, (hipStream_t)stream>>>(
-      links, density, sh_q, scene_offsets, n_scenes, sh_scale, sh_min, n, reso_y, reso_z, col_density, col_sh, col_ones, C,
-      coords, feats, ldf, ((uintptr_t)feats & 15) == 0 && (ldf & 3) == 0);
+      links, density, sh_q, scene_offsets, n_scenes, sh_scale, sh_min, n, reso_y, reso_z, col_density, col_sh, col_ones, col_xyzs,
+      scene_scratch, C, coords, feats, ldf, ((uintptr_t)feats & 15) == 0 && (ldf & 3) == 0);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

@@ -573,8 +573,10 @@ static int launch_colreduce(int mode, const float *a, const float *b, const floa
 }
 
 int mink_bn_stats(const float *x, int64_t n, int32_t C, float eps, float momentum, float *mean, float *invstd,
-                  float *running_mean, float *running_var, void *workspace, void *stream) {
+                  float *running_mean, float *running_var, void *workspace, int64_t workspace_bytes, void *stream) {
   REQ_C4(C, "bn_stats");
+  MINK_REQUIRE(workspace_bytes >= mink_bn_workspace_bytes(n, C), "bn_stats: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+               (long long)(mink_bn_workspace_bytes(n, C)));
   MINK_REQUIRE(n >= 1 && x && mean && invstd && workspace, "bn_stats: bad arguments (n=%lld)", (long long)n);
   MINK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running stats must come in pairs");
   REQ_A16(x, "bn_stats");
@@ -617,21 +619,23 @@ int mink_bn_apply(const float *x, int64_t n, int32_t C, const float *mean, const
 
 int mink_bn_fwd(const float *x, int64_t n, int32_t C, float eps, float momentum, const float *gamma, const float *beta,
                 const float *residual, int32_t relu, float *y, float *mean, float *invstd, float *running_mean,
-                float *running_var, void *workspace, void *stream) {
+                float *running_var, void *workspace, int64_t workspace_bytes, void *stream) {
   REQ_C4(C, "bn_fwd");
   MINK_REQUIRE(n >= 1 && x && gamma && beta && y && mean && invstd, "bn_fwd: bad arguments (n=%lld)", (long long)n);
   MINK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_fwd: running stats must come in pairs");
   REQ_A16(x, "bn_fwd");
   REQ_A16(y, "bn_fwd");
-  int rc = mink_bn_stats(x, n, C, eps, momentum, mean, invstd, running_mean, running_var, workspace, stream);
+  int rc = mink_bn_stats(x, n, C, eps, momentum, mean, invstd, running_mean, running_var, workspace, workspace_bytes, stream);
   if (rc) return rc;
   return mink_bn_apply(x, n, C, mean, invstd, gamma, beta, residual, relu, y, stream);
 }
 
 int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int32_t C, const float *mean,
                 const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual, float *dgamma,
-                float *dbeta, void *workspace, void *stream) {
+                float *dbeta, void *workspace, int64_t workspace_bytes, void *stream) {
   REQ_C4(C, "bn_bwd");
+  MINK_REQUIRE(workspace_bytes >= mink_bn_workspace_bytes(n, C), "bn_bwd: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+               (long long)(mink_bn_workspace_bytes(n, C)));
   MINK_REQUIRE(n >= 1 && dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace,
                "bn_bwd: bad arguments");
   MINK_REQUIRE(!relu || y, "bn_bwd: fused ReLU needs the forward output");
@@ -653,8 +657,10 @@ int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int3
 }
 
 int mink_bn_reduce(int32_t mode, const float *a, const float *b, const float *y, int64_t n, int32_t C, const float *mean,
-                   const float *invstd, double *sums, void *workspace, void *stream) {
+                   const float *invstd, double *sums, void *workspace, int64_t workspace_bytes, void *stream) {
   REQ_C4(C, "bn_reduce");
+  MINK_REQUIRE(workspace_bytes >= mink_bn_workspace_bytes(n, C), "bn_reduce: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+               (long long)(mink_bn_workspace_bytes(n, C)));
   MINK_REQUIRE((mode == 0 || mode == 1) && n >= 1 && a && sums && workspace, "bn_reduce: bad arguments");
   MINK_REQUIRE(mode == 0 || (b && mean && invstd), "bn_reduce: mode 1 needs x, mean and invstd");
   REQ_A16(a, "bn_reduce");
@@ -710,8 +716,10 @@ int mink_bn_relu_pool_fwd(const float *x, int32_t C, const float *mean, const fl
 
 int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32_t C, const float *mean,
                           const float *invstd, const float *gamma, const float *beta, const int32_t *in2out, float *dx,
-                          float *dgamma, float *dbeta, void *workspace, void *stream) {
+                          float *dgamma, float *dbeta, void *workspace, int64_t workspace_bytes, void *stream) {
   REQ_C4(C, "bn_relu_pool_bwd");
+  MINK_REQUIRE(workspace_bytes >= mink_bn_workspace_bytes(n, C), "bn_relu_pool_bwd: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+               (long long)(mink_bn_workspace_bytes(n, C)));
   MINK_REQUIRE(n >= 1 && dy_pool && x && mean && invstd && gamma && beta && in2out && dgamma && dbeta && workspace,
                "bn_relu_pool_bwd: bad arguments");
   REQ_A16(dy_pool, "bn_relu_pool_bwd");

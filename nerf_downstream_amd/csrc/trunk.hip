@@ -50,25 +50,27 @@ int order_after(hipStream_t waiter, hipStream_t producer, int slot) {
   } while (0)
 
 // y = conv(x) and the batch statistics of y (from the convolution's own epilogue when the launch shape allows)
-int conv_stats(const MinkConvLayer &c, const MinkNormLayer &nm, const float *x, int64_t n_out, float *y, void *ws_base,
+int conv_stats(const MinkConvLayer &c, const MinkNormLayer &nm, const float *x, int64_t n_in, int64_t n_out, float *y, void *ws_base,
                int64_t ws_bytes, hipStream_t st) {
   Scratch ws(ws_base, ws_bytes);
   const int ksplit = mink_conv_plan(n_out, c.K, c.cin, c.cout, 0);
-  float *slabs = ksplit > 1 ? (float *)ws.take(4ll * ksplit * n_out * c.cout) : nullptr;
-  void *stats_ws = ws.take(mink_conv_stats_workspace_bytes(n_out, c.cout));
+  const int64_t slab_bytes = ksplit > 1 ? 4ll * ksplit * n_out * c.cout : 0, stats_bytes = mink_conv_stats_workspace_bytes(n_out, c.cout);
+  float *slabs = ksplit > 1 ? (float *)ws.take(slab_bytes) : nullptr;
+  void *stats_ws = ws.take(stats_bytes);
   double *partial = (double *)ws.take(512ll * 2 * c.cout * sizeof(double));
   MINK_REQUIRE((ksplit == 1 || slabs) && stats_ws && partial, "block: scratch too small for a %lld x %d convolution",
                (long long)n_out, c.cout);
   int32_t rows = 0;
-  TRY(mink_conv_gather_gemm_stats(x, c.cin, c.cin, c.w, c.nbr, n_out, c.K, y, c.cout, c.cout, nullptr, ksplit, slabs,
-                                  partial, &rows, stats_ws, st));
+  TRY(mink_conv_gather_gemm_stats(x, n_in, c.cin, c.cin, c.w, c.nbr, n_out, c.K, y, c.cout, c.cout, nullptr, ksplit, slabs, slab_bytes,
+                                  partial, &rows, stats_ws, stats_bytes, st));
   const float mom = nm.running_mean ? nm.momentum : 0.f;
   if (rows > 0)
     return mink_bn_stats_from_partials(partial, rows, n_out, c.cout, nm.eps, mom, nm.mean, nm.invstd, nm.running_mean,
                                        nm.running_var, st);
-  void *bn_ws = ws.take(mink_bn_workspace_bytes(n_out, c.cout));
+  const int64_t bn_bytes = mink_bn_workspace_bytes(n_out, c.cout);
+  void *bn_ws = ws.take(bn_bytes);
   MINK_REQUIRE(bn_ws, "block: scratch too small for batch-norm statistics");
-  return mink_bn_stats(y, n_out, c.cout, nm.eps, mom, nm.mean, nm.invstd, nm.running_mean, nm.running_var, bn_ws, st);
+  return mink_bn_stats(y, n_out, c.cout, nm.eps, mom, nm.mean, nm.invstd, nm.running_mean, nm.running_var, bn_ws, bn_bytes, st);
 }
 
 struct Lane {  // a stream and what is left of its scratch buffer
@@ -88,24 +90,26 @@ int conv_backward(const MinkConvLayer &c, const float *x, int64_t n_in, int64_t 
     const int64_t need = mink_conv_wgrad_workspace_bytes(n_out, c.K, c.cin, c.cout);
     void *slabs = need > 0 ? ws.take(need) : nullptr;
     MINK_REQUIRE(need == 0 || slabs, "block: weight-gradient scratch too small");
-    TRY(mink_conv_wgrad(x, n_in, c.cin, c.cin, gy, c.cout, c.cout, c.nbr, n_out, c.K, c.dw, slabs, weight.st));
+    TRY(mink_conv_wgrad(x, n_in, c.cin, c.cin, gy, c.cout, c.cout, c.nbr, n_out, c.K, c.dw, slabs, need, weight.st));
   }
   if (!gx) return MINK_OK;
   Scratch ws(data.ws, data.bytes);
   if (c.stride == 1) {  // centred odd kernel: the transposed table is the table with the offsets flipped
     const int ksplit = mink_conv_plan(n_out, c.K, c.cout, c.cin, 0);
-    float *slabs = ksplit > 1 ? (float *)ws.take(4ll * ksplit * n_out * c.cin) : nullptr;
+    const int64_t slab_bytes = ksplit > 1 ? 4ll * ksplit * n_out * c.cin : 0;
+    float *slabs = ksplit > 1 ? (float *)ws.take(slab_bytes) : nullptr;
     MINK_REQUIRE(ksplit == 1 || slabs, "block: data-gradient scratch too small");
-    return mink_conv_gather_gemm(gy, c.cout, c.cout, c.w, 1, 1, c.nbr, n_out, c.K, nullptr, 0, gx, c.cin, c.cin, nullptr,
-                                 ksplit, slabs, data.st);
+    return mink_conv_gather_gemm(gy, n_out, c.cout, c.cout, c.w, 1, 1, c.nbr, n_out, c.K, nullptr, 0, gx, c.cin, c.cin, nullptr,
+                                 ksplit, slabs, slab_bytes, data.st);
   }
   MINK_REQUIRE(c.nbr_t, "block: a strided convolution needs its transposed table for the data gradient");
   const int64_t rows = c.perm ? c.n_perm : n_in;
   const int ksplit = mink_conv_plan(rows, c.K, c.cout, c.cin, c.perm ? 1 : 0);
-  float *slabs = ksplit > 1 ? (float *)ws.take(4ll * ksplit * n_in * c.cin) : nullptr;
+  const int64_t slab_bytes = ksplit > 1 ? 4ll * ksplit * n_in * c.cin : 0;
+  float *slabs = ksplit > 1 ? (float *)ws.take(slab_bytes) : nullptr;
   MINK_REQUIRE(ksplit == 1 || slabs, "block: data-gradient scratch too small");
-  return mink_conv_gather_gemm(gy, c.cout, c.cout, c.w, 1, 0, c.nbr_t, n_in, c.K, c.perm, c.perm ? c.n_perm : 0, gx, c.cin,
-                               c.cin, nullptr, ksplit, slabs, data.st);
+  return mink_conv_gather_gemm(gy, n_out, c.cout, c.cout, c.w, 1, 0, c.nbr_t, n_in, c.K, c.perm, c.perm ? c.n_perm : 0, gx, c.cin,
+                               c.cin, nullptr, ksplit, slabs, slab_bytes, data.st);
 }
 
 int check_conv(const MinkConvLayer &c, const char *what, bool backward) {
@@ -176,7 +180,7 @@ int mink_stem_forward(const MinkStem *s, const MinkExec *ex) {
   TRY(check_norm(s->norm, "stem_forward", false));
   MINK_REQUIRE(s->x && s->y && s->out && s->nbr_pool && s->n >= 1 && s->n_pool >= 1, "stem_forward: bad arguments");
   hipStream_t st = (hipStream_t)ex->compute;
-  TRY(conv_stats(s->conv, s->norm, s->x, s->n, s->y, ex->ws_compute, ex->ws_bytes, st));
+  TRY(conv_stats(s->conv, s->norm, s->x, s->n, s->n, s->y, ex->ws_compute, ex->ws_bytes, st));
   return mink_bn_relu_pool_fwd(s->y, s->conv.cout, s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta, s->nbr_pool,
                                s->n_pool, 8, s->out, st);
 }
@@ -193,11 +197,11 @@ int mink_stem_backward(const MinkStem *s, const MinkExec *ex) {
   void *slabs = need > 0 ? ws.take(need) : nullptr;
   MINK_REQUIRE(bn_ws && (need == 0 || slabs), "stem_backward: scratch too small");
   TRY(mink_bn_relu_pool_bwd(s->g_out, s->y, s->n, s->conv.cout, s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta,
-                            s->in2out, nullptr, s->norm.dgamma, s->norm.dbeta, bn_ws, st));
+                            s->in2out, nullptr, s->norm.dgamma, s->norm.dbeta, bn_ws, mink_bn_workspace_bytes(s->n, s->conv.cout), st));
   // the gradient w.r.t. the convolution output is recomputed inside the weight-gradient kernel's operand load
   return mink_conv_wgrad_bn_relu_pool(s->x, s->n, s->conv.cin, s->conv.cin, s->y, s->conv.cout, s->g_out, s->n_pool, s->in2out,
                                       s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta, s->norm.dgamma,
-                                      s->norm.dbeta, s->conv.nbr, s->n, s->conv.K, s->conv.dw, slabs, st);
+                                      s->norm.dbeta, s->conv.nbr, s->n, s->conv.K, s->conv.dw, slabs, need, st);
 }
 
 int mink_block_forward(const MinkBasicBlock *b, const MinkExec *ex) {
@@ -220,13 +224,13 @@ int mink_block_forward(const MinkBasicBlock *b, const MinkExec *ex) {
     TRY(check_norm(b->normd, "block_forward downsample norm", false));
     MINK_REQUIRE(b->yd && b->sd && b->down.cout == C && b->down.cin == b->conv1.cin, "block_forward: bad downsample path");
     TRY(order_after(br, st, 0));  // x is ready
-    TRY(conv_stats(b->down, b->normd, b->x, b->n_out, b->yd, br == st ? ex->ws_compute : ex->ws_branch, ex->ws_bytes, br));
+    TRY(conv_stats(b->down, b->normd, b->x, b->n_in, b->n_out, b->yd, br == st ? ex->ws_compute : ex->ws_branch, ex->ws_bytes, br));
     TRY(mink_bn_apply(b->yd, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, b->normd.beta, nullptr, 0, b->sd, br));
     shortcut = b->sd;
   }
-  TRY(conv_stats(b->conv1, b->norm1, b->x, b->n_out, b->y1, ex->ws_compute, ex->ws_bytes, st));
+  TRY(conv_stats(b->conv1, b->norm1, b->x, b->n_in, b->n_out, b->y1, ex->ws_compute, ex->ws_bytes, st));
   TRY(mink_bn_apply(b->y1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, b->norm1.beta, nullptr, 1, b->h1, st));
-  TRY(conv_stats(b->conv2, b->norm2, b->h1, b->n_out, b->y2, ex->ws_compute, ex->ws_bytes, st));
+  TRY(conv_stats(b->conv2, b->norm2, b->h1, b->n_out, b->n_out, b->y2, ex->ws_compute, ex->ws_bytes, st));
   if (down) TRY(order_after(st, br, 1));
   return mink_bn_apply(b->y2, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, b->norm2.beta, shortcut, 1, b->out, st);
 }
@@ -255,7 +259,7 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
   const bool want_gx = b->g_x != nullptr;
   // out = relu(norm2(y2) + shortcut)
   TRY(mink_bn_bwd(b->g_out, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, 1, g_y2, g_res,
-                  b->norm2.dgamma, b->norm2.dbeta, compute.ws, st));
+                  b->norm2.dgamma, b->norm2.dbeta, compute.ws, bn_bytes, st));
   // ONE event on the compute stream hands g_y2 / g_res to both auxiliary streams (every event record or wait on the
   // compute stream is a barrier packet in the chain of small dependent kernels)
   const bool aux = wst != st || (down && br != st);
@@ -271,7 +275,7 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
     // (on one stream the branch shares the compute scratch: its batch-norm partials sit behind the main chain's)
     const Lane bl = br == st ? branch.after(bn_bytes) : branch;
     TRY(mink_bn_bwd(g_res, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
-                    b->normd.dgamma, b->normd.dbeta, bl.ws, br));
+                    b->normd.dgamma, b->normd.dbeta, bl.ws, bn_bytes, br));
     const Lane rest_b = bl.after(bn_bytes);
     if (want_gx) {
       // The shortcut convolution (kernel volume 1, stride 2) reaches only the input voxels that sit on an output
@@ -286,7 +290,7 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
   const Lane rest = compute.after(2 * bn_bytes);
   TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, -1));
   TRY(mink_bn_bwd(g_h1, b->y1, b->h1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr,
-                  b->norm1.dgamma, b->norm1.dbeta, compute.ws, st));
+                  b->norm1.dgamma, b->norm1.dbeta, compute.ws, bn_bytes, st));
   TRY(conv_backward(b->conv1, b->x, b->n_in, b->n_out, g_y1, want_gx ? (down ? b->g_x : g_xa) : nullptr, rest, weight, 5));
   if (!want_gx) return MINK_OK;
   if (!down) return mink_eltwise(g_xa, g_res, ni, 2, b->g_x, st);

@@ -236,7 +236,7 @@ class CoordinateManager:
         check(
             L.mink_coords_unique(
                 keys.data_ptr(), n, lev.tkeys.data_ptr(), lev.tvals.data_ptr(), lev.cap, coords.data_ptr(),
-                uidx.data_ptr(), inv.data_ptr(), meta.data_ptr(), ws.data_ptr(), _stream(),
+                uidx.data_ptr(), inv.data_ptr(), meta.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
             )
         )
         nu, status = meta.tolist()  # the one host sync of this level
@@ -284,7 +284,7 @@ class CoordinateManager:
                 fc.data_ptr(), mode, n, nlev, (ctypes.c_int32 * nlev)(*ts_list),
                 arr([tkeys[l].data_ptr() for l in range(nlev)]), arr([tvals[l].data_ptr() for l in range(nlev)]), cap,
                 arr([coords[l].data_ptr() for l in range(nlev)]), arr([index_a.data_ptr()] + [None] * (nlev - 1)),
-                arr([index_b[l].data_ptr() for l in range(nlev)]), meta.data_ptr(), ws.data_ptr(), _stream(),
+                arr([index_b[l].data_ptr() for l in range(nlev)]), meta.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
             )
         )
         meta_host = torch.empty(nlev + 2, dtype=torch.int32, pin_memory=True)
@@ -415,7 +415,7 @@ class CoordinateManager:
         pin = torch.empty(max(n_out * K, 1), dtype=torch.int32, device=self.device)
         pout = torch.empty(max(n_out * K, 1), dtype=torch.int32, device=self.device)
         check(
-            L.mink_rulebook(nbr.data_ptr(), n_out, K, counts.data_ptr(), pin.data_ptr(), pout.data_ptr(), ws.data_ptr(), _stream())
+            L.mink_rulebook(nbr.data_ptr(), n_out, K, counts.data_ptr(), pin.data_ptr(), pout.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         )
         c = counts.tolist()
         return {k: torch.stack([pin[c[k] : c[k + 1]], pout[c[k] : c[k + 1]]]) for k in range(K) if c[k + 1] > c[k]}
@@ -439,7 +439,7 @@ class CoordinateManager:
             L, lev = lib(), self.levels[key.ts]
             perm = torch.empty(int(L.mink_class_partition_rows(lev.n, pad)), dtype=torch.int32, device=self.device)
             ws = torch.empty(int(L.mink_class_partition_workspace_bytes(lev.n)), dtype=torch.uint8, device=self.device)
-            check(L.mink_class_partition(lev.coords.data_ptr(), lev.n, key.ts, pad, perm.data_ptr(), ws.data_ptr(), _stream()))
+            check(L.mink_class_partition(lev.coords.data_ptr(), lev.n, key.ts, pad, perm.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
             self.tables[ck] = perm
             self._note_lazy(perm)
         return self.tables[ck]

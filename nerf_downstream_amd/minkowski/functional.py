@@ -167,17 +167,18 @@ def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, ro
         rows = ctypes.c_int32(0)
         check(
             L.mink_conv_gather_gemm_stats(
-                x.data_ptr(), x.stride(0), cin, w.data_ptr(), nbr.data_ptr(), n_out, K, y.data_ptr(), cout, cout,
-                _ptr(bias), ksplit, _ptr(ws), partial.data_ptr(), ctypes.addressof(rows), sws.data_ptr(), _stream(),
+                x.data_ptr(), x.shape[0], x.stride(0), cin, w.data_ptr(), nbr.data_ptr(), n_out, K, y.data_ptr(), cout, cout,
+                _ptr(bias), ksplit, _ptr(ws), 0 if ws is None else ws.numel(), partial.data_ptr(), ctypes.addressof(rows), sws.data_ptr(),
+                sws.numel(), _stream(),
             )
         )
         partial = partial[: rows.value] if rows.value > 0 else None
     else:
         check(
             L.mink_conv_gather_gemm(
-                x.data_ptr(), x.stride(0), cin, w.data_ptr(), int(w_transposed), int(flip_k), nbr.data_ptr(), n_out, K,
+                x.data_ptr(), x.shape[0], x.stride(0), cin, w.data_ptr(), int(w_transposed), int(flip_k), nbr.data_ptr(), n_out, K,
                 _ptr(row_perm), 0 if row_perm is None else row_perm.numel(),
-                y.data_ptr(), cout, cout, _ptr(bias), ksplit, _ptr(ws), _stream(),
+                y.data_ptr(), cout, cout, _ptr(bias), ksplit, _ptr(ws), 0 if ws is None else ws.numel(), _stream(),
             )
         )
     return (y, partial) if stats else y
@@ -211,7 +212,7 @@ def conv_wgrad(x, dy, nbr, kernel_shape, out=None, on=None):
     check(
         L.mink_conv_wgrad(
             x.data_ptr(), x.shape[0], x.stride(0), cin, dy.data_ptr(), dy.stride(0), cout, nbr.data_ptr(), n_out, K,
-            dw.data_ptr(), ws.data_ptr(), raw,
+            dw.data_ptr(), ws.data_ptr(), ws.numel(), raw,
         )
     )
     return dw
@@ -592,7 +593,7 @@ def _bn_statistics(L, x, n, C, eps, momentum, running_mean, running_var, partial
         check(
             L.mink_bn_stats(
                 x.data_ptr(), n, C, eps, mom, mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
-                ws.data_ptr(), _stream(),
+                ws.data_ptr(), ws.numel(), _stream(),
             )
         )
     return mean, invstd
@@ -619,7 +620,7 @@ class BatchNormFunction(torch.autograd.Function):
                 L.mink_bn_fwd(
                     x.data_ptr(), n, C, eps, momentum if running_mean is not None else 0.0, gamma.data_ptr(), beta.data_ptr(),
                     _ptr(residual), int(relu), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
-                    _ptr(running_var), ws.data_ptr(), _stream(),
+                    _ptr(running_var), ws.data_ptr(), ws.numel(), _stream(),
                 )
             )
         else:
@@ -663,7 +664,7 @@ class BatchNormFunction(torch.autograd.Function):
         check(
             L.mink_bn_bwd(
                 gy.data_ptr(), x.data_ptr(), _ptr(y), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                int(ctx.relu), gx.data_ptr(), _ptr(gres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(),
+                int(ctx.relu), gx.data_ptr(), _ptr(gres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
             )
         )
         if views is not None:  # written in place into the reducer's buffer: nothing for autograd to accumulate
@@ -691,7 +692,7 @@ class SyncBatchNormFunction(torch.autograd.Function):
         buf = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
         buf[2 * C] = float(n)
         ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
-        check(L.mink_bn_reduce(0, x.data_ptr(), None, None, n, C, None, None, buf.data_ptr(), ws.data_ptr(), _stream()))
+        check(L.mink_bn_reduce(0, x.data_ptr(), None, None, n, C, None, None, buf.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
         dist.all_reduce(buf, group=group)
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -725,7 +726,7 @@ class SyncBatchNormFunction(torch.autograd.Function):
         ws = _scratch(L.mink_bn_workspace_bytes(n, C), dev, "bn")
         check(
             L.mink_bn_reduce(1, gy.data_ptr(), x.data_ptr(), _ptr(y), n, C, mean.data_ptr(), invstd.data_ptr(),
-                             sums.data_ptr(), ws.data_ptr(), _stream())
+                             sums.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
         )
         dbeta, dgamma = sums[:C].float(), sums[C:].float()  # local sums: averaged later with the other grads
         dist.all_reduce(sums, group=ctx.group)
@@ -784,7 +785,7 @@ class BNReLUSumPoolFunction(torch.autograd.Function):
         check(
             L.mink_bn_relu_pool_bwd(
                 gy.data_ptr(), x.data_ptr(), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                ctx.in2out.data_ptr(), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(),
+                ctx.in2out.data_ptr(), gx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
             )
         )
         return gx, dgamma, dbeta, None, None, None, None, None, None, None, None
@@ -844,7 +845,7 @@ class ConvBNReLUSumPoolFunction(torch.autograd.Function):
         check(
             L.mink_bn_relu_pool_bwd(
                 gy.data_ptr(), y.data_ptr(), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                ctx.in2out.data_ptr(), None, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream(),
+                ctx.in2out.data_ptr(), None, dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), _stream(),
             )
         )
         nbr = ctx.nbr
@@ -857,7 +858,7 @@ class ConvBNReLUSumPoolFunction(torch.autograd.Function):
             L.mink_conv_wgrad_bn_relu_pool(
                 x.data_ptr(), x.shape[0], x.stride(0), x.shape[1], y.data_ptr(), C, gy.data_ptr(), gy.shape[0],
                 ctx.in2out.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                dgamma.data_ptr(), dbeta.data_ptr(), nbr.data_ptr(), n, K, gw.data_ptr(), wws.data_ptr(), _stream(),
+                dgamma.data_ptr(), dbeta.data_ptr(), nbr.data_ptr(), n, K, gw.data_ptr(), wws.data_ptr(), wws.numel(), _stream(),
             )
         )
         if _GRAD_SINK is not None and hasattr(_GRAD_SINK, "flush"):

@@ -286,13 +286,16 @@ class MinkowskiPReLU(nn.Module):
 
 class MinkowskiInstanceNorm(nn.Module):
     """ME.MinkowskiInstanceNorm(num_features) (reference modules/common.py:25-26): every batch sample's voxels are
-    normalised per channel by that sample's own mean / biased variance (eps 1e-6), then scaled and shifted by
-    `weight` (ones) / `bias` (zeros).  The rows of one sample are contiguous, so each sample is one batch-norm pass
-    (training-mode statistics, no running buffers) over its row range."""
+    normalised per channel by that sample's own mean / biased variance, then scaled and shifted by `weight` (ones) /
+    `bias` (zeros).  The rows of one sample are contiguous, so each sample is one batch-norm pass (training-mode
+    statistics, no running buffers) over its row range.
+    eps: ME's instance norm divides by sqrt(var + 1e-8) [ME-recall of MinkowskiInstanceNormFunction; parity unpinned: ME
+    is absent and the reference holds no fixture for this layer -- it is only named by the layer factory, not used by a
+    shipped model]; the value is an attribute so a caller that knows better can set it."""
 
     def __init__(self, num_features):
         super().__init__()
-        self.num_features, self.eps = num_features, 1e-6
+        self.num_features, self.eps = num_features, 1e-8
         self.weight = nn.Parameter(torch.ones(1, num_features))
         self.bias = nn.Parameter(torch.zeros(1, num_features))
 

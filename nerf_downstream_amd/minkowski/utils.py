@@ -45,22 +45,25 @@ def decode_plenoxel_batch(batch, reso=None):
         raise RuntimeError("decode_plenoxel_batch runs on the GPU: move the batch to cuda first")
     reso = tuple(reso or batch.get("reso") or (128, 128, 128))  # data.npz: 128^3; last.ckpt scenes: 256^3
     names = list(batch["feature_names"])
-    width = {"density": 1, "sh": 27, "ones": 1}
-    col, C = {"density": -1, "sh": -1, "ones": -1}, 0
+    width = {"density": 1, "sh": 27, "ones": 1, "xyzs": 3}
+    col, C = {"density": -1, "sh": -1, "ones": -1, "xyzs": -1}, 0
     for f in names:
         if f not in width or col[f] >= 0:
-            raise ValueError(f"feature {f!r} cannot be decoded on the GPU (supported once each: density, sh, ones)")
+            raise ValueError(f"feature {f!r} cannot be decoded on the GPU (supported once each: xyzs, density, sh, ones)")
         col[f] = C
         C += width[f]
     n = links.shape[0]
     coords = torch.empty(n, 4, dtype=torch.int32, device=links.device)
     feats = torch.empty(n, C, dtype=torch.float32, device=links.device)
+    n_scenes = batch["scene_offsets"].numel() - 1
+    scratch = torch.empty(n_scenes, dtype=torch.float32, device=links.device) if col["xyzs"] >= 0 else None  # per-scene max norm
     stream = torch._C._cuda_getCurrentRawStream(links.device.index)
     check(
         lib().mink_decode_plenoxel(
             links.data_ptr(), batch["density"].data_ptr(), batch["sh_q"].data_ptr(), batch["scene_offsets"].data_ptr(),
             batch["scene_offsets"].numel() - 1, batch["sh_scale"].data_ptr(), batch["sh_min"].data_ptr(), n, reso[1], reso[2],
-            col["density"], col["sh"], col["ones"], C, coords.data_ptr(), feats.data_ptr(), C, stream,
+            col["density"], col["sh"], col["ones"], col["xyzs"], None if scratch is None else scratch.data_ptr(), C,
+            coords.data_ptr(), feats.data_ptr(), C, stream,
         )
     )
     return coords, feats
@@ -104,7 +107,7 @@ def augment_batch(coords, feats, scene_offsets, params, streams, seed, raw_cols,
             coords.data_ptr(), int(coords.dtype == torch.int32), feats.data_ptr(), C, C, n,
             offs.data_ptr(), n_scenes, params.data_ptr(), strm.data_ptr(),
             int(seed) & (2 ** 64 - 1), ctypes.cast(cols, ctypes.c_void_p), out_c.data_ptr(), out_f.data_ptr(), C,
-            kept.data_ptr(), ws.data_ptr(), stream,
+            kept.data_ptr(), ws.data_ptr(), ws.numel(), stream,
         )
     )
     # column 37 = MINK_AUG_DROPOUT: without dropout every voxel survives and the count is known on the host

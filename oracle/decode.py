@@ -19,7 +19,14 @@ def decode_batch(scenes, features=("density", "sh"), reso=(128, 128, 128)):
         coords.append(np.concatenate([np.full((len(links), 1), b, np.int64), xyz], 1).astype(np.int32))
         sh = np.asarray(s["sh_q"]).astype(np.float32) * np.float32(1) * np.asarray(s["sh_scale"], np.float32) \
             + np.asarray(s["sh_min"], np.float32)
+        # "xyzs" (co3d.py:209-214): each point minus the mean of ITS OWN three coordinates (the reference reduces over dim=1),
+        # divided by the largest norm of the scene; float32, every operation rounded separately, in this order
+        f = xyz.astype(np.float32)
+        m = ((f[:, 0] + f[:, 1]) + f[:, 2]) / np.float32(3)
+        d = f - m[:, None]
+        nrm = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+        xyzs = (d / nrm.max()).astype(np.float32) if len(links) else d
         cols = {"density": np.asarray(s["density"], np.float32).reshape(-1, 1), "sh": sh.astype(np.float32),
-                "ones": np.ones((len(links), 1), np.float32)}
+                "ones": np.ones((len(links), 1), np.float32), "xyzs": xyzs}
         feats.append(np.concatenate([cols[f] for f in features], 1).astype(np.float32))
     return np.concatenate(coords), np.concatenate(feats)

@@ -410,11 +410,11 @@ class MinkowskiPReLU(nn.Module):
 
 
 class MinkowskiInstanceNorm(nn.Module):
-    """ME.MinkowskiInstanceNorm: per batch sample and channel, (x - mean) / sqrt(biased var + 1e-6) * weight + bias."""
+    """ME.MinkowskiInstanceNorm: per batch sample and channel, (x - mean) / sqrt(biased var + 1e-8) * weight + bias [ME-recall; parity unpinned]."""
 
     def __init__(self, num_features):
         super().__init__()
-        self.eps = 1e-6
+        self.eps = 1e-8
         self.weight = nn.Parameter(torch.ones(1, num_features))
         self.bias = nn.Parameter(torch.zeros(1, num_features))
 

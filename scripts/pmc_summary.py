@@ -27,5 +27,11 @@ for (name, grid), d in agg.items():
     res.append(e)
 res.sort(key=lambda e: -e.get("GRBM_GUI_ACTIVE", e.get("FETCH_SIZE", 0)))
 json.dump(res, open(out, "w"), indent=1)
+# provenance sidecar: bench.py reports it next to roofline.traffic (the GPU box has no .git: the caller passes GIT_HEAD)
+import os
+
+head = os.environ.get("GIT_HEAD", "").strip()
+json.dump({"tag": os.path.basename(out).replace("_pmc.json", "").replace(".json", ""), "git_head": head or "unknown"},
+          open(out.replace(".json", ".meta.json"), "w"), indent=1)
 for e in res[:16]:
     print({k: e[k] for k in ("kernel", "workgroups", "launches", "hbm_traffic_bytes_per_launch", "mfma_pipe_util") if k in e})

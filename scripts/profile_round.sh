@@ -1,10 +1,11 @@
 #!/bin/bash
 # Round profile on the GPU box: kernel trace + stats of the default bench, then separate PMC passes
-# (TCC read / TCC write / SQ+GRBM) as MI355X_MICROARCH.md prescribes.  usage: scripts/profile_round.sh <tag>
+# (TCC read / TCC write / SQ+GRBM) as MI355X_MICROARCH.md prescribes.  usage: GIT_HEAD=$(git rev-parse --short HEAD) scripts/profile_round.sh <tag>
 set -o pipefail
 tag=${1:-r01_v6}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/$tag
+# (GIT_HEAD=<commit> in the environment is recorded next to the PMC summary: the box has no .git)
 mkdir -p $out
 rocprofv3 --kernel-trace --stats -d $out/trace -o bench --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/trace.log 2>&1 || exit 1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do

@@ -23,7 +23,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f"{n} declared in mink_hip.h but not exported"
     handle = _lib.lib()
-    assert handle.mink_abi_version() == 1
+    assert handle.mink_abi_version() == 2  # 2: every scratch buffer travels with its size
     # pure host helpers can run without a GPU
     assert handle.mink_table_capacity(1000) == 2048
     assert handle.mink_conv_plan_ksplit(1_000_000, 27, 64, 0) == 1
@@ -40,3 +40,37 @@ def test_argument_validation_without_gpu():
     assert L.mink_kernel_map(None, None, 64, None, 5, None, 28, None, None, None) == -1
     assert L.mink_bn_apply(None, 4, 6, None, None, None, None, None, 0, None, None) == -1
     assert b"multiple of 4" in L.mink_last_error()
+
+
+def test_undersized_workspace_is_refused_before_any_launch():
+    """ABI v2: the size of a scratch buffer is an argument, checked against the plan the call is about to launch.  The
+    split factors / row splits of a convolution depend on planner state (tuning knobs), so a size cached by the caller
+    for another plan used to be written past; now it is MINK_EINVAL.  Dummy non-NULL pointers: the check comes before
+    the first launch, so this runs without a GPU."""
+    from nerf_downstream_amd import _lib
+
+    L = _lib.lib()
+    P = 0x10000  # aligned, never dereferenced
+    # weight gradient of a mid layer: the plan wants row-split slabs
+    n_out, K, cin, cout = 40000, 27, 64, 64
+    need = L.mink_conv_wgrad_workspace_bytes(n_out, K, cin, cout)
+    assert need > 0
+    assert L.mink_conv_wgrad(P, n_out, cin, cin, P, cout, cout, P, n_out, K, P, P, need - 1, None) == -1
+    assert b"workspace" in L.mink_last_error() and str(need).encode() in L.mink_last_error()
+    # ... and a size that was right for the default plan is too small once a knob asks for more row splits
+    old = L.mink_conv_set_stagger((2 << 12) | (200 << 16))  # force G = 3 and 200 row splits (scripts/kbench.py wsweep)
+    try:
+        assert L.mink_conv_wgrad_workspace_bytes(n_out, K, cin, cout) > need
+        assert L.mink_conv_wgrad(P, n_out, cin, cin, P, cout, cout, P, n_out, K, P, P, need, None) == -1
+        assert b"row splits of this plan" in L.mink_last_error()
+    finally:
+        L.mink_conv_set_stagger(old)
+    # split-K forward: slabs
+    assert L.mink_conv_gather_gemm(P, 512, 64, 64, P, 0, 0, P, 512, 27, None, 0, P, 64, 64, None, 4, P, 4 * 4 * 512 * 64 - 1, None) == -1
+    assert b"slabs" in L.mink_last_error()
+    # batch norm backward / statistics, coordinate pyramid, class partition
+    assert L.mink_bn_bwd(P, P, P, 1000, 64, P, P, P, 1, P, None, P, P, P, L.mink_bn_workspace_bytes(1000, 64) - 1, None) == -1
+    assert b"workspace" in L.mink_last_error()
+    assert L.mink_bn_stats(P, 1000, 64, 1e-5, 0.1, P, P, None, None, P, 16, None) == -1
+    assert L.mink_class_partition(P, 1000, 2, 128, P, P, 8, None) == -1
+    assert b"workspace" in L.mink_last_error()

@@ -140,7 +140,7 @@ def test_prelu_and_instance_norm_match_torch(nparam):
     for k in sizes:
         seg = xr[s : s + k]
         mu, var = seg.mean(0, keepdim=True), seg.var(0, unbiased=False, keepdim=True)
-        parts.append((seg - mu) / torch.sqrt(var + 1e-6) * inorm.weight.detach().cpu() + inorm.bias.detach().cpu())
+        parts.append((seg - mu) / torch.sqrt(var + inorm.eps) * inorm.weight.detach().cpu() + inorm.bias.detach().cpu())
         s += k
     yr = torch.cat(parts)
     (yr * w).sum().backward()

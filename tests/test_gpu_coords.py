@@ -107,7 +107,7 @@ def test_errors():
         ME.TensorField(coordinates=unsorted, features=torch.zeros(2, 4))
 
 
-@pytest.mark.parametrize("features", [("density", "sh"), ("sh",), ("sh", "ones", "density")])
+@pytest.mark.parametrize("features", [("density", "sh"), ("sh",), ("sh", "ones", "density"), ("xyzs", "density", "sh"), ("xyzs",)])
 def test_decode_plenoxel_batch_matches_oracle(features):
     """GPU-side decode of a compact PeRFception batch == the CPU restatement of the
     reference loader, bit for bit (integer coordinates; float32 multiply-then-add de-quantisation),

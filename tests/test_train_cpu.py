@@ -122,8 +122,15 @@ def test_compact_co3d_batch_and_decode_oracle(tmp_path, monkeypatch, per_channel
     coords, f = decode_batch(raw, features=feats)
     assert np.array_equal(coords, plain["coordinates"].numpy().astype(np.int32))
     assert np.array_equal(f, plain["features"].numpy())  # bit-exact: same float32 multiply-then-add
-    with pytest.raises(ValueError):
-        Co3DDataset(phase="train", data_root=str(tmp_path / "data"), features=["xyzs", "sh"], compact=True)
+    # the "xyzs" feature (configs/feature_coord.gin; a per-scene reduction): the decode oracle against the CPU loader's
+    # torch expression -- float32 on both sides, within a rounding of the division
+    fx = ["xyzs", "density"]
+    plain_x = collate_mink([Co3DDataset(phase="train", data_root=str(tmp_path / "data"), features=fx)[i] for i in range(2)])
+    dsx = Co3DDataset(phase="train", data_root=str(tmp_path / "data"), features=fx, compact=True)
+    assert collate_mink([dsx[0], dsx[1]])["feature_names"] == ("xyzs", "density")
+    _, f_x = decode_batch(raw, features=fx)
+    assert f_x.shape == plain_x["features"].shape and np.abs(f_x - plain_x["features"].numpy()).max() < 2e-7
+    assert np.abs(f_x[:, :3]).max() <= 1.0 + 1e-6
 
 
 def test_model_parameter_names_and_counts():
@@ -411,3 +418,34 @@ def test_plenoxel_scannet_dataset_and_segmentation_run(tmp_path):
     logged = [h for h in res["history"] if "train/loss" in h]
     assert res["global_step"] == 2 and len(logged) == 2 and all(np.isfinite(h["train/loss"]) for h in logged)
     assert any("val/mIoU" in h for h in res["history"])
+
+
+def test_density_based_sample_recipe(tmp_path, monkeypatch):
+    """`DensityBasedSample` (reference transforms.py:655-682; bound by configs/co3d_aug3.gin:13-15): the reference's own
+    config file parses, and a recipe that lists the class keeps exactly the voxels above the scene's density percentile
+    (np.percentile semantics: the value is in percent, the comparison strict) -- in the decoded and in the compact
+    sample form alike.  After CoordinateDropout it is refused (the percentile would be taken over a random subset)."""
+    from nerf_downstream_amd import gin_lite as gin
+    from nerf_downstream_amd.co3d_3d.src.data import transforms as T
+    from nerf_downstream_amd.co3d_3d.src.data.co3d import Co3DDataset
+
+    raw = _write_scenes(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gin.clear_config()
+    try:
+        gin.parse_config_files_and_bindings([os.path.join(ROOT, "nerf_downstream_amd", "co3d_3d", "configs", "co3d_aug3.gin")],
+                                            ["DensityBasedSample.percentile = 40.0"])
+        assert T.DensityBasedSample().percentile == 40.0 and T.DensityBasedSample().density_dim == 3
+        kw = dict(phase="train", data_root=str(tmp_path / "data"), features=["density", "sh"],
+                  train_transformations=["DensityBasedSample", "RandomScale"])
+        plain, compact = Co3DDataset(**kw)[1], Co3DDataset(compact=True, **kw)[1]
+    finally:
+        gin.clear_config()
+    d = raw[1]["density"].reshape(-1)
+    keep = d > np.percentile(d, 40.0)
+    assert 0 < keep.sum() < len(d) and plain["coordinates"].shape[0] == keep.sum() == compact["links"].shape[0]
+    assert np.array_equal(compact["links"].numpy(), raw[1]["links"][keep])
+    assert np.array_equal(plain["features"][:, 0].numpy(), d[keep]) and plain["aug_params"].shape == (44,)
+    with pytest.raises(NotImplementedError):
+        T.Compose([T.CoordinateDropout(), T.DensityBasedSample()])
