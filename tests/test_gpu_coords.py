@@ -139,13 +139,23 @@ def test_decode_plenoxel_batch_matches_oracle(features):
     coords, feats = ME.utils.decode_plenoxel_batch(batch)
     ocoords, ofeats = decode_batch(scenes, features=features)
     assert np.array_equal(coords.cpu().numpy(), ocoords)
-    assert np.array_equal(feats.cpu().numpy(), ofeats)
+    # de-quantised SH / density / ones: bit for bit.  "xyzs" (a chain of float32 divisions and a square root): within one
+    # unit in the last place of the oracle's numpy float32 evaluation
+    xcols = np.zeros(feats.shape[1], bool)
+    if "xyzs" in features:
+        x0 = sum({"xyzs": 3, "density": 1, "sh": 27, "ones": 1}[f] for f in features[: features.index("xyzs")])
+        xcols[x0 : x0 + 3] = True
+    got = feats.cpu().numpy()
+    assert np.array_equal(got[:, ~xcols], ofeats[:, ~xcols])
+    if xcols.any():
+        assert np.abs(got[:, xcols] - ofeats[:, xcols]).max() <= 1.2e-7 and np.abs(got[:, xcols]).max() <= 1.0 + 1e-6
     # `last.ckpt` scenes live on a 256^3 grid (reference co3d.py:152): the batch carries its resolution
     links256 = [np.sort(rng.choice(256 ** 3, len(s["links"]), replace=False)).astype(np.int32) for s in scenes]
     b256 = dict(batch, links=torch.from_numpy(np.concatenate(links256)).cuda(), reso=(256, 256, 256))
     c256, f256 = ME.utils.decode_plenoxel_batch(b256)
     oc256, _ = decode_batch([dict(s, links=l) for s, l in zip(scenes, links256)], features=features, reso=(256, 256, 256))
-    assert np.array_equal(c256.cpu().numpy(), oc256) and int(c256[:, 1:].max()) > 127 and torch.equal(f256, feats)
+    assert np.array_equal(c256.cpu().numpy(), oc256) and int(c256[:, 1:].max()) > 127
+    assert torch.equal(f256[:, torch.from_numpy(~xcols)], feats[:, torch.from_numpy(~xcols)])  # (xyzs follows the coordinates)
     if features == ("density", "sh"):
         from nerf_downstream_amd.co3d_3d.src.models import get_model
 

@@ -343,19 +343,19 @@ def _split_batches(phase, n, batch, order):
         yield collate_mink([get(int(i)) for i in order[s : s + batch]])
 
 
-def _fit(ME, device, probe_steps=(), probe=None):
+def _fit(ME, device, probe_steps=(), probe=None, seed=0):
     """SURVEY 8d's fixed-split run: 512 training scenes, 300 steps of the co3d_cls recipe (SGD momentum 0.9, weight
     decay 1e-4, cosine schedule stepped per iteration; configs/co3d_cls.gin), batch 8, fixed seeds.  `probe(step, model,
     batch, loss)` is called after backward at the given steps."""
     from nerf_downstream_amd.co3d_3d.src.models import get_model
     from nerf_downstream_amd.co3d_3d.src.modules.classification_training import ClassificationTraining
 
-    torch.manual_seed(11)
+    torch.manual_seed(11 + 1000 * seed)  # initial weights
     model = get_model("ResNet14", 28, 51, ME=ME) if ME is not None else get_model("ResNet14", 28, 51).to(device)
     module = ClassificationTraining(model)
     opt = torch.optim.SGD(model.parameters(), lr=SPLIT["lr"], momentum=0.9, weight_decay=1e-4)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=SPLIT["steps"])
-    g = torch.Generator().manual_seed(1234)
+    g = torch.Generator().manual_seed(1234 + seed)  # data order
     order = torch.cat([torch.randperm(512, generator=g) for _ in range(1 + SPLIT["steps"] * SPLIT["batch"] // 512)]).numpy()
     losses = []
     model.train()
@@ -401,8 +401,8 @@ def test_fixed_split_top1_matches_oracle(oracle_maps):
          the oracle's own fp32 distance);
       2. top-1 of a given network is the reference's top-1: the HIP-trained weights evaluated on the whole validation
          split by the HIP path and by the oracle agree within 0.1 points (in fact scene by scene);
-      3. the trained accuracy is statistically the reference's: HIP-trained vs oracle-trained top-1 differ by no more
-         than three validation scenes (measured: one)."""
+      3. the trained accuracy is statistically the reference's: several seeds each, a 1,024-scene validation split --
+         `test_fixed_split_top1_statistics` below."""
     from nerf_downstream_amd.co3d_3d.src.models import get_model
     from oracle import me_cpu as OME
 
@@ -449,15 +449,62 @@ def test_fixed_split_top1_matches_oracle(oracle_maps):
     assert 100.0 / 51 * 5 < acc_o < 95.0, "the task must neither sit at chance nor saturate"
     assert abs(acc_h - acc_o) <= 0.1 and torch.equal(logits_h.argmax(1), logits_o.argmax(1))
     assert float((logits_h - logits_o).abs().max()) < 1e-3
-    # 3. trained accuracy: HIP run vs oracle run
-    omodel, lo = _fit(OME, torch.device("cpu"))
-    logits_t, _ = _val_logits(omodel, torch.device("cpu"))
-    acc_t = 100.0 * float((logits_t.argmax(1) == labels).float().mean())
-    print(f"trained top-1: HIP run {acc_h:.3f} %, oracle run {acc_t:.3f} %; first-step losses {lh[0]:.6f} / {lo[0]:.6f}, "
-          f"final (mean of last 20) {lh[-20:].mean():.4f} / {lo[-20:].mean():.4f}")
-    assert abs(lh[0] - lo[0]) < 1e-4  # same start
-    assert abs(acc_h - acc_t) <= 3 * 100.0 / 128 + 1e-6, (acc_h, acc_t)
-    assert abs(lh[-20:].mean() - lo[-20:].mean()) < 0.1
+    # 3. the trained accuracy of a HIP run against an oracle run is a statistical statement: test_fixed_split_top1_statistics
+
+
+@pytest.mark.timeout(1500)
+def test_fixed_split_top1_statistics(oracle_maps):
+    """north_star: "top-1 on a fixed synthetic split matching reference +-0.1 %" as the statistical statement it can only
+    be (fp32 training of this network is chaotic: test_reference_training_does_not_reproduce_itself): THREE seeds (initial
+    weights and data order) each for the HIP trainer and for the CPU oracle, same recipe as above, every trained network
+    evaluated on a 1,024-scene validation split.  Evaluation runs on the HIP path for both families (that the HIP path
+    and the oracle give the same top-1 for the same weights is asserted scene by scene in the test above).
+    Asserted: |mean top-1 (HIP runs) - mean top-1 (oracle runs)| <= 2 x the pooled standard error of the two means,
+    sqrt((s_h^2 + s_o^2) / 3) with s the standard deviation over seeds, floored by the binomial resolution of the split
+    (sqrt(p (1 - p) / 1024 / 3): three 1,024-scene evaluations cannot resolve less).  Two, not one: a one-sigma band
+    rejects a third of all pairs of IDENTICAL implementations.  Also reported: the paired differences per seed."""
+    from nerf_downstream_amd.co3d_3d.src.data.synthetic import SparseVoxelDataset
+    from nerf_downstream_amd.co3d_3d.src.data.utils import collate_mink
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from oracle import me_cpu as OME
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    dev = torch.device("cuda", 0)
+    n_val, seeds = 1024, (0, 1, 2)
+    ds = SparseVoxelDataset(phase="val", num_samples=4 * n_val, num_classes=51, grid=SPLIT["grid"], features=["density", "sh"],
+                            class_sep=SPLIT["sep"], scene_sigma=SPLIT["sigma"])
+    assert len(ds) == n_val
+    val = []
+    for s0 in range(0, n_val, 32):
+        b = collate_mink([ds[i] for i in range(s0, s0 + 32)])
+        val.append(({"coordinates": b["coordinates"].to(dev), "features": b["features"].to(dev)}, b["labels"].long()))
+
+    @torch.no_grad()
+    def top1(model):
+        model.eval()
+        hits = sum(int((model(model.process_input(b)).argmax(1).cpu() == y).sum()) for b, y in val)
+        model.train()
+        return 100.0 * hits / n_val
+
+    acc_h, acc_o = [], []
+    for sd in seeds:
+        hip, _ = _fit(None, dev, seed=sd)
+        acc_h.append(top1(hip))
+        omodel, _ = _fit(OME, torch.device("cpu"), seed=sd)
+        carrier = get_model("ResNet14", 28, 51).to(dev)  # the oracle-trained weights, evaluated by the HIP path
+        carrier.load_state_dict(omodel.state_dict())
+        acc_o.append(top1(carrier))
+    acc_h, acc_o = np.array(acc_h), np.array(acc_o)
+    diff = float(acc_h.mean() - acc_o.mean())
+    p = float(np.concatenate([acc_h, acc_o]).mean()) / 100.0
+    se_seeds = float(np.sqrt((acc_h.var(ddof=1) + acc_o.var(ddof=1)) / len(seeds)))
+    se_floor = 100.0 * float(np.sqrt(p * (1.0 - p) / n_val / len(seeds)))
+    se = max(se_seeds, se_floor)
+    print(f"top-1 on {n_val} validation scenes, seeds {seeds}: HIP runs {np.round(acc_h, 2).tolist()} (mean {acc_h.mean():.2f}), "
+          f"oracle runs {np.round(acc_o, 2).tolist()} (mean {acc_o.mean():.2f}); difference of means {diff:+.2f} points, pooled standard "
+          f"error {se_seeds:.2f} (resolution of the split {se_floor:.2f}); paired differences {np.round(acc_h - acc_o, 2).tolist()}")
+    assert 100.0 / 51 * 5 < 100.0 * p < 95.0, "the task must neither sit at chance nor saturate"
+    assert abs(diff) <= 2.0 * se, (diff, se)
 
 
 def test_reference_training_does_not_reproduce_itself(oracle_maps, monkeypatch):
