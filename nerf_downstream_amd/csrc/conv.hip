@@ -725,13 +725,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float *_
     const int64_t stride = (int64_t)gridDim.x * rlanes;
     for (int64_t row = (int64_t)blockIdx.x * rlanes + rl; row < n_out; row += 4 * stride) {
       float4 v[4] = {b, b, b, b};
-      for (int z = 0; z < ksplit; ++z) {
+      int64_t off[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = row + u * stride;
+        off[u] = (r < n_out ? r : row) * cout + 4 * c4;
+      }
+      // four slabs per trip as well: sixteen independent 16-byte loads in flight (the deep layers sum 14 slabs of a few
+      // hundred rows: one dependent round trip per slab was 11-14 us for a 1 MB output); summed in slab order
+      int z = 0;
+      for (; z + 3 < ksplit; z += 4) {
+        float4 t[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) t[q][u] = *reinterpret_cast<const float4 *>(ws + (int64_t)(z + q) * total + off[u]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u].x += t[q][u].x, v[u].y += t[q][u].y, v[u].z += t[q][u].z, v[u].w += t[q][u].w;
+      }
+      for (; z < ksplit; ++z) {
         float4 t[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int64_t r = row + u * stride;
-          t[u] = *reinterpret_cast<const float4 *>(ws + (int64_t)z * total + (r < n_out ? r : row) * cout + 4 * c4);
-        }
+        for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4 *>(ws + (int64_t)z * total + off[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u].x += t[u].x, v[u].y += t[u].y, v[u].z += t[u].z, v[u].w += t[u].w;
       }
@@ -2404,7 +2421,7 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
   }
   if (zs > 1 && stats_split) {
     const int tpr = cout >> 2, rlanes = 256 / tpr;
-    const int rows = (int)std::max<int64_t>(1, std::min<int64_t>(512, cdiv(n_out, (int64_t)rlanes * 8)));
+    const int rows = (int)std::max<int64_t>(1, std::min<int64_t>(512, cdiv(n_out, (int64_t)rlanes * 4)));  // one four-row trip per thread
     splitk_reduce_stats_kernel<<<dim3((unsigned)rows), 256, (size_t)rlanes * 2 * cout * sizeof(double), st>>>(
         workspace, n_out, cout, zs, bias, y, ldy, stats_out);
     MINK_CHECK_LAUNCH();

@@ -468,7 +468,7 @@ def test_stem_weight_gradient_on_bf16_matrix_cores(oracle_maps):
 
 
 @pytest.mark.parametrize("n_out,K,cin,cout", [(1, 27, 64, 64), (63, 27, 64, 128), (65, 27, 96, 64), (1000, 27, 128, 128),
-                                              (4097, 27, 64, 64), (300, 8, 64, 64), (129, 9, 256, 64)])
+                                              (4097, 27, 64, 64), (300, 8, 64, 64), (129, 9, 256, 64), (128, 27, 512, 512), (530, 27, 256, 256)])
 @pytest.mark.parametrize("transposed", [False, True])
 def test_row_compacted_kernel_against_float64(n_out, K, cin, cout, transposed):
     """compact_gemm_kernel (fp32 mid layers: per-offset row compaction, C tile in LDS) on synthetic tables: ragged row
