@@ -82,6 +82,40 @@ class _Level:
     __slots__ = ("coords", "n", "tkeys", "tvals", "cap")
 
 
+class _Arena:
+    """Device memory of ONE coordinate manager as a few large blocks instead of ~25 small ones.
+
+    The maps of a batch are built on the prepare stream and read on the compute / branch / weight-gradient streams, so
+    every block carries `record_stream` marks -- and the caching allocator answers a block freed with such marks by
+    recording an event on EACH of those streams (the compute stream among them: a barrier packet in the chain of
+    dependent launches).  A manager dies once per training step: ~20 blocks made ~70 us of such packets between one
+    step's optimizer and the next step's first kernel (bench.py --timeline).  Chunks are sized from what the previous
+    manager used, so a steady-state batch takes one or two."""
+
+    last_used = 1 << 20  # bytes the most recent manager has taken so far (class-wide: the next batch is about the same size)
+
+    def __init__(self, device):
+        self.device, self.chunks, self.off, self.used = device, [], 0, 0
+        self.first = int(_Arena.last_used * 1.1) + 4096  # (read before this arena starts counting)
+
+    def take(self, shape, dtype):
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        numel = 1
+        for s in shape:
+            numel *= s
+        nbytes = max(numel, 1) * torch.empty(0, dtype=dtype).element_size()
+        need = (nbytes + 255) // 256 * 256
+        if not self.chunks or self.off + need > self.chunks[-1].numel():
+            size = max(need, self.first if not self.chunks else self.chunks[-1].numel() // 2)
+            self.chunks.append(torch.empty(size, dtype=torch.uint8, device=self.device))
+            self.off = 0
+        t = self.chunks[-1][self.off : self.off + nbytes].view(dtype)[:numel].view(shape)
+        self.off += need
+        self.used += need
+        _Arena.last_used = self.used
+        return t
+
+
 class CoordinateManager:
     def __init__(self, D=3, device=None):
         assert D == 3, "the HIP backend implements 3 spatial dimensions"
@@ -101,6 +135,8 @@ class CoordinateManager:
         self._lazy_marks = []  # (stream, event, tensors) of every map built on demand (outside replay)
         self._lazy_seen = {}   # stream -> number of marks that stream is already ordered after
         self._replaying = False
+        self._arena = None
+        self._arena_only = True  # False once a map was allocated outside the arena (the on-demand builders of stride() / tools)
 
     # ------------------------------------------------------------------ plan record / replay
     @staticmethod
@@ -166,7 +202,7 @@ class CoordinateManager:
         for ts_in, ts_out, ks, dil, transposed in todo:
             K = ks ** 3
             sizes.append((self.levels[ts_out].n * K, self.levels[ts_in].n * K if transposed else 0))
-        pool = torch.empty(sum(a + b for a, b in sizes) + 4, dtype=torch.int32, device=self.device)
+        pool = self._take(sum(a + b for a, b in sizes) + 4, torch.int32)
         descs = (KernelMapDesc * len(todo))()
         # block index of every input map that is looked up (4^3-cell blocks: see MinkKernelMapDesc): one buffer set per
         # input tensor stride, built by the first table that uses it
@@ -177,7 +213,7 @@ class CoordinateManager:
             cap = int(L.mink_table_capacity(self.levels[ts_in].n))
             blk[ts_in] = [cap, need, True, n_pad]  # capacity, int32 offset into the index pool, still to build
             need += 4 * cap + cap + 2 * n_pad + 4  # table (2 x int64 per slot), base, slot, rowids, counter (+pad)
-        bpool = torch.empty(need + 4, dtype=torch.int32, device=self.device)
+        bpool = self._take(need + 4, torch.int32)
         bbase_ptr = bpool.data_ptr()
         off = 0
         for d, (ts_in, ts_out, ks, dil, transposed), (na, nb) in zip(descs, todo, sizes):
@@ -202,7 +238,14 @@ class CoordinateManager:
         check(lib().mink_kernel_map_batch(len(todo), ctypes.cast(descs, ctypes.c_void_p), _stream()))
         self._blk_pool = bpool  # (scratch of the call; kept until the manager goes so no stream bookkeeping is needed)
 
+    def _take(self, shape, dtype):
+        if self._arena is None:
+            self._arena = _Arena(self.device)
+        return self._arena.take(shape, dtype)
+
     def tensors(self):
+        if self._arena is not None and not self._lazy_marks and self._arena_only:
+            return list(self._arena.chunks)  # every map of a prepared manager lives in the arena's few blocks
         out = [self.field_inverse, self.field_unique_index]
         for lev in self.levels.values():
             out += [lev.coords, lev.tkeys, lev.tvals]
@@ -222,6 +265,7 @@ class CoordinateManager:
         """keys -> hash map + first-occurrence rows.  Returns (_Level, unique_index, inverse)."""
         L, dev = lib(), self.device
         n = int(n)
+        self._arena_only = False  # (on-demand path: plain allocations)
         keys = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
         meta = torch.zeros(2, dtype=torch.int32, device=dev)  # [n_unique, status]
         check(L.mink_coords_make_keys(src.data_ptr(), mode, n, out_ts, keys.data_ptr(), meta[1:].data_ptr(), _stream()))
@@ -271,13 +315,13 @@ class CoordinateManager:
             raise ValueError("empty coordinate field")
         L, nlev = lib(), len(ts_list)
         cap = int(L.mink_table_capacity(n))
-        tkeys = torch.empty(nlev, cap, dtype=torch.int64, device=dev)
-        tvals = torch.empty(nlev, cap, dtype=torch.int32, device=dev)
-        coords = torch.empty(nlev, n, 4, dtype=torch.int32, device=dev)
-        index_b = torch.empty(nlev, n, dtype=torch.int32, device=dev)
-        index_a = torch.empty(n, dtype=torch.int32, device=dev)
-        meta = torch.empty(nlev + 2, dtype=torch.int32, device=dev)
-        ws = torch.empty(int(L.mink_levels_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        tkeys = self._take((nlev, cap), torch.int64)
+        tvals = self._take((nlev, cap), torch.int32)
+        coords = self._take((nlev, n, 4), torch.int32)
+        index_b = self._take((nlev, n), torch.int32)
+        index_a = self._take(n, torch.int32)
+        meta = self._take(nlev + 2, torch.int32)
+        ws = self._take(int(L.mink_levels_workspace_bytes(n)), torch.uint8)
         arr = lambda ptrs: (ctypes.c_void_p * nlev)(*ptrs)  # noqa: E731
         check(
             L.mink_coords_build_levels(
@@ -389,6 +433,7 @@ class CoordinateManager:
             lin, lout = self.levels[in_key.ts], self.levels[out_key.ts]
             off = kernel_offsets(ks, in_key.ts, dil)
             K = off.shape[0]
+            self._arena_only = False
             nbr = torch.empty(max(lout.n, 1), K, dtype=torch.int32, device=self.device)[: lout.n]
             nbr_t = None
             if transposed:
@@ -426,6 +471,7 @@ class CoordinateManager:
         self._sync_lazy()
         if ck not in self.tables:
             n = self.size(key)
+            self._arena_only = False
             self.tables[ck] = torch.arange(n, dtype=torch.int32, device=self.device).reshape(n, 1)
             self._note_lazy(self.tables[ck])
         return self.tables[ck]
@@ -437,8 +483,8 @@ class CoordinateManager:
         self._sync_lazy()
         if ck not in self.tables:
             L, lev = lib(), self.levels[key.ts]
-            perm = torch.empty(int(L.mink_class_partition_rows(lev.n, pad)), dtype=torch.int32, device=self.device)
-            ws = torch.empty(int(L.mink_class_partition_workspace_bytes(lev.n)), dtype=torch.uint8, device=self.device)
+            perm = self._take(int(L.mink_class_partition_rows(lev.n, pad)), torch.int32)
+            ws = self._take(int(L.mink_class_partition_workspace_bytes(lev.n)), torch.uint8)
             check(L.mink_class_partition(lev.coords.data_ptr(), lev.n, key.ts, pad, perm.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
             self.tables[ck] = perm
             self._note_lazy(perm)
@@ -461,8 +507,9 @@ class CoordinateManager:
         if key.ts not in self._boff:
             B = self._batch_size
             lev = self.levels[key.ts]
-            boff = torch.empty(B + 1, dtype=torch.int32, device=self.device)
-            status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            boff = self._take(B + 1, torch.int32)
+            status = self._take(1, torch.int32)
+            status.zero_()
             check(lib().mink_batch_offsets(lev.coords.data_ptr(), lev.n, B, boff.data_ptr(), status.data_ptr(), _stream()))
             if key.ts == 1 and int(status.item()) & _STATUS_UNSORTED:
                 raise ValueError("batch indices must be non-decreasing (use ME.utils.sparse_collate)")

@@ -194,9 +194,11 @@ class BucketedGradAllReduce:
             self._home = torch.cuda.current_stream(self.flat.device)
             from .minkowski import functional as Fn
 
-            for st in Fn.compute_streams(self.flat.device):  # last step's collectives / writes on the side streams
-                if st != self._home:
-                    Fn.stream_wait(self._home, st)
+            if self._collect:  # last step's collectives were launched from the side streams (one rank: every gradient
+                # write of the last backward pass was joined by its end-of-backward callback -- no barrier packets here)
+                for st in Fn.compute_streams(self.flat.device):
+                    if st != self._home:
+                        Fn.stream_wait(self._home, st)
         self.flat.zero_()
         self._written.clear()
         self._counted.clear()
