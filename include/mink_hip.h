@@ -203,9 +203,11 @@ int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *bat
  *                        the cin/32 channel chunks instead (<= cin/32 slices; a tile of one
  *                        parity class has few live offsets, every slice sees all of them)
  */
-/* Tuning / A-B knob (benchmarks only): bits 0-5 start-up stagger of the un-pipelined kernel,
- * bit 8 = use the un-pipelined kernel, bit 9 = disable the flattened-K stem path.  Returns the
- * previous stagger value. */
+/* Test / measurement knob (never needed by a caller): bit 9 = no flattened-K stem path, bit 10 = tiled instead of streaming
+ * stem weight gradient, bits 12-15 / 16-27 = force the weight-gradient offset grouping / row-split count (sweeps; this is the
+ * plan change the workspace_bytes arguments guard against), bit 28 = bf16 math keeps the fp32 stem weight gradient, bit 29 =
+ * plain workgroup order in the streaming weight gradient, bit 30 / 31 = the dense gather-GEMM instead of the row-compacted
+ * kernel for the mid layers / the strided data gradients (the tests compare the two).  Returns the previous low byte. */
 int mink_conv_set_stagger(int units);
 /* Matrix-core arithmetic of mink_conv_gather_gemm (forward / input gradient):
  *   0 = exact fp32 MFMA (default), 1 = bf16 operands with fp32 accumulation (BASELINE config
@@ -215,11 +217,9 @@ int mink_conv_set_math(int mode);
 /* Split-K factor the library recommends for a layer (1 for large row counts).  row_classes != 0:
  * the launch will pass a class-partitioned row_perm (stride-2 dgrad), n_out = its n_virtual. */
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_classes);
-/* The same with the reduction width known: returns K -- one slab per kernel offset -- for the deep layers (cin >= 256),
- * which mink_conv_gather_gemm then runs offset-major with the rows of each offset compacted into dense MFMA blocks (half of
- * a deep layer's table is empty) and reduces in ascending offset order; for row_classes != 0 on an fp32 mid layer the
- * channel split of the row-compacted kernel; otherwise mink_conv_plan_ksplit's answer.  The workspace is
- * 4 * ksplit * n_out * cout bytes in every case. */
+/* The same with the reduction width known (what the block sequencer and the Python layer ask): for a class-permuted fp32 mid
+ * layer (row_classes != 0) the channel-chunk split of the row-compacted kernel, for an fp32 mid layer its offset split (<= 14
+ * slabs), otherwise mink_conv_plan_ksplit's answer.  The workspace is 4 * ksplit * n_out * cout bytes in every case. */
 int mink_conv_plan(int64_t n_rows, int32_t K, int32_t cin, int32_t cout, int32_t row_classes);
 /* flip_k: bit 0 = read the weights of offset K-1-k for offset k (data gradient of a stride-1 convolution through the
  * forward table); bit 1 = ACCUMULATE, y[row] += result instead of y[row] = result -- for an un-split launch whose

@@ -788,214 +788,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
   y[row * ldy + c] = s + (bias ? bias[c] : 0.f);
 }
 
-// ------------------------------------------------------------------ offset-major, row-compacted
-// The deep layers (Cin >= 256: a few hundred to a few thousand rows against 1-28 MB of weights) are where the
-// output-stationary kernel above is weakest: half of a 128-row tile's entries for an offset are empty (37-58 % of
-// the table), split-K leaves a handful of items per workgroup and every workgroup re-reads its weight slice.
-// Here a workgroup owns ONE kernel offset k for a 256-row tile and a 64-column slice:
-//   1. the rows of the tile that have a neighbour under offset k are compacted (wave64 ballot + prefix rank) into
-//      dense 32-row MFMA blocks -- ~5 blocks instead of 8, for a strided data gradient 1 instead of 8;
-//   2. plain double-staged GEMM over the input channels: gathered rows [m x 32] and the weight slice [32 x 64] go
-//      through LDS (next chunk's global loads in flight in registers), block x column-half units are dealt to
-//      the four waves;
-//   3. the result goes to slab k at the rows' own indices: (row, offset) entries without a neighbour are never
-//      written -- and never read: the reduce pass sums a row's slabs over the offsets its table row names, in
-//      ascending offset order (ME's summation order), adding bias / column statistics on the way.
-// Every output element still has one owner per pass: no atomics, bitwise reproducible.
-constexpr int OT = 256;  // rows per tile
-
-template <bool W_T>
-__global__ __launch_bounds__(256, 2) void offset_gemm_kernel(GemmParams p) {
-  __shared__ __attribute__((aligned(16))) float sA[OT * LDA];
-  // B tile: forward weights [cin][cout] arrive contiguous along the columns -> stored [kk][n]; the data gradient reads
-  // the same tensor transposed, contiguous along kk -> stored [n][kk] (row stride LDA), and its MFMA operand is then
-  // one 16-byte LDS read per four k-steps, like A
-  __shared__ __attribute__((aligned(16))) float sB[W_T ? BN * LDA : BK * BN];
-  __shared__ int s_in[OT], s_out[OT];
-  __shared__ int s_cnt[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t o0 = (int64_t)blockIdx.x * OT;
-  const int n0 = blockIdx.y * BN;
-  const int k = blockIdx.z;
-  const int kw = p.flip_k ? p.K - 1 - k : k;
-  // ---- 1. compaction of the tile's rows that have a neighbour under offset k
-  const int64_t o = o0 + tid;
-  const int nb = o < p.n_out ? p.nbr[o * p.K + k] : -1;
-  const unsigned long long bal = __ballot(nb >= 0);
-  if (lane == 0) s_cnt[wave] = __popcll(bal);
-  __syncthreads();
-  const int m = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-  if (m == 0) return;  // (uniform) nothing under this offset in this tile
-  {
-    int pos = wave_rank(bal);
-    for (int w = 0; w < wave; ++w) pos += s_cnt[w];
-    if (nb >= 0) s_in[pos] = nb, s_out[pos] = (int)o;
-  }
-  const int mpad = (m + 31) & ~31;
-  if (tid >= m && tid < mpad) s_in[tid] = -1, s_out[tid] = -1;
-  __syncthreads();
-  const int nblk = mpad >> 5;       // 32-row MFMA blocks
-  const int nunits = 2 * nblk;      // (block, column half) units, dealt round-robin to the 4 waves
-  // ---- 2. GEMM over the input channels
-  const int a_cc = tid & 7, a_r = tid >> 3;     // A: rows a_r + 32 i, float4 column a_cc
-  const int b_n4 = tid & 15, b_kk = tid >> 4;   // B (!W_T): rows b_kk + 16 i, float4 column b_n4
-  const int bt_k4 = tid & 7, bt_n = tid >> 3;   // B (W_T) : columns bt_n + 32 i, float4 of k at 4 * bt_k4 (128 contiguous bytes per column)
-  uint4 ga[8], gb[2];
-  unsigned okb = 0u;
-  auto ldraw = [&](const float *base, int64_t off, bool ok) { return *reinterpret_cast<const uint4 *>(base + (ok ? off : 0)); };
-  auto gload = [&](int c0) {
-    okb = 0u;
-    const int c = c0 + 4 * a_cc;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = a_r + 32 * i;
-      const int src = r < mpad ? s_in[r] : -1;
-      const bool ok = src >= 0 && c < p.cin;
-      ga[i] = ldraw(p.x, (int64_t)src * p.ldx + c, ok);
-      okb |= ok ? (1u << i) : 0u;
-    }
-    if (!W_T) {
-      const int n = n0 + 4 * b_n4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int kk = c0 + b_kk + 16 * i;
-        const bool ok = kk < p.cin && n < p.cout;
-        gb[i] = ldraw(p.w, ((int64_t)kw * p.cin + kk) * p.cout + n, ok);
-        okb |= ok ? (256u << i) : 0u;
-      }
-    } else {
-      const int kk = c0 + 4 * bt_k4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int n = n0 + bt_n + 32 * i;
-        const bool ok = n < p.cout && kk < p.cin;
-        gb[i] = ldraw(p.w, ((int64_t)kw * p.cout + n) * p.cin + kk, ok);
-        okb |= ok ? (256u << i) : 0u;
-      }
-    }
-  };
-  auto sts = [&]() {
-    auto masked = [&](uint4 u, unsigned bit) {
-      const unsigned mm = (okb & bit) ? 0xFFFFFFFFu : 0u;
-      return make_uint4(u.x & mm, u.y & mm, u.z & mm, u.w & mm);
-    };
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (a_r + 32 * i < mpad) *reinterpret_cast<uint4 *>(&sA[(a_r + 32 * i) * LDA + 4 * a_cc]) = masked(ga[i], 1u << i);
-    if (!W_T) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4 *>(&sB[(b_kk + 16 * i) * BN + 4 * b_n4]) = masked(gb[i], 256u << i);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        *reinterpret_cast<uint4 *>(&sB[(bt_n + 32 * i) * LDA + 4 * bt_k4]) = masked(gb[i], 256u << i);
-    }
-  };
-  f32x16 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (f32x16){0};
-  const int h = lane >> 5, col = lane & 31;
-  gload(0);
-  for (int c0 = 0; c0 < p.cin; c0 += BK) {
-    __syncthreads();  // the previous chunk's operands have been read
-    sts();
-    __syncthreads();
-    if (c0 + BK < p.cin) gload(c0 + BK);  // in flight during the MFMAs below
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int u = wave + 4 * i;
-      if (u < nunits) {  // uniform per wave
-        const int arow = (u >> 1) * 32 + col;
-        const int cb = (u & 1) * 32 + col;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float4 av = *reinterpret_cast<const float4 *>(&sA[arow * LDA + 8 * t + 4 * h]);
-          const float a4[4] = {av.x, av.y, av.z, av.w};
-          float b4[4];
-          if (W_T) {
-            const float4 bv = *reinterpret_cast<const float4 *>(&sB[cb * LDA + 8 * t + 4 * h]);
-            b4[0] = bv.x, b4[1] = bv.y, b4[2] = bv.z, b4[3] = bv.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b4[j] = sB[(8 * t + 4 * h + j) * BN + cb];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], b4[j], acc[i], 0, 0, 0);
-        }
-      }
-    }
-  }
-  // ---- 3. slab k, at the rows' own indices (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-  float *dst = p.ws + (int64_t)k * p.n_out * p.cout;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int u = wave + 4 * i;
-    if (u < nunits) {
-      const int c = n0 + (u & 1) * 32 + col;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = s_out[(u >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-        if (row >= 0 && c < p.cout) dst[(int64_t)row * p.cout + c] = acc[i][r];
-      }
-    }
-  }
-}
-
-// y[o] = bias + sum over the offsets k the table names for row o (ascending) of slab[k][o]; STATS: per-workgroup column
-// (sum, sum of squares) partials in double for the batch norm that follows (layout of splitk_reduce_stats_kernel)
-template <bool STATS>
-__global__ __launch_bounds__(256) void offset_reduce_kernel(const float *__restrict__ ws, const int *__restrict__ nbr,
-                                                            int64_t n_out, int cout, int K, const float *__restrict__ bias,
-                                                            float *__restrict__ y, int ldy, double *__restrict__ partial) {
-  extern __shared__ double s_red[];  // STATS: [row lanes][2][C]
-  const int tpr = cout >> 2, rlanes = 256 / tpr;
-  const int c4 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
-  const int64_t total = n_out * cout;
-  float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
-  if (rl < rlanes) {
-    const float4 b = bias ? *reinterpret_cast<const float4 *>(bias + 4 * c4) : make_float4(0, 0, 0, 0);
-    for (int64_t row = (int64_t)blockIdx.x * rlanes + rl; row < n_out; row += (int64_t)gridDim.x * rlanes) {
-      float4 v = b;
-      // nine slabs per trip, loaded whether the table names them or not (a slab entry without a neighbour was never
-      // written: its bits are discarded by the select below) -- nine independent loads in flight instead of a chain of
-      // table-dependent ones; added in ascending offset order
-      for (int k0 = 0; k0 < K; k0 += 9) {
-        float4 t[9];
-        bool ok[9];
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-          const int k = k0 + u < K ? k0 + u : K - 1;
-          ok[u] = k0 + u < K && nbr[row * K + k] >= 0;
-          t[u] = *reinterpret_cast<const float4 *>(ws + (int64_t)k * total + row * cout + 4 * c4);
-        }
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-          v.x += ok[u] ? t[u].x : 0.f, v.y += ok[u] ? t[u].y : 0.f;
-          v.z += ok[u] ? t[u].z : 0.f, v.w += ok[u] ? t[u].w : 0.f;
-        }
-      }
-      *reinterpret_cast<float4 *>(y + row * ldy + 4 * c4) = v;
-      if (STATS) {
-        s0.x += v.x, s0.y += v.y, s0.z += v.z, s0.w += v.w;
-        s1.x += v.x * v.x, s1.y += v.y * v.y, s1.z += v.z * v.z, s1.w += v.w * v.w;
-      }
-    }
-    if (STATS) {
-      double *d = s_red + ((int64_t)rl * 2) * cout + 4 * c4;
-      d[0] = s0.x, d[1] = s0.y, d[2] = s0.z, d[3] = s0.w;
-      d[cout + 0] = s1.x, d[cout + 1] = s1.y, d[cout + 2] = s1.z, d[cout + 3] = s1.w;
-    }
-  }
-  if (STATS) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < 2 * cout; e += 256) {
-      double s = 0.0;
-      for (int r = 0; r < rlanes; ++r) s += s_red[(int64_t)r * 2 * cout + e];
-      partial[(int64_t)blockIdx.x * 2 * cout + e] = s;
-    }
-  }
-}
-
 // ------------------------------------------------ output-stationary gather-GEMM over ROW-COMPACTED offsets (fp32)
 // 37-48 % of a mid-layer table is empty, and the kernel above multiplies those entries as zero rows ("zero
 // rows").  Here the workgroup still owns a 128-row x 64-column tile of the output, but
@@ -2052,7 +1844,7 @@ static WgradPlan wgrad_plan(int64_t n_out, int K, int cin, int cout) {
 template <int G>
 static void launch_wgrad(const WgradParams &p, dim3 grid, hipStream_t st) {
   const bool vec = (((uintptr_t)p.x | (uintptr_t)p.dy) & 15) == 0 && ((p.ldx | p.ldy | p.cin | p.cout) & 3) == 0;
-  static const int buf_on = getenv("MINK_WGRAD_BUF") ? atoi(getenv("MINK_WGRAD_BUF")) : 1;  // A/B hook
+  constexpr int buf_on = 1;
   if (p.cin <= 32) {
     if (vec && p.buf_ok && buf_on) wgrad_kernel<G, true, true, true><<<grid, 256, 0, st>>>(p);
     else if (vec) wgrad_kernel<G, true, true><<<grid, 256, 0, st>>>(p);
@@ -2108,33 +1900,25 @@ struct ScopedTimer {  // records an event pair around the launches of one convol
 }  // namespace
 
 static int g_stagger = 0;
-// The offset-major path is built, tested and selectable (mink_conv_set_stagger bit 11 / MINK_OFFSET_MAJOR=1) but NOT the
-// default: alone on the chip it beats the output-stationary kernel on the deep layers (l4.conv2 forward 76 us against 94,
-// data gradient 72 against 92), inside a training step -- beside the weight-gradient and map-preparation streams -- its
-// slab traffic (60-120 MB per layer) makes it lose (step 4.66 ms against 4.52).  See DESIGN.md section 7.
-static int g_offset_major = 0;
-static int g_pipeline = 1;
 static int g_flat = 1;
 static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
-static int g_wgrad_bf16 = getenv("MINK_WGRAD_BF16") ? atoi(getenv("MINK_WGRAD_BF16")) : 1;  // bf16 math: stem weight gradient on the bf16 MFMA too
+static int g_wgrad_bf16 = 1;  // bf16 math: stem weight gradient on the bf16 MFMA too (set_stagger bit 28 switches it off: A/B tests)
 static int g_wgrad_bf16_off = 0;
-static int g_compact = getenv("MINK_COMPACT") ? atoi(getenv("MINK_COMPACT")) : 1;  // fp32 mid layers on compact_gemm_kernel
-static int g_compact_perm = getenv("MINK_COMPACT_PERM") ? atoi(getenv("MINK_COMPACT_PERM")) : 1;  // ... and the class-permuted strided data gradients
-static int g_wgrad_xcd = getenv("MINK_WGRAD_XCD") ? atoi(getenv("MINK_WGRAD_XCD")) : 1;  // streaming wgrad: groups of a row split share an XCD (stream_slot)
+static int g_compact = 1;  // fp32 mid layers on compact_gemm_kernel (set_stagger bit 30: the dense kernel, for the tests that compare the two)
+static int g_compact_perm = 1;  // ... and the class-permuted strided data gradients (bit 31)
+static int g_wgrad_xcd = 1;  // streaming wgrad: groups of a row split share an XCD (stream_slot; bit 29: plain order)
 
 extern "C" {
 
 int mink_conv_set_stagger(int units) {
   const int old = g_stagger;
   g_stagger = units & 255;
-  g_pipeline = !(units & 256);  // bit 8: fall back to the un-pipelined kernel (A/B benchmarks)
   g_flat = !(units & 512);      // bit 9: no flattened-K stem path
   g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
   g_wgrad_bf16_off = (units >> 28) & 1;  // bit 28: bf16 math keeps the exact-fp32 weight-gradient kernel (A/B tests)
   g_wgrad_xcd = !((units >> 29) & 1);    // bit 29: plain workgroup order in the streaming weight-gradient kernels (A/B)
   g_compact = !((units >> 30) & 1);      // bit 30: mid layers back on gather_gemm2_kernel (A/B)
   g_compact_perm = !(((unsigned)units >> 31) & 1u);  // bit 31: class-permuted strided data gradients back on gather_gemm2_kernel (A/B)
-  g_offset_major = (units & 2048) != 0;  // bit 11: offset-major, row-compacted path for the deep layers (Cin >= 256)
   g_wgrad_force = (units >> 12) & 0xFFFF;  // bits 12-15: force G (1, 3, 9), bits 16-27: force the row split count
   return old;
 }
@@ -2170,13 +1954,6 @@ int mink_conv_set_math(int mode) {
   return old;
 }
 
-// Offset-major, row-compacted path (offset_gemm_kernel): worth its K slabs where a slab element stands for many FLOPs
-// (2 * cin per float) and the tables are half empty -- the deep layers.
-static bool offset_major_shape(int64_t n_out, int K, int cin, int cout) {
-  return g_offset_major && K >= 8 && cin >= 256 && (cout & 3) == 0 && cout <= 1024 && n_out >= 1 &&
-         4ll * K * n_out * cout <= (128ll << 20);
-}
-
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_classes) {
   if (n_out <= 0 || K <= 1) return 1;
   const int64_t tiles = cdiv(n_out, BM) * cdiv(cout, BN);
@@ -2204,26 +1981,16 @@ int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_cl
     else score = zs > 7 ? 0.0 : (double)blocks / (512.0 * cdiv(blocks, 512)) - 0.01 * zs;
     if (score > best_score) best_score = score, best = zs;
   }
-  static const int cap = getenv("MINK_KSPLIT_CAP") ? atoi(getenv("MINK_KSPLIT_CAP")) : 0;  // tuning hook (in-step sweeps)
-  if (cap > 0 && best > cap) {  // the largest legal split not above the cap
-    int alt = 1;
-    for (int kper = K; kper >= 1; --kper) {
-      const int zs = (int)cdiv(K, kper);
-      if (zs <= cap) alt = zs;
-    }
-    best = alt;
-  }
   return best;
 }
 
 // XCD-aware launch of compact_gemm_kernel for the layers whose weights do not stay in one L2 (4 MB): few row tiles, many
 // (column tile, slice) pairs.  Turns the three-dimensional grid into the padded one-dimensional one the kernel decodes.
-static int g_compact_swz = getenv("MINK_COMPACT_SWIZZLE") ? atoi(getenv("MINK_COMPACT_SWIZZLE")) : 1;  // A/B hook
 static void compact_swizzle(GemmParams &p, dim3 &grid, int cin, int cout, int K) {
   p.swz_x = p.swz_y = p.swz_z = 0;
   const int64_t wbytes = 4ll * K * cin * cout;
   const unsigned slices = grid.y * grid.z;
-  if (!g_compact_swz || wbytes <= (2ll << 20) || grid.x > 64 || slices < 16) return;
+  if (wbytes <= (2ll << 20) || grid.x > 64 || slices < 16) return;
   p.swz_x = (int)grid.x, p.swz_y = (int)grid.y, p.swz_z = (int)grid.z;
   grid = dim3((unsigned)(cdiv(slices, 8) * 8 * grid.x), 1, 1);
 }
@@ -2238,7 +2005,7 @@ static bool compact_shape(int64_t n_rows, int K, int cin, int cout, int row_clas
   return zmin == 1 || zmin * 4 * n_rows * cout <= (128ll << 20);
 }
 static int compact_plan(int64_t n_rows, int K, int cout) {
-  static const int wg_cap = getenv("MINK_COMPACT_WG_CAP") ? atoi(getenv("MINK_COMPACT_WG_CAP")) : 2048;  // tuning hook (in-step sweeps)
+  constexpr int wg_cap = 2048;
   const int64_t tiles = cdiv(n_rows, 64) * cdiv(cout, BN);
   const int64_t slab_cap = std::max<int64_t>(1, (128ll << 20) / (4 * n_rows * cout));
   int best = (int)cdiv(K, CKP);
@@ -2257,7 +2024,7 @@ static bool compact_perm_shape(int64_t n_rows, int K, int cin, int cout, int row
   return g_compact && g_compact_perm && g_math == 0 && row_classes && K >= 8 && cin >= 64 && cin % BK == 0 && cout % BN == 0 && n_rows >= 1;
 }
 static int compact_perm_plan(int64_t n_rows, int cin, int cout) {
-  static const int cap = getenv("MINK_PERM_SPLIT_CAP") ? atoi(getenv("MINK_PERM_SPLIT_CAP")) : 850;  // tuning hook
+  constexpr int cap = 850;
   const int ncc = cin / BK;
   // (n_rows is the padded length of the class permutation: up to 127 padding rows per class, whose tiles exit at once)
   const int64_t tiles = cdiv(std::max<int64_t>(n_rows - 512, 64), 64) * cdiv(cout, BN);
@@ -2271,7 +2038,6 @@ static int compact_perm_plan(int64_t n_rows, int cin, int cout) {
 
 int mink_conv_plan(int64_t n_rows, int32_t K, int32_t cin, int32_t cout, int32_t row_classes) {
   if (compact_perm_shape(n_rows, K, cin, cout, row_classes)) return compact_perm_plan(n_rows, cin, cout);
-  if (offset_major_shape(n_rows, K, cin, cout)) return K;  // one slab per offset (offset_gemm_kernel)
   if (compact_shape(n_rows, K, cin, cout, row_classes)) return compact_plan(n_rows, K, cout);
   return mink_conv_plan_ksplit(n_rows, K, cout, row_classes);
 }
@@ -2315,35 +2081,14 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
   hipStream_t st = (hipStream_t)stream;
   const bool al = (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && (ldx & 3) == 0 && (cin & 3) == 0;
   const bool vec = al && (w_transposed ? true : (cout & 3) == 0);
-  MINK_REQUIRE(!p.accumulate || (zs == 1 && vec && g_pipeline && !stats_out),
+  MINK_REQUIRE(!p.accumulate || (zs == 1 && vec && !stats_out),
                "gather_gemm: accumulation needs an un-split launch of the pipelined kernel (16-byte aligned operands)");
   flip_k &= 1;
   const bool want_stats = stats_out && stats_rows && stats_ws && !row_perm && !w_transposed;
-  const bool stats_direct = want_stats && zs == 1 && vec && g_pipeline;  // conv epilogue -> per-tile partials -> stage 2
+  const bool stats_direct = want_stats && zs == 1 && vec;  // conv epilogue -> per-tile partials -> stage 2
   const bool stats_split = want_stats && zs > 1 && (cout & 3) == 0 && cout <= 1024 && (ldy & 3) == 0 &&
                            (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
-  if (ksplit == K && vec && g_pipeline && !p.accumulate && offset_major_shape(n_out, K, cin, cout) && (ldy & 3) == 0 &&
-      (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0) {
-    // offset-major, row-compacted: one slab per offset, reduced in ascending offset order (a class permutation of the
-    // rows is not needed -- the per-offset compaction is the finer tool)
-    const dim3 og((unsigned)cdiv(n_out, OT), (unsigned)cdiv(cout, BN), (unsigned)K);
-    if (w_transposed) offset_gemm_kernel<true><<<og, 256, 0, st>>>(p);
-    else offset_gemm_kernel<false><<<og, 256, 0, st>>>(p);
-    MINK_CHECK_LAUNCH();
-    const int tpr = cout >> 2, rlanes = 256 / tpr;
-    // (the statistics partials are limited to 512 rows; without them every (row, 4 columns) gets its own thread)
-    const int rows = (int)std::max<int64_t>(1, std::min<int64_t>(want_stats ? 512 : (1 << 20), cdiv(n_out, (int64_t)rlanes)));
-    if (want_stats) {
-      offset_reduce_kernel<true><<<dim3((unsigned)rows), 256, (size_t)rlanes * 2 * cout * sizeof(double), st>>>(
-          workspace, nbr, n_out, cout, K, bias, y, ldy, stats_out);
-      *stats_rows = rows;
-    } else {
-      offset_reduce_kernel<false><<<dim3((unsigned)rows), 256, 0, st>>>(workspace, nbr, n_out, cout, K, bias, y, ldy, nullptr);
-    }
-    MINK_CHECK_LAUNCH();
-    return MINK_OK;
-  }
-  if (compact_perm_shape(n_virtual, K, cin, cout, row_perm != nullptr) && row_perm && vec && g_pipeline && !p.accumulate && !stats_out &&
+  if (compact_perm_shape(n_virtual, K, cin, cout, row_perm != nullptr) && row_perm && vec && !p.accumulate && !stats_out &&
       (ldy & 3) == 0 && 4ll * K * cin * cout < (1ll << 31) && (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0) {
     // class-permuted rows, every live offset of a tile, split over channel chunks (compact_gemm_kernel<.., PERM>)
     constexpr int CMT = 64;
@@ -2371,7 +2116,7 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
   }
   if (stats_direct) p.stats = (float *)stats_ws;
   unsigned tiles_x = grid.x;  // row tiles that wrote statistics partials
-  const bool compact = g_compact && g_math == 0 && vec && g_pipeline && !row_perm && !p.accumulate && K >= 8 && p.kper <= CKP && cin >= 64 &&
+  const bool compact = g_compact && g_math == 0 && vec && !row_perm && !p.accumulate && K >= 8 && p.kper <= CKP && cin >= 64 &&
                        cin % BK == 0 && cout % BN == 0 && (ldy & 3) == 0 && 4ll * K * cin * cout < (1ll << 31) &&
                        (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
   if (compact) {  // row-compacted offsets, C tile in LDS (compact_gemm_kernel)
@@ -2391,7 +2136,7 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
     else compact_gemm_kernel<false, CMT><<<cgrid, 256, smem, st>>>(p);
   } else {
     const bool stage = row_perm != nullptr;
-    if (vec && g_pipeline) {
+    if (vec) {
       // the flat path addresses x rows with a 24-bit multiply: the table must not name a row >= 2^24 - 1 (n_in bounds it)
       const bool flat = cin == 28 && zs == 1 && !flip_k && !w_transposed && !stage && g_flat && ldx <= 32 &&
                         4ll * K * cin * cout < (1ll << 31) && n_in < (1 << 24) - 1;
@@ -2407,9 +2152,7 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
       else if (g_math == 3) MINK_LAUNCH_GG2(3);
       else MINK_LAUNCH_GG2(0);
 #undef MINK_LAUNCH_GG2
-    } else if (w_transposed && vec) gather_gemm_kernel<true, true><<<grid, 256, 0, st>>>(p);
-    else if (w_transposed) gather_gemm_kernel<true, false><<<grid, 256, 0, st>>>(p);
-    else if (vec) gather_gemm_kernel<false, true><<<grid, 256, 0, st>>>(p);
+    } else if (w_transposed) gather_gemm_kernel<true, false><<<grid, 256, 0, st>>>(p);  // operands that are not 16-byte rows (e.g. 27 channels)
     else gather_gemm_kernel<false, false><<<grid, 256, 0, st>>>(p);
   }
   MINK_CHECK_LAUNCH();
@@ -2505,7 +2248,7 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
   const bool bf16_stream = g_math == 1 && g_wgrad_bf16 && !g_wgrad_bf16_off && pl.G == 9 && stream_ok && g_wgrad_stream;
   // flattened (offset, channel) tiling: 24 instead of 27 tiles when the axis fits three groups of 256 rows and the
   // padded channels are worth saving; ldx <= 32 keeps "no neighbour" + "past the axis" inside 32-bit offset arithmetic
-  static const int flat_on = getenv("MINK_WGRAD_FLAT") ? atoi(getenv("MINK_WGRAD_FLAT")) : 1;
+  constexpr int flat_on = 1;
   const bool flat = flat_on && K * cin <= 768 && K * cin > 512 && ldx <= 32 && cin >= 16;
   if (fuse) {
     MINK_REQUIRE(pl.G == 9 && stream_ok && g_wgrad_stream && 4 * fuse->n_pool * ldy < (1ll << 31),
@@ -2513,11 +2256,7 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
     p.dyp = fuse->dyp, p.in2out = fuse->in2out, p.mean = fuse->mean, p.invstd = fuse->invstd, p.gamma = fuse->gamma;
     p.beta = fuse->beta, p.dgamma = fuse->dgamma, p.dbeta = fuse->dbeta, p.inv_n = 1.f / (float)n_out;
     p.dyp_bytes = (unsigned)(4 * fuse->n_pool * ldy), p.i2o_bytes = (unsigned)(4 * n_out);
-    static const int depth = getenv("MINK_WGRAD_DEPTH") ? atoi(getenv("MINK_WGRAD_DEPTH")) : 4;  // tuning hook: row pairs in flight
-    if (bf16_stream) wgrad_stream_bf16_kernel<true><<<grid, 256, 0, st>>>(p);
-    else if (depth == 6) wgrad_stream_kernel<6, true><<<grid, 256, 0, st>>>(p);
-    else if (depth == 8) wgrad_stream_kernel<8, true><<<grid, 256, 0, st>>>(p);
-    else if (depth == 2) wgrad_stream_kernel<2, true><<<grid, 256, 0, st>>>(p);
+    if (bf16_stream) wgrad_stream_bf16_kernel<true><<<grid, 256, 0, st>>>(p);  // (four row pairs in flight: 2 / 6 / 8 measured, DESIGN appendix)
     else if (flat) wgrad_stream_kernel<4, true, true><<<grid, 256, 0, st>>>(p);
     else wgrad_stream_kernel<4, true><<<grid, 256, 0, st>>>(p);
   } else if (bf16_stream) wgrad_stream_bf16_kernel<false><<<grid, 256, 0, st>>>(p);

@@ -38,7 +38,6 @@ def _as_int(v):
 _OFFSET_CACHE = {}
 
 
-_ONDEMAND_HASH = os.environ.get("MINK_ONDEMAND_HASH", "0") != "0"  # on-demand tables through the per-voxel hash (A/B, tests)
 
 
 def kernel_offsets(kernel_size, in_ts, dilation=1):
@@ -424,29 +423,11 @@ class CoordinateManager:
         self.trace.append(("ktable",) + kk + (bool(transposed),))
         self._sync_lazy()
         ent = self.tables.get(kk)
-        if (ent is None or (transposed and ent[1] is None)) and not _ONDEMAND_HASH:
+        if ent is None or (transposed and ent[1] is None):
             # a table asked for outside a prepared plan (first batches, tools): the same block-index builder, for one table
             self._build_tables_batched([("ktable",) + kk + (bool(transposed),)])
             ent = self.tables[kk]
             self._note_lazy(*ent)
-        elif ent is None or (transposed and ent[1] is None):  # MINK_ONDEMAND_HASH=1: the per-voxel hash look-up (mink_kernel_map)
-            lin, lout = self.levels[in_key.ts], self.levels[out_key.ts]
-            off = kernel_offsets(ks, in_key.ts, dil)
-            K = off.shape[0]
-            self._arena_only = False
-            nbr = torch.empty(max(lout.n, 1), K, dtype=torch.int32, device=self.device)[: lout.n]
-            nbr_t = None
-            if transposed:
-                nbr_t = torch.full((max(lin.n, 1), K), -1, dtype=torch.int32, device=self.device)[: lin.n]
-            check(
-                lib().mink_kernel_map(
-                    lin.tkeys.data_ptr(), lin.tvals.data_ptr(), lin.cap, lout.coords.data_ptr(), lout.n,
-                    off.ctypes.data, K, nbr.data_ptr(), nbr_t.data_ptr() if transposed else None, _stream(),
-                )
-            )
-            ent = (nbr, nbr_t)
-            self.tables[kk] = ent
-            self._note_lazy(nbr, nbr_t)
         return ent
 
     def kernel_map(self, in_key, out_key, stride=1, kernel_size=3, dilation=1, is_transpose=False, is_pool=False):

@@ -144,9 +144,6 @@ def kernel_timings():
 
 # ------------------------------------------------------------------------- convolution
 _FORCE_KSPLIT = 0  # benchmarking hook (scripts/kbench.py ksweep)
-if os.environ.get("MINK_OFFSET_MAJOR") == "1":  # A/B hook: deep layers (Cin >= 256) on the offset-major, row-compacted kernel
-    lib().mink_conv_set_stagger(2048)
-
 
 def gather_gemm(x, w, nbr, cout, w_transposed=False, flip_k=False, bias=None, row_perm=None, stats=False):
     """y[o] = sum_k x[nbr[o,k]] @ W[k] (+bias) on the fp32 matrix cores.  `stats=True` (forward

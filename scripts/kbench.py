@@ -57,7 +57,7 @@ if which == "stagger":
     nbr, _ = m.kernel_table(k1, k1, 3, 1)
     w = torch.randn(27, 28, 64, device=dev) * 0.05
     xin = x.F.contiguous()
-    for st in (0, 512, 0, 512, 0, 512, 256):
+    for st in (0, 512, 0, 512, 0, 512):  # bit 9: without the flattened-K stem path
         lib().mink_conv_set_stagger(st)
         t = timeit(lambda: Fn.gather_gemm(xin, w, nbr, 64), reps)
         print(f"stagger {st}: stem fwd {t*1e3:8.1f} us")

@@ -204,34 +204,27 @@ def test_block_index_tables_match_oracle(oracle_maps, grid, negative, dup):
 
 
 @pytest.mark.gpu
-def test_on_demand_tables_through_block_index_equal_the_per_voxel_hash():
-    """A neighbour table asked for outside a prepared plan goes through the block-index builder (one table per call);
-    the per-voxel hash look-up it replaced (mink_kernel_map, still in the C ABI) must give the same table bit for bit,
-    for every kernel shape the networks use: 3^3 stride 1 / 2 (with the transposed table), 2^3 stride 2, 1^3 stride 2."""
-    import importlib
-
+def test_block_index_tables_equal_the_per_voxel_hash():
+    """Neighbour tables come from the 4^3-block index (mink_kernel_map_batch); the per-voxel hash look-up it replaced
+    (mink_kernel_map, still in the C ABI for callers that keep ME's own map) must give the same table bit for bit, for
+    every kernel shape the networks use: 3^3 stride 1 / 2 (with the transposed table), 2^3 stride 2, 1^3 stride 2."""
     from nerf_downstream_amd import minkowski as ME
-    from nerf_downstream_amd.minkowski import coords as C
+    from nerf_downstream_amd._lib import check, lib
+    from nerf_downstream_amd.minkowski.coords import kernel_offsets
 
     coords, feats = batch_scenes([31, 32, 33], grid=48, cin=4)
-
-    def tables(hash_path):
-        old = C._ONDEMAND_HASH
-        C._ONDEMAND_HASH = hash_path
-        try:
-            x = ME.TensorField(coordinates=coords.cuda(), features=feats.cuda()).sparse()
-            m, k1 = x.coordinate_manager, x.coordinate_map_key
-            k2 = m.stride(k1, 2)
-            out = []
-            for kin, kout, ks, tr in ((k1, k1, 3, False), (k1, k2, 3, True), (k1, k2, 2, True), (k1, k2, 1, True), (k2, k2, 3, False)):
-                nbr, nbr_t = m.kernel_table(kin, kout, ks, 1, transposed=tr)
-                out += [nbr.cpu(), None if nbr_t is None else nbr_t.cpu()]
-            return out
-        finally:
-            C._ONDEMAND_HASH = old
-
-    a, b = tables(False), tables(True)
-    for ta, tb in zip(a, b):
-        assert (ta is None) == (tb is None)
-        if ta is not None:
-            assert ta.shape == tb.shape and torch.equal(ta, tb)
+    x = ME.TensorField(coordinates=coords.cuda(), features=feats.cuda()).sparse()
+    m, k1 = x.coordinate_manager, x.coordinate_map_key
+    k2 = m.stride(k1, 2)
+    for kin, kout, ks, tr in ((k1, k1, 3, False), (k1, k2, 3, True), (k1, k2, 2, True), (k1, k2, 1, True), (k2, k2, 3, False)):
+        nbr, nbr_t = m.kernel_table(kin, kout, ks, 1, transposed=tr)
+        lin, lout = m.levels[kin.ts], m.levels[kout.ts]
+        off = kernel_offsets(ks, kin.ts, 1)
+        K = off.shape[0]
+        ref = torch.empty(lout.n, K, dtype=torch.int32, device="cuda")
+        ref_t = torch.full((lin.n, K), -1, dtype=torch.int32, device="cuda") if tr else None
+        check(lib().mink_kernel_map(lin.tkeys.data_ptr(), lin.tvals.data_ptr(), lin.cap, lout.coords.data_ptr(), lout.n,
+                                    off.ctypes.data, K, ref.data_ptr(), None if ref_t is None else ref_t.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert torch.equal(nbr, ref), (kin.ts, kout.ts, ks)
+        assert (nbr_t is None) == (ref_t is None) and (ref_t is None or torch.equal(nbr_t, ref_t)), (kin.ts, kout.ts, ks)

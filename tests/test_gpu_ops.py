@@ -45,21 +45,6 @@ def test_convolution(oracle_maps, cin, cout, ksize, stride, ts, grid):
     _convolution_case(oracle_maps, cin, cout, ksize, stride, ts, grid)
 
 
-@pytest.mark.parametrize("cin,cout,stride,ts,grid", [(256, 256, 1, 8, 32), (256, 512, 2, 8, 64), (512, 512, 1, 16, 64)])
-def test_convolution_offset_major_path(oracle_maps, cin, cout, stride, ts, grid):
-    """The offset-major, row-compacted kernel for the deep layers (selectable; off by default):
-    forward, flipped-table and strided data gradients against the oracle, and bitwise run-to-run."""
-    from nerf_downstream_amd._lib import lib
-
-    lib().mink_conv_set_stagger(2048)
-    try:
-        assert lib().mink_conv_plan(2000, 27, cin, cout, 0) == 27
-        _convolution_case(oracle_maps, cin, cout, 3, stride, ts, grid)
-    finally:
-        lib().mink_conv_set_stagger(0)
-    assert lib().mink_conv_plan(2000, 27, cin, cout, 0) != 27 or cin < 256
-
-
 def _convolution_case(oracle_maps, cin, cout, ksize, stride, ts, grid):
     torch.manual_seed(1)
     ME, OME, tf, otf = _pair([3, 4], grid, cin, negative=True)
