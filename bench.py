@@ -306,8 +306,6 @@ def main():
         Fn.set_wgrad_overlap(os.environ["BENCH_WGRAD_OVERLAP"] != "0")
     state = {"tf": model.process_input(batches[0])}
 
-    gated = os.environ.get("BENCH_PREPARE_GATE", "0") != "0"
-
     def step(i):
         # software pipeline: the TensorField (+ coordinate/kernel maps, built on a side stream) of
         # batch i+1 is prepared while batch i computes; every step builds exactly one set.  The
@@ -316,23 +314,15 @@ def main():
         tf = state["tf"]
         side = getattr(model, "_side", None)
         Fn.log_phase("step_begin", torch.cuda.current_stream())
-        if not gated:
-            Fn.log_phase("pyramid_begin", side)
-            nxt = model.process_input(batches[(i + 1) % len(batches)], defer=True)
-            Fn.log_phase("pyramid_end", side)
+        Fn.log_phase("pyramid_begin", side)
+        nxt = model.process_input(batches[(i + 1) % len(batches)], defer=True)
+        Fn.log_phase("pyramid_end", side)
         if reducer is not None:
             reducer.zero_grad()
         else:
             opt.zero_grad(set_to_none=True)
         Fn.log_phase("grads_cleared", torch.cuda.current_stream())
         out = model(tf)
-        if gated:  # the next batch's preparation starts once this batch's stem convolution is done (Fn.mark_phase)
-            Fn.log_phase("forward_queued", torch.cuda.current_stream())
-            if Fn._PHASE_LOG is not None and side is not None:  # (so that the mark below is stamped behind the gate)
-                side.wait_event(Fn.phase_event("stem_forward"))
-            Fn.log_phase("pyramid_begin", side)
-            nxt = model.process_input(batches[(i + 1) % len(batches)], defer=True, gate=Fn.phase_event("stem_forward"))
-            Fn.log_phase("pyramid_end", side)
         loss = cross_entropy(out, labels_dev[i % len(batches)])  # the trainer's own loss call (classification_training.py)
         loss.backward()
         Fn.log_phase("backward_queued", torch.cuda.current_stream())

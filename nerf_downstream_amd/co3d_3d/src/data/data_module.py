@@ -55,6 +55,31 @@ class LengthBalancedDistributedSampler(Sampler):
             yield from (int(idx[j]) for j in mine)
 
 
+class EpochSampler(Sampler):
+    """Single-rank shuffling whose order is a function of (seed, epoch) alone -- what DistributedSampler gives the
+    multi-rank runs -- so a run resumed inside epoch e draws epoch e's permutation again, and `skip(k)` drops the k
+    samples trained on before the checkpoint at the INDEX level (no scene is loaded to be thrown away)."""
+
+    def __init__(self, n, seed=0):
+        self.n, self.seed, self.epoch, self._skip = int(n), int(seed), 0, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def skip(self, samples):
+        self._skip = int(samples)  # for the next iteration only
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.seed + self.epoch)
+        perm = torch.randperm(self.n, generator=g).tolist()
+        k, self._skip = self._skip, 0
+        return iter(perm[k:])
+
+
 class DataModule:
     def __init__(self, train_phase="train", val_phase="val", test_phase="test", batch_size=12, val_batch_size=6,
                  train_num_workers=4, val_num_workers=2, collate_func_name="collate_mink", world_size=1, rank=0, seed=0):
@@ -74,11 +99,11 @@ class DataModule:
                 sampler = LengthBalancedDistributedSampler(lengths, batch_size, self.world_size, self.rank, seed=self.seed)
             else:
                 sampler = DistributedSampler(ds, self.world_size, self.rank, shuffle=shuffle, seed=self.seed, drop_last=shuffle)
-        g = torch.Generator()
-        g.manual_seed(self.seed)
+        elif shuffle:
+            sampler = EpochSampler(len(ds), seed=self.seed)
         return DataLoader(ds, batch_size=batch_size, num_workers=workers, collate_fn=self.collate_fn,
-                          shuffle=shuffle and sampler is None, sampler=sampler, pin_memory=False,
-                          persistent_workers=workers > 0, drop_last=shuffle, generator=g)
+                          shuffle=False, sampler=sampler, pin_memory=False,
+                          persistent_workers=workers > 0, drop_last=shuffle)
 
     def train_dataloader(self):
         if not hasattr(self, "train_dataset"):

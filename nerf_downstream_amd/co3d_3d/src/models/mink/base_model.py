@@ -26,20 +26,12 @@ class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
         self._side = None
         self.prepare_ahead = True
 
-    def process_input(self, batch, defer=False, _fence=True, gate=None):
+    def process_input(self, batch, defer=False, _fence=True):
         """`defer=True` (extension, HIP backend): only launch the coordinate pyramid of this batch
         on the side stream and return at once; `finish_input(field)` -- call it after the current
         batch's forward/backward have been queued -- reads the row counts back (already there by
-        then, so the host never blocks) and builds the kernel maps.  `gate`: an event the prepare stream waits for
-        before it starts on this batch (the training loops pass the current step's "stem_forward" phase event, so
-        preparation runs beside the small middle layers, not beside the stem kernels)."""
+        then, so the host never blocks) and builds the kernel maps."""
         ME = self._ME
-        if gate is not None and self.prepare_ahead and getattr(ME, "SUPPORTS_PREPARE_AHEAD", False):
-            import torch
-
-            if self._side is None:
-                self._side = self._new_prepare_stream(torch.device("cuda", torch.cuda.current_device()))
-            self._side.wait_event(gate)
         if "links" in batch:  # compact PeRFception batch: de-quantise + links -> coordinates on the device
             with self._prepare_stream_ctx(batch["links"], fence=batch.get("h2d_event", True)):
                 coords, feats = ME.utils.decode_plenoxel_batch(batch)

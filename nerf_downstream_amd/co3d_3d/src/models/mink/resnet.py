@@ -99,7 +99,7 @@ class ResNetBase(MinkowskiBaseModel):
             # an input that needs a gradient) takes the module path.
             from nerf_downstream_amd.minkowski import trunk
 
-            if self._trunk_plan is None:
+            if self._trunk_plan is None or (self._trunk_plan and trunk.stale(self._trunk_plan)):
                 self._trunk_plan = trunk.plan_for(self) or False
             xs = x.sparse()
             if self._trunk_plan and trunk.usable(self, self._trunk_plan, xs):

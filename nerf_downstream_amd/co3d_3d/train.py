@@ -243,9 +243,12 @@ def train(
     while not done and (max_epochs <= 0 or epoch < max_epochs):
         if hasattr(train_loader.sampler, "set_epoch"):
             train_loader.sampler.set_epoch(epoch)
-        it = iter(train_loader)
         batch_in_epoch = 0
-        for _ in range(skip_batches):  # resumed inside this epoch: these batches were trained on before the checkpoint
+        if skip_batches and hasattr(train_loader.sampler, "skip"):  # resumed inside this epoch: drop what was trained on, by index
+            train_loader.sampler.skip(skip_batches * train_loader.batch_size)
+            batch_in_epoch, skip_batches = skip_batches, 0
+        it = iter(train_loader)
+        for _ in range(skip_batches):  # (samplers without skip(): the batches are drawn and dropped)
             if next(it, None) is None:
                 break
             batch_in_epoch += 1

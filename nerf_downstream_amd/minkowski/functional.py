@@ -302,23 +302,6 @@ _HOME_STREAMS = {}  # device index -> the stream the network itself runs on (not
 _BRANCH_STREAMS = {}
 
 
-_PHASE_EVENTS = {}
-
-
-def mark_phase(name, stream):
-    """Record the process-wide event `name` on `stream` (re-recorded every step).  The native trunk marks
-    "stem_forward" once the stem convolution of a batch is queued: the two stem kernels fill every register file of
-    the chip, and map preparation that lands beside them costs both sides (rocprof: the stem neighbour table 0.17 ms
-    alone, 0.71 ms beside the stem weight gradient, which itself goes from 0.83 to 0.94 ms), so the next batch's
-    preparation is gated to start after it -- in the latency-bound middle of the step (`process_input(gate=...)`)."""
-    ev = _PHASE_EVENTS.get(name)
-    if ev is None:
-        ev = _PHASE_EVENTS[name] = torch.cuda.Event()
-    ev.record(stream)
-    log_phase(name, stream)
-    return ev
-
-
 _PHASE_LOG = None  # diagnostic (bench.py --timeline): [(name, timing event, host clock)] of every mark
 
 
@@ -329,11 +312,6 @@ def log_phase(name, stream):
         t = torch.cuda.Event(enable_timing=True)
         t.record(stream)
         _PHASE_LOG.append((name, t, time.perf_counter()))
-
-
-def phase_event(name):
-    """The event of `mark_phase(name)`, or None if that phase has not been marked (e.g. module-by-module path)."""
-    return _PHASE_EVENTS.get(name)
 
 
 _SKEW = int(os.environ.get("MINK_STREAM_SKEW", "0"))  # race hunting: delay every auxiliary stream by this many GPU cycles

@@ -32,7 +32,7 @@ class _Stage:
 
 
 class _Plan:
-    __slots__ = ("stages", "params", "norms", "stem", "out_ts", "ptrs", "ex")
+    __slots__ = ("stages", "params", "norms", "stem", "out_ts", "ptrs", "ex", "sources")
 
 
 def plan_for(model):
@@ -79,6 +79,14 @@ def plan_for(model):
             ts *= st.stride
             stages.append(st)
     plan.stages, plan.params, plan.out_ts = stages, params, ts
+    # where every parameter lives (module, attribute), in the order of `params`: `stale()` compares identities
+    src = [(model.conv1, "kernel"), (model.bn1.bn, "weight"), (model.bn1.bn, "bias")]
+    for st in stages:
+        src += [(st.conv1, "kernel"), (st.norm1.bn, "weight"), (st.norm1.bn, "bias"), (st.conv2, "kernel"), (st.norm2.bn, "weight"),
+                (st.norm2.bn, "bias")]
+        if st.down is not None:
+            src += [(st.down, "kernel"), (st.normd.bn, "weight"), (st.normd.bn, "bias")]
+    plan.sources = src
     plan.norms = [model.bn1] + [n for s in stages for n in (s.norm1, s.norm2, s.normd) if n is not None]
     plan.stem, plan.ptrs, plan.ex = _StemDesc(), None, Exec()
     return plan
@@ -109,9 +117,21 @@ def _fill_static(plan):
             _fill_norm(d.normd, st.normd)
 
 
+def stale(plan):
+    """True when a module no longer holds the Parameter object the plan captured (load_state_dict(assign=True),
+    torch.utils.swap_tensors, a re-assigned attribute): the plan must be rebuilt -- its kernels would read, and its
+    gradients go to, tensors the model no longer owns."""
+    for (mod, name), p in zip(plan.sources, plan.params):
+        if getattr(mod, name) is not p:
+            return True
+    return False
+
+
 def _refresh(plan):
-    """Re-write the static part when a parameter or buffer has moved (load_state_dict(assign=True), .to(), ...)."""
-    ptrs = tuple(p.data_ptr() for p in plan.params) + tuple(n.bn.running_mean.data_ptr() for n in plan.norms)
+    """Re-write the static part when a parameter or buffer has moved in place (.to(), .data swaps) or a norm's
+    momentum / eps was changed."""
+    ptrs = tuple(p.data_ptr() for p in plan.params) + tuple(n.bn.running_mean.data_ptr() for n in plan.norms) + \
+        tuple((n.bn.momentum, n.bn.eps) for n in plan.norms)
     if ptrs != plan.ptrs:
         _fill_static(plan)
         plan.ptrs = ptrs
@@ -214,7 +234,7 @@ class TrunkFunction(torch.autograd.Function):
         sd.x, sd.y, sd.out, sd.g_out = x.data_ptr(), a0, a0 + 4 * n0 * C0, None
         Fn.log_phase("stem_forward_begin", cur)
         check(L.mink_stem_forward(ctypes.byref(sd), exp))
-        Fn.mark_phase("stem_forward", cur)
+        Fn.log_phase("stem_forward", cur)
         Fn.note_table(nbr0)
         saved = [(x, w0, arena0, nbr0, nbr_pool, i2o, pad)]
         # ---- residual blocks

@@ -212,3 +212,33 @@ def test_native_trunk_is_bitwise_the_module_path(oracle_maps, name, cin, seeds):
             assert torch.equal(g[k], ref_g[k]), (overlap, k)
         for k in ref_b:
             assert torch.equal(b[k], ref_b[k]), (overlap, k)
+
+
+def test_native_trunk_follows_replaced_parameters(oracle_maps):
+    """load_state_dict(assign=True) REPLACES the Parameter objects of the modules.  The trunk's plan captured the old
+    ones: it must notice (trunk.stale) and rebuild, or the forward pass would keep reading -- and the backward pass keep
+    writing gradients to -- tensors the model no longer owns."""
+    from helpers import trunk_node
+
+    coords, feats = batch_scenes([51, 52, 53], grid=64, cin=28)
+    batch = {"coordinates": coords.cuda(), "features": feats.cuda()}
+    labels = torch.tensor([3, 7, 11]).cuda()
+    hip, _ = _models("ResNet14", 28, 51)
+    out0 = hip(hip.process_input(batch))
+    assert trunk_node(out0) is not None
+    F.cross_entropy(out0, labels).backward()
+    torch.manual_seed(123)
+    other = {k: (torch.randn_like(v) * 0.05 if v.is_floating_point() and v.dim() > 1 else v.clone()) for k, v in hip.state_dict().items()}
+    hip.load_state_dict(other, assign=True)
+    hip.zero_grad(set_to_none=True)
+    out1 = hip(hip.process_input(batch))
+    assert trunk_node(out1) is not None
+    F.cross_entropy(out1, labels).backward()
+    fresh, _ = _models("ResNet14", 28, 51)
+    fresh.load_state_dict(other)
+    out2 = fresh(fresh.process_input(batch))
+    F.cross_entropy(out2, labels).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2) and not torch.equal(out1, out0)
+    for (k, p), (_, q) in zip(hip.named_parameters(), fresh.named_parameters()):
+        assert p.grad is not None and torch.equal(p.grad, q.grad), k

@@ -449,3 +449,22 @@ def test_density_based_sample_recipe(tmp_path, monkeypatch):
     assert np.array_equal(plain["features"][:, 0].numpy(), d[keep]) and plain["aug_params"].shape == (44,)
     with pytest.raises(NotImplementedError):
         T.Compose([T.CoordinateDropout(), T.DensityBasedSample()])
+
+
+def test_single_rank_resume_replays_the_epoch_permutation():
+    """Single-rank shuffling is a function of (seed, epoch) (EpochSampler): a run resumed inside epoch e, b batches in,
+    sees exactly the remaining indices of epoch e's permutation -- no scene twice, none skipped -- and the skipped
+    samples are dropped by index, not loaded."""
+    from nerf_downstream_amd.co3d_3d.src.data.data_module import EpochSampler
+
+    s = EpochSampler(23, seed=5)
+    s.set_epoch(3)
+    full = list(s)
+    assert sorted(full) == list(range(23)) and list(s) == full  # same epoch, same order
+    s.set_epoch(4)
+    assert list(s) != full
+    r = EpochSampler(23, seed=5)  # the resumed process
+    r.set_epoch(3)
+    r.skip(2 * 4)  # two batches of four were trained on
+    assert list(r) == full[8:]
+    assert list(r) == full  # the skip applies to one iteration only
