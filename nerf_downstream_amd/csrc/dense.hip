@@ -21,35 +21,48 @@ __device__ __forceinline__ float4 ld4g(const float *p) { return *reinterpret_cas
 // kernel is W[cin = N][cout = Kd] (reference modules/common.py:116-125 with kernel_size 1: `downsample`,
 // models/mink/resnet.py:120-128).  64 x 64 output tile per workgroup, four waves of 32 x 32 on v_mfma_f32_32x32x2_f32:
 // one accumulator chain per output element, k ascending -- bit for bit the sum the gather-GEMM forms for a one-column table.
-constexpr int DT = 64, DK = 32, DLD = DK + 1;  // odd LDS row stride: the 32 lanes of a half-wave read 32 rows of one column
+constexpr int DT = 64, DK = 32, DLT = DT + 1;  // LDS tiles are k-major [k][row]: the 32 lanes of a half-wave read 32 consecutive rows
 
 __global__ __launch_bounds__(256) void dense_xwt_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         float *__restrict__ y, int64_t n, int Kd, int N) {
-  __shared__ float sA[DT * DLD], sB[DT * DLD];
+  __shared__ float sA[2][DK * DLT], sB[2][DK * DLT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * DT;
   const int col0 = blockIdx.y * DT;
   const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1);
   f32x16 acc = (f32x16){0};
-  for (int k0 = 0; k0 < Kd; k0 += DK) {
-    // stage A = x[row0.., k0..k0+32) and B = w[col0.., k0..k0+32): 64 rows x 8 float4 each, two per thread
+  // A = x[row0.., k0..k0+32) and B = w[col0.., k0..k0+32): 64 rows x 8 float4 each, two per thread; the next chunk's
+  // loads are issued before this chunk's MFMAs (double-buffered LDS, one barrier per chunk)
+  float4 ra[2], rb[2];
+  auto gload = [&](int k0) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int e = tid + 256 * it, r = e >> 3, c = (e & 7) * 4;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      if (row0 + r < n && k0 + c < Kd) a = ld4g(x + (row0 + r) * Kd + k0 + c);
-      if (col0 + r < N && k0 + c < Kd) b = ld4g(w + (int64_t)(col0 + r) * Kd + k0 + c);
-      float *da = sA + r * DLD + c, *db = sB + r * DLD + c;
-      da[0] = a.x, da[1] = a.y, da[2] = a.z, da[3] = a.w;
-      db[0] = b.x, db[1] = b.y, db[2] = b.z, db[3] = b.w;
+      ra[it] = rb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < n && k0 + c < Kd) ra[it] = ld4g(x + (row0 + r) * Kd + k0 + c);
+      if (col0 + r < N && k0 + c < Kd) rb[it] = ld4g(w + (int64_t)(col0 + r) * Kd + k0 + c);
     }
-    __syncthreads();
+  };
+  auto sts = [&](int buf) {
 #pragma unroll
-    for (int kk = 0; kk < DK; kk += 2) {
-      const float a = sA[(wr + (lane & 31)) * DLD + kk + (lane >> 5)];
-      const float b = sB[(wc + (lane & 31)) * DLD + kk + (lane >> 5)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int it = 0; it < 2; ++it) {
+      const int e = tid + 256 * it, r = e >> 3, c = (e & 7) * 4;
+      float *da = sA[buf] + c * DLT + r, *db = sB[buf] + c * DLT + r;
+      da[0] = ra[it].x, da[DLT] = ra[it].y, da[2 * DLT] = ra[it].z, da[3 * DLT] = ra[it].w;
+      db[0] = rb[it].x, db[DLT] = rb[it].y, db[2 * DLT] = rb[it].z, db[3 * DLT] = rb[it].w;
     }
+  };
+  gload(0);
+  sts(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < Kd; k0 += DK, buf ^= 1) {
+    const bool more = k0 + DK < Kd;
+    if (more) gload(k0 + DK);
+    const float *a = sA[buf] + (lane >> 5) * DLT + wr + (lane & 31), *b = sB[buf] + (lane >> 5) * DLT + wc + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < DK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk * DLT], b[kk * DLT], acc, 0, 0, 0);
+    if (more) sts(buf ^ 1);
     __syncthreads();
   }
   const int col = col0 + wc + (lane & 31);

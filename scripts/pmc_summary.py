@@ -31,7 +31,10 @@ json.dump(res, open(out, "w"), indent=1)
 import os
 
 head = os.environ.get("GIT_HEAD", "").strip()
-json.dump({"tag": os.path.basename(out).replace("_pmc.json", "").replace(".json", ""), "git_head": head or "unknown"},
+tag = os.path.basename(out).replace("_pmc.json", "").replace(".json", "")
+if tag == "pmc":  # gpurun_out/<tag>/pmc.json
+    tag = os.path.basename(os.path.dirname(os.path.abspath(out)))
+json.dump({"tag": tag, "git_head": head or "unknown"},
           open(out.replace(".json", ".meta.json"), "w"), indent=1)
 for e in res[:16]:
     print({k: e[k] for k in ("kernel", "workgroups", "launches", "hbm_traffic_bytes_per_launch", "mfma_pipe_util") if k in e})
