@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--num-classes", type=int, default=51)
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="matrix-core arithmetic of conv forward/dgrad (fp32 = exact, the headline; bf16 = BASELINE config #3)")
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
+                    help="HBM storage of the full-resolution stage (input features, stem output) under --math bf16")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only (CPU test): rendezvous over gloo, one all-reduce, print ranks_seen; no compute, no number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -282,6 +284,9 @@ def main():
 
     _lib.lib()  # fail loudly if the HIP backend is missing
     Fn.set_conv_math(args.math)
+    if args.storage == "bf16" and args.math != "bf16":
+        raise SystemExit("--storage bf16 needs --math bf16")
+    Fn.set_conv_storage(args.storage)
     if os.environ.get("BENCH_COMPUTE_STREAM", "0") != "0":
         # compute on a stream of its own instead of the legacy default stream: a CU-subset stream
         # (hipExtStreamCreateWithCUMask has no non-blocking flag) synchronises implicitly with the default stream
@@ -421,6 +426,7 @@ def main():
         raise SystemExit(f"non-finite loss {loss_val}: invalid run")
 
     if rank == 0:
+        storage_note = " math, bf16 storage at full resolution" if args.storage == "bf16" else ""
         res = {
             "metric": f"voxels/sec fwd+bwd Mink-{args.model} on CO3D plenoxels",
             "value": vox.item() / tmax.item(),
@@ -433,12 +439,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16 (MFMA operands of forward, data gradient and the stem weight gradient; fp32 accumulate and storage, mid-layer wgrad fp32)",
-                      "bf16x3": "f32 via split-bf16 MFMA (3 products)"}[args.math],
+                      "bf16x3": "f32 via split-bf16 MFMA (3 products)"}[args.math]
+            + (" -- bf16 STORAGE of the input features and the stem output" if args.storage == "bf16" else ""),
             "data": "synthetic",
             "config": {
                 "workload": f"Mink-{args.model} full CO3D-category classification ({args.num_classes} classes), "
                 f"batch={args.batch}/GPU, {args.grid}^3 synthetic plenoxel grids (~{vox_per_step[0] // args.batch} voxels x "
-                f"{args.in_channel} SH+density features per scene), fp32, fwd+bwd+SGD step incl. coordinate/kernel map build",
+                f"{args.in_channel} SH+density features per scene), {args.math}{storage_note}, fwd+bwd+SGD step incl. coordinate/kernel map build",
                 "global_batch": args.batch * world,
                 "voxels_per_step_per_gpu": vox_per_step[0],
                 "parallelism": f"dp{world}",

@@ -508,6 +508,8 @@ typedef struct {
   float *y;        /* [n][cout] convolution output (kept for backward) */
   float *out;      /* [n_pool][cout] */
   const float *g_out;  /* backward: gradient of `out` */
+  void *xb;        /* ABI 3, bf16 storage (needs mink_conv_set_math(1)): [n][32] bf16 copy of x, written by forward and read by
+                      backward; `y` is then bf16 [n][cout].  NULL: fp32 storage */
 } MinkStem;
 
 typedef struct {
@@ -531,6 +533,34 @@ int mink_stem_forward(const MinkStem *s, const MinkExec *ex);
 int mink_stem_backward(const MinkStem *s, const MinkExec *ex);
 int mink_block_forward(const MinkBasicBlock *b, const MinkExec *ex);
 int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex);
+
+/* ------------------------------------------------------------------ bf16 storage of the full-resolution stage
+ * BASELINE config "bf16 mixed precision", storage form: the network input and the stem convolution's output -- three
+ * quarters of the activation bytes of a Mink-ResNet step -- are kept in HBM as bf16; the pooled level and everything
+ * below stay fp32.  Arithmetic is that of mink_conv_set_math(1) (bf16 operands, fp32 accumulation); the batch-norm
+ * statistics are those of the STORED (rounded) convolution output.
+ *   mink_rows_to_bf16     x fp32 [n][c] (pitch ldx) -> xb bf16 [n][32], zero-padded (c <= 32)
+ *   mink_stem_conv_bf16s  yb bf16 [n_out][64] = conv over nbr [n_out][27] of xb with w fp32 [27][cin][64];
+ *                         stats_out: double [stats_rows][2][64] column (sum, sum of squares) partials for
+ *                         mink_bn_stats_from_partials; stats_rows must equal mink_stem_conv_bf16s_stats_rows()
+ *                         (one row per workgroup of the persistent launch)
+ *   mink_bn_relu_pool_fwd_b16 / _bwd_b16: mink_bn_relu_pool_fwd / _bwd (parameter gradients only) reading that bf16 output
+ *   mink_conv_wgrad_bn_relu_pool_b16: mink_conv_wgrad_bn_relu_pool with x = xb (pitch 32) and y bf16 */
+int mink_rows_to_bf16(const float *x, int64_t n, int32_t c, int32_t ldx, void *xb, void *stream);
+int mink_stem_conv_bf16s_supported(int64_t n_in, int64_t n_out, int32_t K, int32_t cin, int32_t cout);
+int32_t mink_stem_conv_bf16s_stats_rows(void);
+int mink_stem_conv_bf16s(const void *xb, int64_t n_in, const float *w, int32_t cin, const int32_t *nbr, int64_t n_out, int32_t K,
+                         void *yb, int32_t cout, double *stats_out, int32_t stats_rows, void *stream);
+int mink_bn_relu_pool_fwd_b16(const void *xb, int32_t C, const float *mean, const float *invstd, const float *gamma,
+                              const float *beta, const int32_t *nbr, int64_t n_out, int32_t K, float *y, void *stream);
+int mink_bn_relu_pool_bwd_b16(const float *dy_pool, const void *xb, int64_t n, int32_t C, const float *mean, const float *invstd,
+                              const float *gamma, const float *beta, const int32_t *in2out, float *dgamma, float *dbeta,
+                              void *workspace, int64_t workspace_bytes, void *stream);
+int mink_conv_wgrad_bn_relu_pool_b16(const void *xb, int64_t n_in, int32_t cin, const void *yb, int32_t cout, const float *dy_pool,
+                                     int64_t n_pool, const int32_t *in2out, const float *mean, const float *invstd,
+                                     const float *gamma, const float *beta, const float *dgamma, const float *dbeta,
+                                     const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace,
+                                     int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ streams confined to a CU subset
  * A HIP stream whose kernels may only run on compute units [first_cu, first_cu + n_cus) of the device's

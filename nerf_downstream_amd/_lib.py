@@ -48,7 +48,7 @@ class Stem(ctypes.Structure):
     """MinkStem"""
 
     _fields_ = [("conv", ConvLayer), ("norm", NormLayer), ("nbr_pool", _p), ("in2out", _p), ("n", _i64), ("n_pool", _i64),
-                ("x", _p), ("y", _p), ("out", _p), ("g_out", _p)]
+                ("x", _p), ("y", _p), ("out", _p), ("g_out", _p), ("xb", _p)]
 
 
 class BasicBlock(ctypes.Structure):
@@ -138,6 +138,16 @@ SIGNATURES = {
     "mink_activation": (ctypes.c_int, [_p, _p, _p, _i32, _i64, _i32, _f32, _p, _p]),
     "mink_block_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
     "mink_block_grad_scratch_floats": (_i64, [_i64, _i64, _i32, _i32, _i32]),
+    "mink_rows_to_bf16": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p]),
+    "mink_stem_conv_bf16s_supported": (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32]),
+    "mink_stem_conv_bf16s_stats_rows": (_i32, []),
+    "mink_stem_conv_bf16s": (ctypes.c_int, [_p, _i64, _p, _i32, _p, _i64, _i32, _p, _i32, _p, _i32, _p]),
+    "mink_bn_relu_pool_fwd_b16": (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
+    "mink_bn_relu_pool_bwd_b16": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "mink_conv_wgrad_bn_relu_pool_b16": (
+        ctypes.c_int,
+        [_p, _i64, _i32, _p, _i32, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _p],
+    ),
     "mink_stem_supported": (ctypes.c_int, [_i64, _i32, _i32, _i32]),
     "mink_stem_forward": (ctypes.c_int, [_p, _p]),
     "mink_stem_backward": (ctypes.c_int, [_p, _p]),

@@ -1629,12 +1629,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
 // the pooled gradient as the fp32 kernel does (parents one block ahead).
 using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
 
+__device__ __forceinline__ bf16x8v pack_bits_bf16x8(const float (&v)[8]) {  // registers that already hold bf16 bits in their low halves
+  auto lo = [&](int i) { return __float_as_uint(v[i]); };
+  const uint4 u = make_uint4(lo(0) | (lo(1) << 16), lo(2) | (lo(3) << 16), lo(4) | (lo(5) << 16), lo(6) | (lo(7) << 16));
+  return __builtin_bit_cast(bf16x8v, u);
+}
 __device__ __forceinline__ bf16x8v pack_bf16x8(const float (&v)[8]) {
   const uint4 u = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
   return __builtin_bit_cast(bf16x8v, u);
 }
 
-template <bool FUSE>
+// B16 (bf16 STORAGE of the full-resolution stage, stem16.hip): x is the bf16 copy of the input ([n][32], 64-byte rows) and
+// `dy` -- FUSE: the convolution output -- is bf16 too; the operands are then 2-byte loads that need no conversion.
+template <bool FUSE, bool B16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p) {
   constexpr int G = 9, SB = 1;           // offsets per group, offsets per sub-batch (gathers run one sub-batch ahead)
   __shared__ float sR[2 * 16 * 64];
@@ -1651,13 +1658,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
   const int nrel = (int)(rend - rbeg);
   const int nblocks = (nrel + 15) >> 4;
   const int nq = (nblocks + 1 - wa) >> 1;  // this wave's blocks: b = 2 q + wa
-  const unsigned ldx4 = 4u * p.ldx, ldy4 = 4u * p.ldy, K4 = 4u * p.K;
+  const unsigned ldx4 = (B16 ? 2u : 4u) * p.ldx, ldy4 = (B16 ? 2u : 4u) * p.ldy, ldp4 = 4u * p.ldy, K4 = 4u * p.K;
   // (as in the fp32 kernel: what is indexed by the output row ends at this split's last row -- rows past it read zeros)
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rd = make_rsrc(p.dy, (unsigned)rend * ldy4), rn = make_rsrc(p.nbr, p.nbr_bytes);
   const __amdgpu_buffer_rsrc_t rp = make_rsrc(FUSE ? (const void *)p.dyp : (const void *)p.dy, FUSE ? p.dyp_bytes : 0u),
                                ri = make_rsrc(FUSE ? (const void *)p.in2out : (const void *)p.nbr, FUSE ? (unsigned)rend * 4u : 0u);
-  const unsigned xcol = 4u * min(col, p.cin - 1);
-  const unsigned dcol = 4u * min(co0 + 32 * wn + col, p.cout - 1);
+  const unsigned xcol = (B16 ? 2u : 4u) * min(col, p.cin - 1);
+  const unsigned dcol = (B16 ? 2u : 4u) * min(co0 + 32 * wn + col, p.cout - 1), pcol = 4u * min(co0 + 32 * wn + col, p.cout - 1);
   const int cco = min(co0 + 32 * wn + col, p.cout - 1);
   const float c_mu = FUSE ? p.mean[cco] : 0.f, c_is = FUSE ? p.invstd[cco] : 0.f, c_ga = FUSE ? p.gamma[cco] : 0.f,
               c_be = FUSE ? p.beta[cco] : 0.f, c_dgn = FUSE ? p.dgamma[cco] * p.inv_n : 0.f,
@@ -1703,8 +1710,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = 16 * (2 * q + wa) + 8 * h + j;
-        braw[j] = buf_load(rd, __umul24(r, ldy4) + dbase);
-        if (FUSE) bpool[j] = buf_load(rp, __umul24(par[j], ldy4) + dcol);
+        if constexpr (B16)
+          braw[j] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rd, (int)(__umul24(r, ldy4) + dbase), 0, 0) << 16);
+        else
+          braw[j] = buf_load(rd, __umul24(r, ldy4) + dbase);
+        if (FUSE) bpool[j] = buf_load(rp, __umul24(par[j], ldp4) + pcol);
       }
     };
     auto b_fragment = [&](int q) __attribute__((always_inline)) {
@@ -1731,7 +1741,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
         const unsigned nbv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          xraw[buf][g][j] = buf_load(rx, __umul24(nbv[j], ldx4) + xcol);  // (-1 is row 0xFFFFFF: beyond x, reads as zero)
+          if constexpr (B16)  // (the bf16 bits, kept in the low half of the register)
+            xraw[buf][g][j] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rx, (int)(__umul24(nbv[j], ldx4) + xcol), 0, 0));
+          else
+            xraw[buf][g][j] = buf_load(rx, __umul24(nbv[j], ldx4) + xcol);  // (-1 is row 0xFFFFFF: beyond x, reads as zero)
       }
     };
     // ---- prologue: table of block 0 staged, of block 1 in flight; B operands and first x sub-batch of block 0 in flight
@@ -1760,7 +1773,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_bf16_kernel(WgradParams p
           load_x(nxt, slot ^ 1, 0);
           load_table(q + 2);
         }
-        acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack_bf16x8(xraw[cur][0]), bfrag, acc[sb], 0, 0, 0);
+        acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B16 ? pack_bits_bf16x8(xraw[cur][0]) : pack_bf16x8(xraw[cur][0]), bfrag, acc[sb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);  // keep the sub-batches (and the load FIFO) in program order
       }
     }
@@ -2208,6 +2221,7 @@ struct WgradFuse {  // dy = input gradient of pool(relu(bn(y))): see mink_conv_w
   const int32_t *in2out;
   int64_t n_pool;
   const float *mean, *invstd, *gamma, *beta, *dgamma, *dbeta;
+  int b16;  // x and y are bf16 (x: [n_in][ldx] with ldx = 32; y: [n_out][cout]) -- bf16 storage of the full-resolution stage
 };
 
 static bool wgrad_stream_ok(int64_t n_in, int32_t ldx, int32_t cin, int32_t ldy, int32_t cout, int64_t n_out, int32_t K) {
@@ -2241,7 +2255,8 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
   p.ngroups = pl.ngroups;
   p.ablate = g_stagger | (g_wgrad_xcd ? 0 : 4096);
   const dim3 grid((unsigned)(pl.ngroups * cdiv(cin, WT) * p.ct_tiles), (unsigned)pl.nsplit);
-  const int64_t xb = 4 * n_in * ldx, db = 4 * n_out * ldy, nb = 4 * n_out * K;
+  const int esz = fuse && fuse->b16 ? 2 : 4;
+  const int64_t xb = esz * n_in * ldx, db = esz * n_out * ldy, nb = 4 * n_out * K;
   p.x_bytes = (unsigned)xb, p.dy_bytes = (unsigned)db, p.nbr_bytes = (unsigned)nb;
   p.buf_ok = xb < (1ll << 31) && db < (1ll << 31) && nb < (1ll << 31) && n_in < (1 << 24) && xb <= 0xFFFFFFll * 4 * ldx;
   const bool stream_ok = wgrad_stream_ok(n_in, ldx, cin, ldy, cout, n_out, K);
@@ -2256,7 +2271,9 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
     p.dyp = fuse->dyp, p.in2out = fuse->in2out, p.mean = fuse->mean, p.invstd = fuse->invstd, p.gamma = fuse->gamma;
     p.beta = fuse->beta, p.dgamma = fuse->dgamma, p.dbeta = fuse->dbeta, p.inv_n = 1.f / (float)n_out;
     p.dyp_bytes = (unsigned)(4 * fuse->n_pool * ldy), p.i2o_bytes = (unsigned)(4 * n_out);
-    if (bf16_stream) wgrad_stream_bf16_kernel<true><<<grid, 256, 0, st>>>(p);  // (four row pairs in flight: 2 / 6 / 8 measured, DESIGN appendix)
+    MINK_REQUIRE(!fuse->b16 || bf16_stream, "wgrad_bn_relu_pool_b16: needs bf16 math (mink_conv_set_math(1))");
+    if (fuse->b16) wgrad_stream_bf16_kernel<true, true><<<grid, 256, 0, st>>>(p);
+    else if (bf16_stream) wgrad_stream_bf16_kernel<true><<<grid, 256, 0, st>>>(p);  // (four row pairs in flight: 2 / 6 / 8 measured, DESIGN appendix)
     else if (flat) wgrad_stream_kernel<4, true, true><<<grid, 256, 0, st>>>(p);
     else wgrad_stream_kernel<4, true><<<grid, 256, 0, st>>>(p);
   } else if (bf16_stream) wgrad_stream_bf16_kernel<false><<<grid, 256, 0, st>>>(p);
@@ -2292,8 +2309,20 @@ int mink_conv_wgrad_bn_relu_pool(const float *x, int64_t n_in, int32_t ldx, int3
                                  void *workspace, int64_t workspace_bytes, void *stream) {
   MINK_REQUIRE(y && dy_pool && in2out && mean && invstd && gamma && beta && dgamma && dbeta && n_pool >= 1,
                "wgrad_bn_relu_pool: NULL pointer");
-  const WgradFuse f = {dy_pool, in2out, n_pool, mean, invstd, gamma, beta, dgamma, dbeta};
+  const WgradFuse f = {dy_pool, in2out, n_pool, mean, invstd, gamma, beta, dgamma, dbeta, 0};
   return wgrad_impl(x, n_in, ldx, cin, y, cout, cout, nbr, n_out, K, dw, workspace, workspace_bytes, &f, stream);
+}
+
+int mink_conv_wgrad_bn_relu_pool_b16(const void *xb, int64_t n_in, int32_t cin, const void *yb, int32_t cout, const float *dy_pool,
+                                     int64_t n_pool, const int32_t *in2out, const float *mean, const float *invstd,
+                                     const float *gamma, const float *beta, const float *dgamma, const float *dbeta,
+                                     const int32_t *nbr, int64_t n_out, int32_t K, float *dw, void *workspace,
+                                     int64_t workspace_bytes, void *stream) {
+  MINK_REQUIRE(xb && yb && dy_pool && in2out && mean && invstd && gamma && beta && dgamma && dbeta && n_pool >= 1 && cin >= 1 && cin <= 32,
+               "wgrad_bn_relu_pool_b16: bad arguments");
+  const WgradFuse f = {dy_pool, in2out, n_pool, mean, invstd, gamma, beta, dgamma, dbeta, 1};
+  return wgrad_impl((const float *)xb, n_in, 32, cin, (const float *)yb, cout, cout, nbr, n_out, K, dw, workspace, workspace_bytes, &f,
+                    stream);
 }
 
 }  // extern "C"

@@ -12,13 +12,21 @@ constexpr int kRedBlocks = 2048;  // workgroups of the column reductions (8 per 
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// four consecutive elements of a row-major matrix stored as fp32 or (B16) as bf16; `i` counts ELEMENTS
+template <bool B16>
+__device__ __forceinline__ float4 ldx4(const float *p, int64_t i) {
+  if constexpr (!B16) return *reinterpret_cast<const float4 *>(p + i);
+  const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(p) + i);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
 
 // ---------------------------------------------------------------------- column sums
 // Generic two-quantity column reduction over rows: each thread owns 4 channels (one float4
 // column) and strides over rows; partial[blk][2][C] in double.
 // MODE 0: (sum x, sum x^2)      MODE 1: (sum g, sum g*xhat) with g = dy * (relu ? y>0 : 1)
 // MODE 2: as MODE 1 for the fused bn+relu+sum-pool: g = dy_pool[in2out[row]] * (gamma*xhat+beta > 0)
-template <int MODE>
+template <int MODE, bool B16 = false>  // B16 (MODE 2 only): `b`, the convolution output, is stored as bf16
 __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                        const float *__restrict__ yrelu, int64_t n, int C,
                                                        const float *__restrict__ mean,
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int64_t r = rows[u] < n ? rows[u] : row;
-          xs[u] = ld4(b + r * LD + 4 * c4);
+          xs[u] = ldx4<B16>(b, r * LD + 4 * c4);
           gs[u] = ld4(a + (int64_t)par[u] * LD + 4 * c4);
         }
 #pragma unroll
@@ -325,6 +333,7 @@ __global__ __launch_bounds__(EB) void activation_kernel(const float *__restrict_
 // ------------------------------------------------ fused bn + relu + sum-pool (stem tail)
 // y[o] = sum_{i child of o} relu((x[i]-mean)*invstd*gamma+beta): the normalised [N,C] tensor of
 // the finest level (the largest activation of the network) is never written to HBM.
+template <bool B16>  // B16: x is stored as bf16
 __global__ __launch_bounds__(EB) void bn_relu_pool_fwd_kernel(const float *__restrict__ x, int C4,
                                                               const float *__restrict__ mean,
                                                               const float *__restrict__ invstd,
@@ -351,14 +360,14 @@ __global__ __launch_bounds__(EB) void bn_relu_pool_fwd_kernel(const float *__res
     for (int k = 0; k < 8; ++k) ch[k] = nbr[o * 8 + k];
     float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = ld4(x + (int64_t)max(ch[k], 0) * (4 * C4) + c);  // (a missing child re-reads row 0)
+    for (int k = 0; k < 8; ++k) v[k] = ldx4<B16>(x, (int64_t)max(ch[k], 0) * (4 * C4) + c);  // (a missing child re-reads row 0)
 #pragma unroll
     for (int k = 0; k < 8; ++k)  // same order of additions as the loop below
       if (ch[k] >= 0) add(v[k]);
   } else {
     for (int k = 0; k < K; ++k) {
       const int i = nbr[o * K + k];
-      if (i >= 0) add(ld4(x + (int64_t)i * (4 * C4) + c));
+      if (i >= 0) add(ldx4<B16>(x, (int64_t)i * (4 * C4) + c));
     }
   }
   (void)sh;
@@ -700,24 +709,36 @@ int mink_bn_bwd_from_sums(const float *dy, const float *x, const float *y, int64
   return MINK_OK;
 }
 
-int mink_bn_relu_pool_fwd(const float *x, int32_t C, const float *mean, const float *invstd, const float *gamma,
-                          const float *beta, const int32_t *nbr, int64_t n_out, int32_t K, float *y, void *stream) {
+static int bn_relu_pool_fwd_impl(const float *x, bool b16, int32_t C, const float *mean, const float *invstd, const float *gamma,
+                                 const float *beta, const int32_t *nbr, int64_t n_out, int32_t K, float *y, void *stream) {
   REQ_C4(C, "bn_relu_pool_fwd");
   MINK_REQUIRE(n_out >= 0 && K >= 1, "bn_relu_pool_fwd: bad shape");
   if (n_out == 0) return MINK_OK;
   MINK_REQUIRE(x && mean && invstd && gamma && beta && nbr && y, "bn_relu_pool_fwd: NULL pointer");
   REQ_A16(x, "bn_relu_pool_fwd");
   REQ_A16(y, "bn_relu_pool_fwd");
-  bn_relu_pool_fwd_kernel<<<dim3((unsigned)cdiv(n_out * (C >> 2), EB)), EB, 0, (hipStream_t)stream>>>(
-      x, C >> 2, mean, invstd, gamma, beta, nbr, n_out, K, y);
+  const dim3 grid((unsigned)cdiv(n_out * (C >> 2), EB));
+  if (b16) bn_relu_pool_fwd_kernel<true><<<grid, EB, 0, (hipStream_t)stream>>>(x, C >> 2, mean, invstd, gamma, beta, nbr, n_out, K, y);
+  else bn_relu_pool_fwd_kernel<false><<<grid, EB, 0, (hipStream_t)stream>>>(x, C >> 2, mean, invstd, gamma, beta, nbr, n_out, K, y);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }
 
-int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32_t C, const float *mean,
-                          const float *invstd, const float *gamma, const float *beta, const int32_t *in2out, float *dx,
-                          float *dgamma, float *dbeta, void *workspace, int64_t workspace_bytes, void *stream) {
+int mink_bn_relu_pool_fwd(const float *x, int32_t C, const float *mean, const float *invstd, const float *gamma,
+                          const float *beta, const int32_t *nbr, int64_t n_out, int32_t K, float *y, void *stream) {
+  return bn_relu_pool_fwd_impl(x, false, C, mean, invstd, gamma, beta, nbr, n_out, K, y, stream);
+}
+
+int mink_bn_relu_pool_fwd_b16(const void *xb, int32_t C, const float *mean, const float *invstd, const float *gamma,
+                              const float *beta, const int32_t *nbr, int64_t n_out, int32_t K, float *y, void *stream) {
+  return bn_relu_pool_fwd_impl((const float *)xb, true, C, mean, invstd, gamma, beta, nbr, n_out, K, y, stream);
+}
+
+static int bn_relu_pool_bwd_impl(const float *dy_pool, const float *x, bool b16, int64_t n, int32_t C, const float *mean,
+                                 const float *invstd, const float *gamma, const float *beta, const int32_t *in2out, float *dx,
+                                 float *dgamma, float *dbeta, void *workspace, int64_t workspace_bytes, void *stream) {
   REQ_C4(C, "bn_relu_pool_bwd");
+  MINK_REQUIRE(!b16 || !dx, "bn_relu_pool_bwd_b16: parameter gradients only (dx must be NULL)");
   MINK_REQUIRE(workspace_bytes >= mink_bn_workspace_bytes(n, C), "bn_relu_pool_bwd: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
                (long long)(mink_bn_workspace_bytes(n, C)));
   MINK_REQUIRE(n >= 1 && dy_pool && x && mean && invstd && gamma && beta && in2out && dgamma && dbeta && workspace,
@@ -732,8 +753,12 @@ int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32
   int64_t nblk = cdiv(n, (int64_t)rlanes * 8);
   if (nblk > kRedBlocks) nblk = kRedBlocks;
   const size_t shm = (size_t)rlanes * 2 * C * sizeof(double);
-  colreduce_kernel<2><<<dim3((unsigned)nblk), EB, shm, st>>>(dy_pool, x, nullptr, n, C, mean, invstd, (double *)workspace,
-                                                            in2out, gamma, beta);
+  if (b16)
+    colreduce_kernel<2, true><<<dim3((unsigned)nblk), EB, shm, st>>>(dy_pool, x, nullptr, n, C, mean, invstd, (double *)workspace,
+                                                                      in2out, gamma, beta);
+  else
+    colreduce_kernel<2><<<dim3((unsigned)nblk), EB, shm, st>>>(dy_pool, x, nullptr, n, C, mean, invstd, (double *)workspace,
+                                                              in2out, gamma, beta);
   MINK_CHECK_LAUNCH();
   launch_bwd_finalize((const double *)workspace, (int)nblk, C, gamma, dgamma, dbeta, st);
   MINK_CHECK_LAUNCH();
@@ -743,6 +768,20 @@ int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32
                                                            gamma, beta, dgamma, dbeta, dx);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
+}
+
+int mink_bn_relu_pool_bwd(const float *dy_pool, const float *x, int64_t n, int32_t C, const float *mean,
+                          const float *invstd, const float *gamma, const float *beta, const int32_t *in2out, float *dx,
+                          float *dgamma, float *dbeta, void *workspace, int64_t workspace_bytes, void *stream) {
+  return bn_relu_pool_bwd_impl(dy_pool, x, false, n, C, mean, invstd, gamma, beta, in2out, dx, dgamma, dbeta, workspace, workspace_bytes,
+                               stream);
+}
+
+int mink_bn_relu_pool_bwd_b16(const float *dy_pool, const void *xb, int64_t n, int32_t C, const float *mean, const float *invstd,
+                              const float *gamma, const float *beta, const int32_t *in2out, float *dgamma, float *dbeta,
+                              void *workspace, int64_t workspace_bytes, void *stream) {
+  return bn_relu_pool_bwd_impl(dy_pool, (const float *)xb, true, n, C, mean, invstd, gamma, beta, in2out, nullptr, dgamma, dbeta, workspace,
+                               workspace_bytes, stream);
 }
 
 int mink_eltwise(const float *a, const float *b, int64_t count, int32_t mode, float *y, void *stream) {

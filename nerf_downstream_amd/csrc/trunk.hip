@@ -180,6 +180,20 @@ int mink_stem_forward(const MinkStem *s, const MinkExec *ex) {
   TRY(check_norm(s->norm, "stem_forward", false));
   MINK_REQUIRE(s->x && s->y && s->out && s->nbr_pool && s->n >= 1 && s->n_pool >= 1, "stem_forward: bad arguments");
   hipStream_t st = (hipStream_t)ex->compute;
+  if (s->xb) {  // bf16 storage of the full-resolution stage: x copy and conv output in bf16, statistics of the stored values
+    const MinkConvLayer &c = s->conv;
+    MINK_REQUIRE(mink_stem_conv_bf16s_supported(s->n, s->n, c.K, c.cin, c.cout), "stem_forward: bf16 storage does not support this stem");
+    Scratch ws(ex->ws_compute, ex->ws_bytes);
+    const int rows = mink_stem_conv_bf16s_stats_rows();
+    double *partial = (double *)ws.take((int64_t)rows * 2 * c.cout * sizeof(double));
+    MINK_REQUIRE(partial, "stem_forward: scratch too small");
+    TRY(mink_rows_to_bf16(s->x, s->n, c.cin, c.cin, s->xb, st));
+    TRY(mink_stem_conv_bf16s(s->xb, s->n, c.w, c.cin, c.nbr, s->n, c.K, s->y, c.cout, partial, rows, st));
+    TRY(mink_bn_stats_from_partials(partial, rows, s->n, c.cout, s->norm.eps, s->norm.running_mean ? s->norm.momentum : 0.f, s->norm.mean,
+                                    s->norm.invstd, s->norm.running_mean, s->norm.running_var, st));
+    return mink_bn_relu_pool_fwd_b16(s->y, c.cout, s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta, s->nbr_pool, s->n_pool, 8,
+                                     s->out, st);
+  }
   TRY(conv_stats(s->conv, s->norm, s->x, s->n, s->n, s->y, ex->ws_compute, ex->ws_bytes, st));
   return mink_bn_relu_pool_fwd(s->y, s->conv.cout, s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta, s->nbr_pool,
                                s->n_pool, 8, s->out, st);
@@ -196,6 +210,13 @@ int mink_stem_backward(const MinkStem *s, const MinkExec *ex) {
   const int64_t need = mink_conv_wgrad_workspace_bytes(s->n, s->conv.K, s->conv.cin, s->conv.cout);
   void *slabs = need > 0 ? ws.take(need) : nullptr;
   MINK_REQUIRE(bn_ws && (need == 0 || slabs), "stem_backward: scratch too small");
+  if (s->xb) {
+    TRY(mink_bn_relu_pool_bwd_b16(s->g_out, s->y, s->n, s->conv.cout, s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta, s->in2out,
+                                  s->norm.dgamma, s->norm.dbeta, bn_ws, mink_bn_workspace_bytes(s->n, s->conv.cout), st));
+    return mink_conv_wgrad_bn_relu_pool_b16(s->xb, s->n, s->conv.cin, s->y, s->conv.cout, s->g_out, s->n_pool, s->in2out, s->norm.mean,
+                                            s->norm.invstd, s->norm.gamma, s->norm.beta, s->norm.dgamma, s->norm.dbeta, s->conv.nbr,
+                                            s->n, s->conv.K, s->conv.dw, slabs, need, st);
+  }
   TRY(mink_bn_relu_pool_bwd(s->g_out, s->y, s->n, s->conv.cout, s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta,
                             s->in2out, nullptr, s->norm.dgamma, s->norm.dbeta, bn_ws, mink_bn_workspace_bytes(s->n, s->conv.cout), st));
   // the gradient w.r.t. the convolution output is recomputed inside the weight-gradient kernel's operand load

@@ -25,7 +25,7 @@ from .modules import (  # noqa: F401
     MinkowskiSyncBatchNorm,
     cat,
 )
-from .functional import set_conv_math  # noqa: F401
+from .functional import set_conv_math, set_conv_storage  # noqa: F401
 from .tensor import SparseTensor, TensorField  # noqa: F401
 
 

@@ -64,6 +64,29 @@ def set_conv_math(mode="fp32"):
     return {0: "fp32", 1: "bf16", 3: "bf16x3"}[old]
 
 
+_STORAGE_B16 = False
+
+
+def set_conv_storage(mode="fp32"):
+    """HBM storage of the FULL-RESOLUTION stage of a Mink-ResNet trunk (input features and the stem convolution's
+    output, three quarters of the activation bytes of a step): "fp32" (default) or "bf16".  "bf16" takes effect under
+    `set_conv_math("bf16")` on the native trunk (minkowski/trunk.py); every tensor from the pooled level down, the
+    parameters, their gradients and the batch-norm statistics stay fp32.  Returns the previous mode name."""
+    global _STORAGE_B16
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(f"conv storage {mode!r}: choose 'fp32' or 'bf16'")
+    old, _STORAGE_B16 = _STORAGE_B16, mode == "bf16"
+    return "bf16" if old else "fp32"
+
+
+def conv_math():
+    """The current mode name of set_conv_math (read without changing it)."""
+    L = lib()
+    old = L.mink_conv_set_math(0)
+    L.mink_conv_set_math(old)
+    return {0: "fp32", 1: "bf16", 3: "bf16x3"}[old]
+
+
 # ---------------------------------------------------------------------- kernel timing
 # bench.py measures the dominant kernel live with HIP events recorded on the launch stream.  The events are recorded
 # inside the native library around each convolution call (mink_conv_timing), so the module-by-module path and the

@@ -225,20 +225,24 @@ class TrunkFunction(torch.autograd.Function):
             need = max(need, _ws_need(L, n_in, n_out, st.cin, st.C)[0])
             ts, n_in = ts_out, n_out
         exp = _exec(plan, cur, br, cur, need, dev)
-        arena0 = torch.empty(n0 * C0 + n1 * C0 + 2 * C0, dtype=torch.float32, device=dev)
+        # bf16 storage of the full-resolution stage (Fn.set_conv_storage): y in bf16 and a bf16 copy of x behind it
+        b16 = bool(Fn._STORAGE_B16 and Fn.conv_math() == "bf16" and L.mink_stem_conv_bf16s_supported(n0, n0, w0.shape[0], cin, C0))
+        ny = (n0 * C0 // 2 + 16 * n0 + 3) // 4 * 4 if b16 else n0 * C0  # floats of the y (+ xb) region: 16-byte multiples
+        arena0 = torch.empty(ny + n1 * C0 + 2 * C0, dtype=torch.float32, device=dev)
         a0 = arena0.data_ptr()
         sd = plan.stem
         sd.conv.w, sd.conv.dw, sd.conv.nbr, sd.conv.cin = w0.data_ptr(), None, nbr0.data_ptr(), cin
-        sd.norm.mean, sd.norm.invstd = a0 + 4 * (n0 + n1) * C0, a0 + 4 * ((n0 + n1) * C0 + C0)
+        sd.norm.mean, sd.norm.invstd = a0 + 4 * (ny + n1 * C0), a0 + 4 * (ny + n1 * C0 + C0)
         sd.nbr_pool, sd.in2out, sd.n, sd.n_pool = nbr_pool.data_ptr(), i2o.data_ptr(), n0, n1
-        sd.x, sd.y, sd.out, sd.g_out = x.data_ptr(), a0, a0 + 4 * n0 * C0, None
+        sd.x, sd.y, sd.out, sd.g_out = x.data_ptr(), a0, a0 + 4 * ny, None
+        sd.xb = a0 + 2 * n0 * C0 if b16 else None
         Fn.log_phase("stem_forward_begin", cur)
         check(L.mink_stem_forward(ctypes.byref(sd), exp))
         Fn.log_phase("stem_forward", cur)
         Fn.note_table(nbr0)
-        saved = [(x, w0, arena0, nbr0, nbr_pool, i2o, pad)]
+        saved = [(x, w0, arena0, nbr0, nbr_pool, i2o, pad, b16)]
         # ---- residual blocks
-        hp = a0 + 4 * n0 * C0
+        hp = a0 + 4 * ny
         skew = Fn._SKEW and br != cur
         arena = None
         for st, (ts_in, ts_out, n_in, n_out) in zip(plan.stages, shapes):
@@ -279,7 +283,7 @@ class TrunkFunction(torch.autograd.Function):
         dev = g_out.device
         g_out = Fn._f32c(g_out)
         sink = Fn._GRAD_SINK
-        x, w0p, arena0, nbr0, nbr_pool, i2o, pad = saved[0]
+        x, w0p, arena0, nbr0, nbr_pool, i2o, pad, b16 = saved[0]
         views = Fn._sink_views(*params) if (sink is not None and pad == 0) else None
         # the weight gradients may run on the side stream (joined once, at the end of backward) when nothing consumes a
         # gradient earlier: the gradient buffer's owner (the sink) has them written in place, or autograd merely
@@ -400,11 +404,13 @@ class TrunkFunction(torch.autograd.Function):
 
     @staticmethod
     def _restore_stem(plan, sv):
-        x, w0, arena0, nbr0, nbr_pool, i2o, pad = sv
+        x, w0, arena0, nbr0, nbr_pool, i2o, pad, b16 = sv
         sd = plan.stem
         n0, n1, C0 = x.shape[0], nbr_pool.shape[0], w0.shape[-1]
         a0 = arena0.data_ptr()
+        ny = arena0.numel() - n1 * C0 - 2 * C0
         sd.conv.w, sd.conv.nbr, sd.conv.cin = w0.data_ptr(), nbr0.data_ptr(), x.shape[1]
-        sd.norm.mean, sd.norm.invstd = a0 + 4 * (n0 + n1) * C0, a0 + 4 * ((n0 + n1) * C0 + C0)
+        sd.norm.mean, sd.norm.invstd = a0 + 4 * (ny + n1 * C0), a0 + 4 * (ny + n1 * C0 + C0)
         sd.nbr_pool, sd.in2out, sd.n, sd.n_pool = nbr_pool.data_ptr(), i2o.data_ptr(), n0, n1
-        sd.x, sd.y, sd.out = x.data_ptr(), a0, a0 + 4 * n0 * C0
+        sd.xb = a0 + 2 * n0 * C0 if b16 else None
+        sd.x, sd.y, sd.out = x.data_ptr(), a0, a0 + 4 * ny

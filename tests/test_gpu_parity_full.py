@@ -13,7 +13,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import batch_scenes
+from helpers import batch_scenes, trunk_node
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -202,7 +202,8 @@ def _check_every_map(oracle_maps, field, coords, plan_ops):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("name,batch,math", [("ResNet14", 16, "fp32"), ("ResNet34", 4, "fp32"), ("ResNet14", 16, "bf16")])
+@pytest.mark.parametrize("name,batch,math", [("ResNet14", 16, "fp32"), ("ResNet34", 4, "fp32"), ("ResNet14", 16, "bf16"),
+                                             ("ResNet14", 16, "bf16s")])
 def test_baseline_batch_backward_and_every_map_match_oracle(oracle_maps, name, batch, math):
     """BASELINE config #2's own batch (B=16 x 128^3, ~825 k voxels) and config #3's per-GPU shape (ResNet34, B=4) through
     forward AND backward at the launch shapes bench.py runs -- the planners pick kernels, split factors and launch orders
@@ -210,7 +211,8 @@ def test_baseline_batch_backward_and_every_map_match_oracle(oracle_maps, name, b
     parameter gradient against a float64 run of the oracle with the criterion of tests/test_gpu_resnet.py (relative L2
     <= max(1e-3, 8x the oracle's own fp32 error, 3/sqrt(rows x channels) for a ReLU flip)), every map of the plan bit for
     bit.  bf16 (BASELINE config #4 at full size): logits 2.5e-2, gradient cosine 0.97 (bounds derived in
-    test_whole_model_reduced_precision_matrix_math)."""
+    test_whole_model_reduced_precision_matrix_math); bf16s: the same with the input features and the stem output STORED as
+    bf16 (set_conv_storage, csrc/stem16.hip), same bounds -- one more tensor rounded to 8 bits."""
     from nerf_downstream_amd.co3d_3d.src.models import get_model
     from nerf_downstream_amd.minkowski import functional as Fn
     from oracle import me_cpu as OME
@@ -221,12 +223,14 @@ def test_baseline_batch_backward_and_every_map_match_oracle(oracle_maps, name, b
     b = _baseline_batch(batch=batch)
     coords, feats, labels = b["coordinates"], b["features"], b["labels"].long()
     hip, ref = _pair(name, 28, 51, seed=777)
-    old = Fn.set_conv_math(math)
+    old, old_st = Fn.set_conv_math("bf16" if math == "bf16s" else math), Fn.set_conv_storage("bf16" if math == "bf16s" else "fp32")
     try:
         out, field, reducer = _bench_like_step(hip, {"coordinates": coords.cuda(), "features": feats.cuda()}, labels.cuda())
     finally:
-        Fn.set_conv_math(old)
+        Fn.set_conv_math(old), Fn.set_conv_storage(old_st)
     assert hip._trunk_plan, "the native trunk (bench.py's path) was not taken"
+    if math == "bf16s":
+        assert trunk_node(out).saved[0][-1] is True, "bf16 storage was not taken"
     assert field.coordinate_manager.prepared, "the second pass must run on maps prepared ahead"
     oout = ref(ref.process_input({"coordinates": coords, "features": feats}))
     err = float((out.detach().cpu() - oout.detach()).abs().max())
