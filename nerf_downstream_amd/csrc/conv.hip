@@ -1628,6 +1628,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
 // slot; the x gathers run one three-offset sub-batch ahead of the MFMAs; FUSE recomputes dY from the conv output and
 // the pooled gradient as the fp32 kernel does (parents one block ahead).
 using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x8v pack_bits_bf16x8(const float (&v)[8]) {  // registers that already hold bf16 bits in their low halves
   auto lo = [&](int i) { return __float_as_uint(v[i]); };
@@ -1797,6 +1798,177 @@ epilogue:
         const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = acc[g][r] + sR[(wn * 16 + r) * 64 + lane];
         if (ci < p.cin && co < p.cout) dst[((int64_t)k * p.cin + ci) * p.cout + co] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------- streaming wgrad over bf16 STORAGE, operands transposed through LDS
+// With x ([n][32] bf16, 64-byte rows) and the convolution output in bf16 (stem16.hip) the kernel above still issues eight
+// 2-byte gathers per MFMA operand: a lane of the A operand holds ONE channel of EIGHT different rows.  Here the sixteen
+// gathered rows of an operand are fetched the way they lie in memory -- four lanes x 16 bytes per row, ONE load per lane --
+// written to a wave-private 1 KB LDS image [16 rows][32 channels] and read back with ds_read_b64_tr_b16, gfx950's
+// transposing LDS read (a lane receives its channel of four rows), two reads per operand.  The B operand (dY recomputed
+// from the convolution output, the pooled gradient and the batch-norm constants, FUSE of the kernels above) takes the same
+// route: a lane computes eight consecutive columns of one row (constants per column from LDS), packs them and the wave
+// reads the block back transposed -- 3 loads per block instead of 16.  ~16 load instructions per 16-row block instead of
+// ~100.  Ownership, row splits, slabs and epilogue are those of wgrad_stream_bf16_kernel; LDS traffic is wave-private and
+// in issue order (no barrier in the loop).  cout == 64, K == 27, x pitch 32.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr16(const unsigned short *p) {  // ds_read_b64_tr_b16 (EXEC must be all ones)
+  return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p));
+}
+template <int A>
+__device__ __forceinline__ unsigned quad_bcast(unsigned v) {  // lane A of every quad
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, A | (A << 2) | (A << 4) | (A << 6), 0xF, 0xF, false);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_stream_b16t_kernel(WgradParams p) {
+  constexpr int G = 9;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ float sR[2 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned short sA[4][3][16 * 32];  // [wave][ring][row][channel]
+  __shared__ __attribute__((aligned(16))) unsigned short sB[4][16 * 32];     // [wave][row][column of the wave's half]
+  __shared__ __attribute__((aligned(16))) float sC[7][64];                   // per column: invstd, -mean*invstd, gamma, beta, gamma*invstd, dgamma/n, dbeta/n
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wa = wave >> 1, h = lane >> 5, col = lane & 31;
+  const StreamSlot ss = stream_slot(p);
+  const int grp = ss.grp;
+  const int k0 = grp * G;
+  const int64_t rbeg = (int64_t)ss.split * p.rows_per_split;
+  const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
+  const int nrel = (int)(rend - rbeg);
+  const int nblocks = (nrel + 15) >> 4;
+  const int nq = (nblocks + 1 - wa) >> 1;  // this wave's blocks: b = 2 q + wa
+  if (tid < 64) {
+    const float is = p.invstd[tid], mu = p.mean[tid], ga = p.gamma[tid];
+    sC[0][tid] = is, sC[1][tid] = -mu * is, sC[2][tid] = ga, sC[3][tid] = p.beta[tid], sC[4][tid] = ga * is;
+    sC[5][tid] = p.dgamma[tid] * p.inv_n, sC[6][tid] = p.dbeta[tid] * p.inv_n;
+  }
+  __syncthreads();
+  f32x16 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = (f32x16){0};
+  if (nq > 0) {  // (wave-uniform)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), ry = make_rsrc(p.dy, (unsigned)rend * 128u),
+                                 rn = make_rsrc(p.nbr, (unsigned)rend * 4u * 27u), rp = make_rsrc(p.dyp, p.dyp_bytes),
+                                 ri = make_rsrc(p.in2out, (unsigned)rend * 4u);
+    const int g_row = lane >> 2, g_ch = lane & 3;  // gather / compute role: row of the block, 16-byte chunk
+    const unsigned nbase = (unsigned)rbeg * 108u + 4u * (unsigned)(k0 + 3 * g_ch), ibase = (unsigned)rbeg * 4u;
+    const unsigned ybase = (unsigned)rbeg * 128u + 64u * wn + 16u * g_ch, pcol = 128u * wn + 32u * g_ch;
+    unsigned short *sAw = &sA[wave][0][0], *sBw = &sB[wave][0];
+    const int st_off = g_row * 32 + 8 * g_ch;                                        // halfword offset of this lane's 16 bytes
+    const int tr_off = (8 * h + ((lane & 15) >> 2)) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);  // transposed read, rows 8h..8h+3 (+128: rows 8h+4..)
+    unsigned traw[3], par, ent[G];
+    u32x4v ga[G], yraw, dp0, dp1;
+    auto rel_row = [&](int q) { return 16 * (2 * q + wa) + g_row; };
+    auto load_table = [&](int q) __attribute__((always_inline)) {  // entries 3 g_ch .. + 2 of the lane's row (g_ch == 3: idle)
+      const int r = rel_row(q);
+      const bool ok = q < nq && r < nrel && g_ch < 3;
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        traw[e] = ok ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rn, (int)(__umul24(r, 108u) + nbase + 4u * e), 0, 0) : 0xFFFFFFFFu;
+    };
+    auto load_par = [&](int q) __attribute__((always_inline)) {
+      const int r = rel_row(q);
+      par = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ri, (int)(q < nq && r < nrel ? 4u * r + ibase : OOB), 0, 0);  // (past the end: parent 0)
+    };
+    auto spread = [&]() __attribute__((always_inline)) {  // every lane of a row's quad gets the row's nine entries
+      ent[0] = quad_bcast<0>(traw[0]), ent[1] = quad_bcast<0>(traw[1]), ent[2] = quad_bcast<0>(traw[2]);
+      ent[3] = quad_bcast<1>(traw[0]), ent[4] = quad_bcast<1>(traw[1]), ent[5] = quad_bcast<1>(traw[2]);
+      ent[6] = quad_bcast<2>(traw[0]), ent[7] = quad_bcast<2>(traw[1]), ent[8] = quad_bcast<2>(traw[2]);
+    };
+    auto gather = [&](int g) __attribute__((always_inline)) {  // (-1 is row 0xFFFFFF: beyond x, reads as zeros)
+      ga[g] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(__umul24(ent[g], 64u) + 16u * g_ch), 0, 0);
+    };
+    auto load_b = [&](int q) __attribute__((always_inline)) {  // conv output row chunk + pooled gradient of its parent
+      const int r = rel_row(q);
+      yraw = __builtin_amdgcn_raw_buffer_load_b128(ry, (int)(q < nq && r < nrel ? __umul24(r, 128u) + ybase : OOB), 0, 0);
+      const unsigned po = __umul24(par, 256u) + pcol;
+      dp0 = __builtin_amdgcn_raw_buffer_load_b128(rp, (int)po, 0, 0);
+      dp1 = __builtin_amdgcn_raw_buffer_load_b128(rp, (int)(po + 16u), 0, 0);
+    };
+    // ---- prologue
+    load_table(0);
+    load_par(0);
+    spread();
+#pragma unroll
+    for (int g = 0; g < G; ++g) gather(g);
+    load_b(0);
+    load_table(1);
+    load_par(1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int q = 0; q < nq; ++q) {
+      spread();  // entries of block q + 1
+      // ---- B operand of block q
+      {
+        const int cb = 32 * wn + 8 * g_ch;
+        const unsigned yw[4] = {yraw[0], yraw[1], yraw[2], yraw[3]};
+        const float dpv[8] = {__uint_as_float(dp0[0]), __uint_as_float(dp0[1]), __uint_as_float(dp0[2]), __uint_as_float(dp0[3]),
+                              __uint_as_float(dp1[0]), __uint_as_float(dp1[1]), __uint_as_float(dp1[2]), __uint_as_float(dp1[3])};
+        const bool live = rel_row(q) < nrel;
+        float v[8];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {  // four columns at a time: 28 constants live, not 56
+          float4 cs[7];
+#pragma unroll
+          for (int c = 0; c < 7; ++c) cs[c] = *reinterpret_cast<const float4 *>(&sC[c][cb + 4 * hf]);
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const int e = 4 * hf + e4;
+            auto at = [&](int c) { return e4 == 0 ? cs[c].x : e4 == 1 ? cs[c].y : e4 == 2 ? cs[c].z : cs[c].w; };
+            const float y = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xFFFF0000u) : (yw[e >> 1] << 16));
+            const float xh = fmaf(y, at(0), at(1));
+            const float m = fmaf(xh, at(2), at(3)) > 0.f ? 1.f : 0.f;
+            v[e] = (live ? at(4) : 0.f) * fmaf(-at(5), xh, fmaf(dpv[e], m, -at(6)));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        *reinterpret_cast<uint4 *>(sBw + st_off) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+      }
+      const uint2 b_lo = lds_tr16(sBw + tr_off), b_hi = lds_tr16(sBw + tr_off + 128);
+      const bf16x8v bfrag = __builtin_bit_cast(bf16x8v, make_uint4(b_lo.x, b_lo.y, b_hi.x, b_hi.y));
+      load_b(q + 1);  // (its parents arrived one block ago)
+      load_par(q + 2);
+      load_table(q + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- nine offsets: gathered rows of block q -> LDS -> transposed fragment; the registers take block q + 1's rows
+      *reinterpret_cast<u32x4v *>(sAw + st_off) = ga[0];
+      gather(0);
+      uint2 a_lo = lds_tr16(sAw + tr_off), a_hi = lds_tr16(sAw + tr_off + 128);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const bf16x8v afrag = __builtin_bit_cast(bf16x8v, make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y));
+        if (g + 1 < G) {
+          unsigned short *slot = sAw + ((g + 1) % 3) * 512;
+          *reinterpret_cast<u32x4v *>(slot + st_off) = ga[g + 1];
+          gather(g + 1);
+          a_lo = lds_tr16(slot + tr_off), a_hi = lds_tr16(slot + tr_off + 128);
+        }
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // ---- epilogue: add the two wave rows through LDS, store the partial slab
+  float *dst = p.out + (int64_t)ss.split * p.K * p.cin * p.cout;
+  const int co = 32 * wn + col;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int k = k0 + g;
+    __syncthreads();
+    if (wa == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sR[(wn * 16 + r) * 64 + lane] = acc[g][r];
+    }
+    __syncthreads();
+    if (wa == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[g][r] + sR[(wn * 16 + r) * 64 + lane];
+        if (ci < p.cin) dst[((int64_t)k * p.cin + ci) * p.cout + co] = v;
       }
     }
   }
@@ -2272,7 +2444,8 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
     p.beta = fuse->beta, p.dgamma = fuse->dgamma, p.dbeta = fuse->dbeta, p.inv_n = 1.f / (float)n_out;
     p.dyp_bytes = (unsigned)(4 * fuse->n_pool * ldy), p.i2o_bytes = (unsigned)(4 * n_out);
     MINK_REQUIRE(!fuse->b16 || bf16_stream, "wgrad_bn_relu_pool_b16: needs bf16 math (mink_conv_set_math(1))");
-    if (fuse->b16) wgrad_stream_bf16_kernel<true, true><<<grid, 256, 0, st>>>(p);
+    if (fuse->b16 && cout == 64 && ldx == 32 && !(g_stagger & 2048)) wgrad_stream_b16t_kernel<<<grid, 256, 0, st>>>(p);  // (bit 11: the 2-byte-gather kernel, A/B tests)
+    else if (fuse->b16) wgrad_stream_bf16_kernel<true, true><<<grid, 256, 0, st>>>(p);
     else if (bf16_stream) wgrad_stream_bf16_kernel<true><<<grid, 256, 0, st>>>(p);  // (four row pairs in flight: 2 / 6 / 8 measured, DESIGN appendix)
     else if (flat) wgrad_stream_kernel<4, true, true><<<grid, 256, 0, st>>>(p);
     else wgrad_stream_kernel<4, true><<<grid, 256, 0, st>>>(p);

@@ -56,3 +56,30 @@ t_cast = timeit(lambda: check(L.mink_rows_to_bf16(xin.data_ptr(), n, 28, xin.str
 t_new = timeit(run)
 pairs = int((nbr >= 0).sum())
 print(f"stem fwd: fp32 storage / bf16 math {t_ref:7.1f} us | bf16 storage {t_new:7.1f} us (+ cast {t_cast:5.1f} us) | gathers {pairs * 64 / t_new / 1e6:6.2f} TB/s")
+
+# ---- fused stem weight gradient: fp32 storage (bf16 math) / bf16 storage with 2-byte gathers / with LDS-transposed operands
+k2 = ME.CoordinateMapKey(2)
+m.stride(k1, 2)
+nbr_pool, _ = m.kernel_table(k1, k2, 2, 1)
+i2o = m.stride_map(k1, k2)
+npool, C = nbr_pool.shape[0], 64
+yf = yb.float().contiguous()
+xf = xb[:, :28].float().contiguous()
+mean, invstd = yf.mean(0).contiguous(), (yf.var(0, unbiased=False) + 1e-5).rsqrt().contiguous()
+gamma, beta = (torch.rand(C, device=dev) + 0.5), (torch.rand(C, device=dev) - 0.5)
+gp = torch.randn(npool, C, device=dev)
+dg, db = torch.randn(C, device=dev), torch.randn(C, device=dev)
+need = L.mink_conv_wgrad_workspace_bytes(n, 27, 28, C)
+slabs = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+dws = [torch.empty(27, 28, C, device=dev) for _ in range(3)]
+f32 = lambda o: check(L.mink_conv_wgrad_bn_relu_pool(xf.data_ptr(), n, 28, 28, yf.data_ptr(), C, gp.data_ptr(), npool, i2o.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dg.data_ptr(), db.data_ptr(), nbr.data_ptr(), n, 27, o.data_ptr(), slabs.data_ptr(), need, st))
+b16 = lambda o: check(L.mink_conv_wgrad_bn_relu_pool_b16(xb.data_ptr(), n, 28, yb.data_ptr(), C, gp.data_ptr(), npool, i2o.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dg.data_ptr(), db.data_ptr(), nbr.data_ptr(), n, 27, o.data_ptr(), slabs.data_ptr(), need, st))
+t0 = timeit(lambda: f32(dws[0]))
+L.mink_conv_set_stagger(1 << 11)
+t1 = timeit(lambda: b16(dws[1]))
+L.mink_conv_set_stagger(0)
+t2 = timeit(lambda: b16(dws[2]))
+torch.cuda.synchronize()
+print(f"stem wgrad (fused): fp32 storage {t0:7.1f} us | bf16 storage, 2-byte gathers {t1:7.1f} us | LDS-transposed {t2:7.1f} us")
+print("bitwise: b16 old == fp32-storage", bool(torch.equal(dws[0], dws[1])), "| new == old", bool(torch.equal(dws[1], dws[2])),
+      "| rel diff new vs old", float((dws[2] - dws[1]).norm() / dws[1].norm()))
