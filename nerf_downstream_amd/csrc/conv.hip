@@ -2089,6 +2089,7 @@ static int g_flat = 1;
 static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
 static int g_wgrad_bf16 = 1;  // bf16 math: stem weight gradient on the bf16 MFMA too (set_stagger bit 28 switches it off: A/B tests)
 static int g_wgrad_bf16_off = 0;
+static int g_b16t_off = 0;      // set_stagger bit 11: the bf16-storage stem weight gradient without the LDS transposition (A/B tests)
 static int g_compact = 1;  // fp32 mid layers on compact_gemm_kernel (set_stagger bit 30: the dense kernel, for the tests that compare the two)
 static int g_compact_perm = 1;  // ... and the class-permuted strided data gradients (bit 31)
 static int g_wgrad_xcd = 1;  // streaming wgrad: groups of a row split share an XCD (stream_slot; bit 29: plain order)
@@ -2098,6 +2099,7 @@ extern "C" {
 int mink_conv_set_stagger(int units) {
   const int old = g_stagger;
   g_stagger = units & 255;
+  g_b16t_off = (units >> 11) & 1;      // bit 11: bf16-storage stem weight gradient with 2-byte gathers (A/B)
   g_flat = !(units & 512);      // bit 9: no flattened-K stem path
   g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
   g_wgrad_bf16_off = (units >> 28) & 1;  // bit 28: bf16 math keeps the exact-fp32 weight-gradient kernel (A/B tests)
@@ -2444,7 +2446,7 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
     p.beta = fuse->beta, p.dgamma = fuse->dgamma, p.dbeta = fuse->dbeta, p.inv_n = 1.f / (float)n_out;
     p.dyp_bytes = (unsigned)(4 * fuse->n_pool * ldy), p.i2o_bytes = (unsigned)(4 * n_out);
     MINK_REQUIRE(!fuse->b16 || bf16_stream, "wgrad_bn_relu_pool_b16: needs bf16 math (mink_conv_set_math(1))");
-    if (fuse->b16 && cout == 64 && ldx == 32 && !(g_stagger & 2048)) wgrad_stream_b16t_kernel<<<grid, 256, 0, st>>>(p);  // (bit 11: the 2-byte-gather kernel, A/B tests)
+    if (fuse->b16 && cout == 64 && ldx == 32 && !g_b16t_off) wgrad_stream_b16t_kernel<<<grid, 256, 0, st>>>(p);  // (bit 11: the 2-byte-gather kernel, A/B tests)
     else if (fuse->b16) wgrad_stream_bf16_kernel<true, true><<<grid, 256, 0, st>>>(p);
     else if (bf16_stream) wgrad_stream_bf16_kernel<true><<<grid, 256, 0, st>>>(p);  // (four row pairs in flight: 2 / 6 / 8 measured, DESIGN appendix)
     else if (flat) wgrad_stream_kernel<4, true, true><<<grid, 256, 0, st>>>(p);
