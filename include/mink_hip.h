@@ -510,6 +510,8 @@ typedef struct {
   const float *g_out;  /* backward: gradient of `out` */
   void *xb;        /* ABI 3, bf16 storage (needs mink_conv_set_math(1)): [n][32] bf16 copy of x, written by forward and read by
                       backward; `y` is then bf16 [n][cout].  NULL: fp32 storage */
+  int32_t xb_ready; /* nonzero: `xb` already holds mink_rows_to_bf16(x) (made ahead of the step, e.g. beside the previous one):
+                      forward does not write it */
 } MinkStem;
 
 typedef struct {

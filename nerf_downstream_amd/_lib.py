@@ -48,7 +48,7 @@ class Stem(ctypes.Structure):
     """MinkStem"""
 
     _fields_ = [("conv", ConvLayer), ("norm", NormLayer), ("nbr_pool", _p), ("in2out", _p), ("n", _i64), ("n_pool", _i64),
-                ("x", _p), ("y", _p), ("out", _p), ("g_out", _p), ("xb", _p)]
+                ("x", _p), ("y", _p), ("out", _p), ("g_out", _p), ("xb", _p), ("xb_ready", _i32)]
 
 
 class BasicBlock(ctypes.Structure):

@@ -1823,13 +1823,18 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {  // lane A of every
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, A | (A << 2) | (A << 4) | (A << 6), 0xF, 0xF, false);
 }
 
+// SHARE: the two waves of a row block (column halves wn = 0 / 1) need the same nine gathered operands; instead of each
+// gathering all nine (the L2 -> L1 path, not the matrix pipe, bounds this kernel) each gathers every second one into an
+// image the pair shares, double-buffered over blocks with ONE workgroup barrier per block.
+template <bool SHARE>
 __global__ __launch_bounds__(256, 2) void wgrad_stream_b16t_kernel(WgradParams p) {
   constexpr int G = 9;
   constexpr unsigned OOB = 0x80000000u;
+  constexpr int NSL = SHARE ? 2 * 2 * G : 4 * 3;  // 1 KB operand images: [row pair wa][buffer][offset] / [wave][ring]
   __shared__ float sR[2 * 16 * 64];
-  __shared__ __attribute__((aligned(16))) unsigned short sA[4][3][16 * 32];  // [wave][ring][row][channel]
-  __shared__ __attribute__((aligned(16))) unsigned short sB[4][16 * 32];     // [wave][row][column of the wave's half]
-  __shared__ __attribute__((aligned(16))) float sC[7][64];                   // per column: invstd, -mean*invstd, gamma, beta, gamma*invstd, dgamma/n, dbeta/n
+  __shared__ __attribute__((aligned(16))) unsigned short sA[NSL][16 * 32];  // [row][channel]
+  __shared__ __attribute__((aligned(16))) unsigned short sB[4][16 * 32];    // [wave][row][column of the wave's half]
+  __shared__ __attribute__((aligned(16))) float sC[7][64];                  // per column: invstd, -mean*invstd, gamma, beta, gamma*invstd, dgamma/n, dbeta/n
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wa = wave >> 1, h = lane >> 5, col = lane & 31;
@@ -1840,7 +1845,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_b16t_kernel(WgradParams p
   const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
   const int nrel = (int)(rend - rbeg);
   const int nblocks = (nrel + 15) >> 4;
-  const int nq = (nblocks + 1 - wa) >> 1;  // this wave's blocks: b = 2 q + wa
+  // this wave's blocks: b = 2 q + wa.  SHARE: every wave runs the trip count of wa = 0 (a barrier per trip); a block past
+  // the end has no live row
+  const int nq = SHARE ? (nblocks + 1) >> 1 : (nblocks + 1 - wa) >> 1;
   if (tid < 64) {
     const float is = p.invstd[tid], mu = p.mean[tid], ga = p.gamma[tid];
     sC[0][tid] = is, sC[1][tid] = -mu * is, sC[2][tid] = ga, sC[3][tid] = p.beta[tid], sC[4][tid] = ga * is;
@@ -1850,18 +1857,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_b16t_kernel(WgradParams p
   f32x16 acc[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = (f32x16){0};
-  if (nq > 0) {  // (wave-uniform)
+  if (nq > 0) {  // (uniform: per wave, with SHARE per workgroup)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), ry = make_rsrc(p.dy, (unsigned)rend * 128u),
                                  rn = make_rsrc(p.nbr, (unsigned)rend * 4u * 27u), rp = make_rsrc(p.dyp, p.dyp_bytes),
                                  ri = make_rsrc(p.in2out, (unsigned)rend * 4u);
     const int g_row = lane >> 2, g_ch = lane & 3;  // gather / compute role: row of the block, 16-byte chunk
     const unsigned nbase = (unsigned)rbeg * 108u + 4u * (unsigned)(k0 + 3 * g_ch), ibase = (unsigned)rbeg * 4u;
     const unsigned ybase = (unsigned)rbeg * 128u + 64u * wn + 16u * g_ch, pcol = 128u * wn + 32u * g_ch;
-    unsigned short *sAw = &sA[wave][0][0], *sBw = &sB[wave][0];
+    unsigned short *sBw = &sB[wave][0];
     const int st_off = g_row * 32 + 8 * g_ch;                                        // halfword offset of this lane's 16 bytes
     const int tr_off = (8 * h + ((lane & 15) >> 2)) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);  // transposed read, rows 8h..8h+3 (+128: rows 8h+4..)
     unsigned traw[3], par, ent[G];
     u32x4v ga[G], yraw, dp0, dp1;
+    auto mine = [&](int g) { return !SHARE || (g & 1) == wn; };  // operands this wave gathers
     auto rel_row = [&](int q) { return 16 * (2 * q + wa) + g_row; };
     auto load_table = [&](int q) __attribute__((always_inline)) {  // entries 3 g_ch .. + 2 of the lane's row (g_ch == 3: idle)
       const int r = rel_row(q);
@@ -1889,65 +1897,91 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_b16t_kernel(WgradParams p
       dp0 = __builtin_amdgcn_raw_buffer_load_b128(rp, (int)po, 0, 0);
       dp1 = __builtin_amdgcn_raw_buffer_load_b128(rp, (int)(po + 16u), 0, 0);
     };
+    auto b_operand = [&](int q) __attribute__((always_inline)) {  // dY of block q: computed row-major, read back transposed
+      const int cb = 32 * wn + 8 * g_ch;
+      const unsigned yw[4] = {yraw[0], yraw[1], yraw[2], yraw[3]};
+      const float dpv[8] = {__uint_as_float(dp0[0]), __uint_as_float(dp0[1]), __uint_as_float(dp0[2]), __uint_as_float(dp0[3]),
+                            __uint_as_float(dp1[0]), __uint_as_float(dp1[1]), __uint_as_float(dp1[2]), __uint_as_float(dp1[3])};
+      const bool live = rel_row(q) < nrel;
+      float v[8];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {  // four columns at a time: 28 constants live, not 56
+        float4 cs[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) cs[c] = *reinterpret_cast<const float4 *>(&sC[c][cb + 4 * hf]);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int e = 4 * hf + e4;
+          auto at = [&](int c) { return e4 == 0 ? cs[c].x : e4 == 1 ? cs[c].y : e4 == 2 ? cs[c].z : cs[c].w; };
+          const float y = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xFFFF0000u) : (yw[e >> 1] << 16));
+          const float xh = fmaf(y, at(0), at(1));
+          const float m = fmaf(xh, at(2), at(3)) > 0.f ? 1.f : 0.f;
+          v[e] = (live ? at(4) : 0.f) * fmaf(-at(5), xh, fmaf(dpv[e], m, -at(6)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      *reinterpret_cast<uint4 *>(sBw + st_off) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+      const uint2 b_lo = lds_tr16(sBw + tr_off), b_hi = lds_tr16(sBw + tr_off + 128);
+      return __builtin_bit_cast(bf16x8v, make_uint4(b_lo.x, b_lo.y, b_hi.x, b_hi.y));
+    };
     // ---- prologue
     load_table(0);
     load_par(0);
     spread();
 #pragma unroll
-    for (int g = 0; g < G; ++g) gather(g);
+    for (int g = 0; g < G; ++g)
+      if (mine(g)) gather(g);
     load_b(0);
     load_table(1);
     load_par(1);
     __builtin_amdgcn_sched_barrier(0);
     for (int q = 0; q < nq; ++q) {
       spread();  // entries of block q + 1
-      // ---- B operand of block q
-      {
-        const int cb = 32 * wn + 8 * g_ch;
-        const unsigned yw[4] = {yraw[0], yraw[1], yraw[2], yraw[3]};
-        const float dpv[8] = {__uint_as_float(dp0[0]), __uint_as_float(dp0[1]), __uint_as_float(dp0[2]), __uint_as_float(dp0[3]),
-                              __uint_as_float(dp1[0]), __uint_as_float(dp1[1]), __uint_as_float(dp1[2]), __uint_as_float(dp1[3])};
-        const bool live = rel_row(q) < nrel;
-        float v[8];
+      if constexpr (SHARE) {
+        // this wave's operands of block q -> the pair's image (buffer q & 1); the registers take block q + 1's rows
+        unsigned short *img = &sA[(wa * 2 + (q & 1)) * G][0];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {  // four columns at a time: 28 constants live, not 56
-          float4 cs[7];
-#pragma unroll
-          for (int c = 0; c < 7; ++c) cs[c] = *reinterpret_cast<const float4 *>(&sC[c][cb + 4 * hf]);
-#pragma unroll
-          for (int e4 = 0; e4 < 4; ++e4) {
-            const int e = 4 * hf + e4;
-            auto at = [&](int c) { return e4 == 0 ? cs[c].x : e4 == 1 ? cs[c].y : e4 == 2 ? cs[c].z : cs[c].w; };
-            const float y = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xFFFF0000u) : (yw[e >> 1] << 16));
-            const float xh = fmaf(y, at(0), at(1));
-            const float m = fmaf(xh, at(2), at(3)) > 0.f ? 1.f : 0.f;
-            v[e] = (live ? at(4) : 0.f) * fmaf(-at(5), xh, fmaf(dpv[e], m, -at(6)));
+        for (int g = 0; g < G; ++g)
+          if (mine(g)) {
+            *reinterpret_cast<u32x4v *>(img + g * 512 + st_off) = ga[g];
+            gather(g);
           }
+        const bf16x8v bfrag = b_operand(q);
+        load_b(q + 1);  // (its parents arrived one block ago)
+        load_par(q + 2);
+        load_table(q + 2);
+        __syncthreads();  // both waves' operands are in the image (the other buffer is rewritten only after the next barrier)
+        uint2 a_lo = lds_tr16(img + tr_off), a_hi = lds_tr16(img + tr_off + 128);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const bf16x8v afrag = __builtin_bit_cast(bf16x8v, make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y));
+          if (g + 1 < G) a_lo = lds_tr16(img + (g + 1) * 512 + tr_off), a_hi = lds_tr16(img + (g + 1) * 512 + tr_off + 128);
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[g], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        *reinterpret_cast<uint4 *>(sBw + st_off) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-      }
-      const uint2 b_lo = lds_tr16(sBw + tr_off), b_hi = lds_tr16(sBw + tr_off + 128);
-      const bf16x8v bfrag = __builtin_bit_cast(bf16x8v, make_uint4(b_lo.x, b_lo.y, b_hi.x, b_hi.y));
-      load_b(q + 1);  // (its parents arrived one block ago)
-      load_par(q + 2);
-      load_table(q + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- nine offsets: gathered rows of block q -> LDS -> transposed fragment; the registers take block q + 1's rows
-      *reinterpret_cast<u32x4v *>(sAw + st_off) = ga[0];
-      gather(0);
-      uint2 a_lo = lds_tr16(sAw + tr_off), a_hi = lds_tr16(sAw + tr_off + 128);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const bf16x8v afrag = __builtin_bit_cast(bf16x8v, make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y));
-        if (g + 1 < G) {
-          unsigned short *slot = sAw + ((g + 1) % 3) * 512;
-          *reinterpret_cast<u32x4v *>(slot + st_off) = ga[g + 1];
-          gather(g + 1);
-          a_lo = lds_tr16(slot + tr_off), a_hi = lds_tr16(slot + tr_off + 128);
-        }
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[g], 0, 0, 0);
+      } else {
+        unsigned short *sAw = &sA[wave * 3][0];
+        const bf16x8v bfrag = b_operand(q);
+        load_b(q + 1);  // (its parents arrived one block ago)
+        load_par(q + 2);
+        load_table(q + 2);
         __builtin_amdgcn_sched_barrier(0);
+        // ---- nine offsets: gathered rows of block q -> LDS -> transposed fragment; the registers take block q + 1's rows
+        *reinterpret_cast<u32x4v *>(sAw + st_off) = ga[0];
+        gather(0);
+        uint2 a_lo = lds_tr16(sAw + tr_off), a_hi = lds_tr16(sAw + tr_off + 128);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const bf16x8v afrag = __builtin_bit_cast(bf16x8v, make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y));
+          if (g + 1 < G) {
+            unsigned short *slot = sAw + ((g + 1) % 3) * 512;
+            *reinterpret_cast<u32x4v *>(slot + st_off) = ga[g + 1];
+            gather(g + 1);
+            a_lo = lds_tr16(slot + tr_off), a_hi = lds_tr16(slot + tr_off + 128);
+          }
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[g], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
@@ -2446,7 +2480,8 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
     p.beta = fuse->beta, p.dgamma = fuse->dgamma, p.dbeta = fuse->dbeta, p.inv_n = 1.f / (float)n_out;
     p.dyp_bytes = (unsigned)(4 * fuse->n_pool * ldy), p.i2o_bytes = (unsigned)(4 * n_out);
     MINK_REQUIRE(!fuse->b16 || bf16_stream, "wgrad_bn_relu_pool_b16: needs bf16 math (mink_conv_set_math(1))");
-    if (fuse->b16 && cout == 64 && ldx == 32 && !g_b16t_off) wgrad_stream_b16t_kernel<<<grid, 256, 0, st>>>(p);  // (bit 11: the 2-byte-gather kernel, A/B tests)
+    if (fuse->b16 && cout == 64 && ldx == 32 && !g_b16t_off && !(g_stagger & 32)) wgrad_stream_b16t_kernel<true><<<grid, 256, 0, st>>>(p);
+    else if (fuse->b16 && cout == 64 && ldx == 32 && !g_b16t_off) wgrad_stream_b16t_kernel<false><<<grid, 256, 0, st>>>(p);  // (bit 11: the 2-byte-gather kernel, A/B tests)
     else if (fuse->b16) wgrad_stream_bf16_kernel<true, true><<<grid, 256, 0, st>>>(p);
     else if (bf16_stream) wgrad_stream_bf16_kernel<true><<<grid, 256, 0, st>>>(p);  // (four row pairs in flight: 2 / 6 / 8 measured, DESIGN appendix)
     else if (flat) wgrad_stream_kernel<4, true, true><<<grid, 256, 0, st>>>(p);

@@ -187,7 +187,7 @@ int mink_stem_forward(const MinkStem *s, const MinkExec *ex) {
     const int rows = mink_stem_conv_bf16s_stats_rows();
     double *partial = (double *)ws.take((int64_t)rows * 2 * c.cout * sizeof(double));
     MINK_REQUIRE(partial, "stem_forward: scratch too small");
-    TRY(mink_rows_to_bf16(s->x, s->n, c.cin, c.cin, s->xb, st));
+    if (!s->xb_ready) TRY(mink_rows_to_bf16(s->x, s->n, c.cin, c.cin, s->xb, st));
     TRY(mink_stem_conv_bf16s(s->xb, s->n, c.w, c.cin, c.nbr, s->n, c.K, s->y, c.cout, partial, rows, st));
     TRY(mink_bn_stats_from_partials(partial, rows, s->n, c.cout, s->norm.eps, s->norm.running_mean ? s->norm.momentum : 0.f, s->norm.mean,
                                     s->norm.invstd, s->norm.running_mean, s->norm.running_var, st));

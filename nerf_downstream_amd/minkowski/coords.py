@@ -131,6 +131,7 @@ class CoordinateManager:
         self.trace = []  # every map request, in order: lets the next batch be prepared ahead of use
         self._pending_field = None  # pyramid launched, row counts not read back yet (insert_field(defer=True))
         self.prepared = False
+        self.xb = None  # (source pointer, bf16 copy [n, 32] of the field's features): TensorField.finish under bf16 storage
         self._lazy_marks = []  # (stream, event, tensors) of every map built on demand (outside replay)
         self._lazy_seen = {}   # stream -> number of marks that stream is already ordered after
         self._replaying = False

@@ -79,6 +79,13 @@ def set_conv_storage(mode="fp32"):
     return "bf16" if old else "fp32"
 
 
+def rows_to_bf16(x):
+    """bf16 copy [n, 32] (zero-padded) of fp32 rows with at most 32 channels (mink_rows_to_bf16) on the current stream."""
+    xb = torch.empty(x.shape[0], 32, dtype=torch.bfloat16, device=x.device)
+    check(lib().mink_rows_to_bf16(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), xb.data_ptr(), _stream()))
+    return xb
+
+
 def conv_math():
     """The current mode name of set_conv_math (read without changing it)."""
     L = lib()

@@ -125,6 +125,12 @@ class TensorField:
         with torch.cuda.stream(self._build_stream):
             m.finish_field()
             m.replay(plan)
+            F = self._F
+            if (Fn._STORAGE_B16 and F.is_cuda and F.dtype == torch.float32 and F.dim() == 2 and F.shape[1] <= 32
+                    and F.stride(1) == 1 and m.levels[1].n == F.shape[0]):
+                # bf16 storage of the full-resolution stage: the bf16 copy of the input rows (no duplicate voxels: the
+                # sparse tensor's features ARE these rows) is made here, beside the previous step, not at the head of this one
+                m.xb = (F.data_ptr(), Fn.rows_to_bf16(F))
             self._ready = self._build_stream.record_event()
 
     @property
@@ -148,6 +154,8 @@ class TensorField:
             m.hand_over(cur)
             for t in (self._F, self._C):  # may have been produced on the build stream (GPU-side decode)
                 t.record_stream(cur)
+            if m.xb is not None:
+                m.xb[1].record_stream(cur)
             self._ready = None
         n_unique = m.levels[1].n
         F = self._F

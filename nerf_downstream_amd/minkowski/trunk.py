@@ -235,12 +235,17 @@ class TrunkFunction(torch.autograd.Function):
         sd.norm.mean, sd.norm.invstd = a0 + 4 * (ny + n1 * C0), a0 + 4 * (ny + n1 * C0 + C0)
         sd.nbr_pool, sd.in2out, sd.n, sd.n_pool = nbr_pool.data_ptr(), i2o.data_ptr(), n0, n1
         sd.x, sd.y, sd.out, sd.g_out = x.data_ptr(), a0, a0 + 4 * ny, None
-        sd.xb = a0 + 2 * n0 * C0 if b16 else None
+        sd.xb, sd.xb_ready = (a0 + 2 * n0 * C0 if b16 else None), 0
+        xb_pre = getattr(m, "xb", None)
+        if b16 and xb_pre is not None and xb_pre[0] == x.data_ptr() and xb_pre[1].shape[0] == n0 and cin <= 32:
+            sd.xb, sd.xb_ready = xb_pre[1].data_ptr(), 1  # made beside the previous step (TensorField.finish)
+        else:
+            xb_pre = None
         Fn.log_phase("stem_forward_begin", cur)
         check(L.mink_stem_forward(ctypes.byref(sd), exp))
         Fn.log_phase("stem_forward", cur)
         Fn.note_table(nbr0)
-        saved = [(x, w0, arena0, nbr0, nbr_pool, i2o, pad, b16)]
+        saved = [(x, w0, arena0, nbr0, nbr_pool, i2o, pad, b16, xb_pre)]
         # ---- residual blocks
         hp = a0 + 4 * ny
         skew = Fn._SKEW and br != cur
@@ -283,7 +288,7 @@ class TrunkFunction(torch.autograd.Function):
         dev = g_out.device
         g_out = Fn._f32c(g_out)
         sink = Fn._GRAD_SINK
-        x, w0p, arena0, nbr0, nbr_pool, i2o, pad, b16 = saved[0]
+        x, w0p, arena0, nbr0, nbr_pool, i2o, pad, b16, xb_pre = saved[0]
         views = Fn._sink_views(*params) if (sink is not None and pad == 0) else None
         # the weight gradients may run on the side stream (joined once, at the end of backward) when nothing consumes a
         # gradient earlier: the gradient buffer's owner (the sink) has them written in place, or autograd merely
@@ -404,7 +409,7 @@ class TrunkFunction(torch.autograd.Function):
 
     @staticmethod
     def _restore_stem(plan, sv):
-        x, w0, arena0, nbr0, nbr_pool, i2o, pad, b16 = sv
+        x, w0, arena0, nbr0, nbr_pool, i2o, pad, b16, xb_pre = sv
         sd = plan.stem
         n0, n1, C0 = x.shape[0], nbr_pool.shape[0], w0.shape[-1]
         a0 = arena0.data_ptr()
@@ -412,5 +417,5 @@ class TrunkFunction(torch.autograd.Function):
         sd.conv.w, sd.conv.nbr, sd.conv.cin = w0.data_ptr(), nbr0.data_ptr(), x.shape[1]
         sd.norm.mean, sd.norm.invstd = a0 + 4 * (ny + n1 * C0), a0 + 4 * (ny + n1 * C0 + C0)
         sd.nbr_pool, sd.in2out, sd.n, sd.n_pool = nbr_pool.data_ptr(), i2o.data_ptr(), n0, n1
-        sd.xb = a0 + 2 * n0 * C0 if b16 else None
+        sd.xb = (xb_pre[1].data_ptr() if xb_pre is not None else a0 + 2 * n0 * C0) if b16 else None
         sd.x, sd.y, sd.out = x.data_ptr(), a0, a0 + 4 * ny

@@ -71,15 +71,17 @@ gp = torch.randn(npool, C, device=dev)
 dg, db = torch.randn(C, device=dev), torch.randn(C, device=dev)
 need = L.mink_conv_wgrad_workspace_bytes(n, 27, 28, C)
 slabs = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
-dws = [torch.empty(27, 28, C, device=dev) for _ in range(3)]
+dws = [torch.empty(27, 28, C, device=dev) for _ in range(4)]
 f32 = lambda o: check(L.mink_conv_wgrad_bn_relu_pool(xf.data_ptr(), n, 28, 28, yf.data_ptr(), C, gp.data_ptr(), npool, i2o.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dg.data_ptr(), db.data_ptr(), nbr.data_ptr(), n, 27, o.data_ptr(), slabs.data_ptr(), need, st))
 b16 = lambda o: check(L.mink_conv_wgrad_bn_relu_pool_b16(xb.data_ptr(), n, 28, yb.data_ptr(), C, gp.data_ptr(), npool, i2o.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dg.data_ptr(), db.data_ptr(), nbr.data_ptr(), n, 27, o.data_ptr(), slabs.data_ptr(), need, st))
 t0 = timeit(lambda: f32(dws[0]))
 L.mink_conv_set_stagger(1 << 11)
 t1 = timeit(lambda: b16(dws[1]))
-L.mink_conv_set_stagger(0)
+L.mink_conv_set_stagger(32)
 t2 = timeit(lambda: b16(dws[2]))
+L.mink_conv_set_stagger(0)
+t3 = timeit(lambda: b16(dws[3]))
 torch.cuda.synchronize()
-print(f"stem wgrad (fused): fp32 storage {t0:7.1f} us | bf16 storage, 2-byte gathers {t1:7.1f} us | LDS-transposed {t2:7.1f} us")
-print("bitwise: b16 old == fp32-storage", bool(torch.equal(dws[0], dws[1])), "| new == old", bool(torch.equal(dws[1], dws[2])),
-      "| rel diff new vs old", float((dws[2] - dws[1]).norm() / dws[1].norm()))
+print(f"stem wgrad (fused): fp32 storage {t0:7.1f} us | bf16 storage, 2-byte gathers {t1:7.1f} us | LDS-transposed, per-wave images {t2:7.1f} us | images shared by the column halves {t3:7.1f} us")
+print("bitwise: b16 old == fp32-storage", bool(torch.equal(dws[0], dws[1])), "| per-wave == old", bool(torch.equal(dws[1], dws[2])),
+      "| shared == old", bool(torch.equal(dws[1], dws[3])), "| rel diff", float((dws[3] - dws[1]).norm() / dws[1].norm()))

@@ -230,7 +230,8 @@ def test_baseline_batch_backward_and_every_map_match_oracle(oracle_maps, name, b
         Fn.set_conv_math(old), Fn.set_conv_storage(old_st)
     assert hip._trunk_plan, "the native trunk (bench.py's path) was not taken"
     if math == "bf16s":
-        assert trunk_node(out).saved[0][-1] is True, "bf16 storage was not taken"
+        assert trunk_node(out).saved[0][7] is True, "bf16 storage was not taken"
+        assert trunk_node(out).saved[0][8] is not None, "the bf16 copy of the input was not made ahead on the prepare stream"
     assert field.coordinate_manager.prepared, "the second pass must run on maps prepared ahead"
     oout = ref(ref.process_input({"coordinates": coords, "features": feats}))
     err = float((out.detach().cpu() - oout.detach()).abs().max())

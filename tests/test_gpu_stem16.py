@@ -171,7 +171,7 @@ def test_training_step_with_bf16_storage_against_fp32_storage():
             ME.set_conv_math(old_m), ME.set_conv_storage(old_s)
         node = trunk_node(out)
         assert node is not None, "the native trunk was not taken"
-        res[(math, storage)] = (out.detach().clone(), torch.cat([p.grad.flatten() for p in net.parameters()]), node.saved[0][-1],
+        res[(math, storage)] = (out.detach().clone(), torch.cat([p.grad.flatten() for p in net.parameters()]), node.saved[0][7],
                                 node.saved[0][2].numel())
     (o_f, g_f, b_f, sz_f), (o_b, g_b, b_b, sz_b), (_, _, b_x, sz_x) = res[("bf16", "fp32")], res[("bf16", "bf16")], res[("fp32", "bf16")]
     assert (b_f, b_b, b_x) == (False, True, False) and sz_b < sz_f and sz_x == sz_f
