@@ -1823,14 +1823,13 @@ __device__ __forceinline__ unsigned quad_bcast(unsigned v) {  // lane A of every
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, A | (A << 2) | (A << 4) | (A << 6), 0xF, 0xF, false);
 }
 
-// SHARE: the two waves of a row block (column halves wn = 0 / 1) need the same nine gathered operands; instead of each
-// gathering all nine (the L2 -> L1 path, not the matrix pipe, bounds this kernel) each gathers every second one into an
-// image the pair shares, double-buffered over blocks with ONE workgroup barrier per block.
-template <bool SHARE>
+// (A variant whose two column-half waves shared ONE set of gathered operands through a double-buffered image and a
+// barrier per block measured 246 us against 244: the gathers are not what bounds this kernel -- PMC: 184 vector-ALU
+// instructions per 16-row block and wave, the recomputation of dY, beside nine MFMAs.)
 __global__ __launch_bounds__(256, 2) void wgrad_stream_b16t_kernel(WgradParams p) {
   constexpr int G = 9;
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int NSL = SHARE ? 2 * 2 * G : 4 * 3;  // 1 KB operand images: [row pair wa][buffer][offset] / [wave][ring]
+  constexpr int NSL = 4 * 3;  // 1 KB operand images: [wave][ring]
   __shared__ float sR[2 * 16 * 64];
   __shared__ __attribute__((aligned(16))) unsigned short sA[NSL][16 * 32];  // [row][channel]
   __shared__ __attribute__((aligned(16))) unsigned short sB[4][16 * 32];    // [wave][row][column of the wave's half]
@@ -1845,9 +1844,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_b16t_kernel(WgradParams p
   const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
   const int nrel = (int)(rend - rbeg);
   const int nblocks = (nrel + 15) >> 4;
-  // this wave's blocks: b = 2 q + wa.  SHARE: every wave runs the trip count of wa = 0 (a barrier per trip); a block past
-  // the end has no live row
-  const int nq = SHARE ? (nblocks + 1) >> 1 : (nblocks + 1 - wa) >> 1;
+  const int nq = (nblocks + 1 - wa) >> 1;  // this wave's blocks: b = 2 q + wa
   if (tid < 64) {
     const float is = p.invstd[tid], mu = p.mean[tid], ga = p.gamma[tid];
     sC[0][tid] = is, sC[1][tid] = -mu * is, sC[2][tid] = ga, sC[3][tid] = p.beta[tid], sC[4][tid] = ga * is;
@@ -1857,7 +1854,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_b16t_kernel(WgradParams p
   f32x16 acc[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) acc[g] = (f32x16){0};
-  if (nq > 0) {  // (uniform: per wave, with SHARE per workgroup)
+  if (nq > 0) {  // (wave-uniform)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), ry = make_rsrc(p.dy, (unsigned)rend * 128u),
                                  rn = make_rsrc(p.nbr, (unsigned)rend * 4u * 27u), rp = make_rsrc(p.dyp, p.dyp_bytes),
                                  ri = make_rsrc(p.in2out, (unsigned)rend * 4u);
@@ -1869,7 +1866,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_b16t_kernel(WgradParams p
     const int tr_off = (8 * h + ((lane & 15) >> 2)) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);  // transposed read, rows 8h..8h+3 (+128: rows 8h+4..)
     unsigned traw[3], par, ent[G];
     u32x4v ga[G], yraw, dp0, dp1;
-    auto mine = [&](int g) { return !SHARE || (g & 1) == wn; };  // operands this wave gathers
     auto rel_row = [&](int q) { return 16 * (2 * q + wa) + g_row; };
     auto load_table = [&](int q) __attribute__((always_inline)) {  // entries 3 g_ch .. + 2 of the lane's row (g_ch == 3: idle)
       const int r = rel_row(q);
@@ -1929,37 +1925,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_b16t_kernel(WgradParams p
     load_par(0);
     spread();
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-      if (mine(g)) gather(g);
+    for (int g = 0; g < G; ++g) gather(g);
     load_b(0);
     load_table(1);
     load_par(1);
     __builtin_amdgcn_sched_barrier(0);
     for (int q = 0; q < nq; ++q) {
       spread();  // entries of block q + 1
-      if constexpr (SHARE) {
-        // this wave's operands of block q -> the pair's image (buffer q & 1); the registers take block q + 1's rows
-        unsigned short *img = &sA[(wa * 2 + (q & 1)) * G][0];
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-          if (mine(g)) {
-            *reinterpret_cast<u32x4v *>(img + g * 512 + st_off) = ga[g];
-            gather(g);
-          }
-        const bf16x8v bfrag = b_operand(q);
-        load_b(q + 1);  // (its parents arrived one block ago)
-        load_par(q + 2);
-        load_table(q + 2);
-        __syncthreads();  // both waves' operands are in the image (the other buffer is rewritten only after the next barrier)
-        uint2 a_lo = lds_tr16(img + tr_off), a_hi = lds_tr16(img + tr_off + 128);
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const bf16x8v afrag = __builtin_bit_cast(bf16x8v, make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y));
-          if (g + 1 < G) a_lo = lds_tr16(img + (g + 1) * 512 + tr_off), a_hi = lds_tr16(img + (g + 1) * 512 + tr_off + 128);
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[g], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
+      {
         unsigned short *sAw = &sA[wave * 3][0];
         const bf16x8v bfrag = b_operand(q);
         load_b(q + 1);  // (its parents arrived one block ago)
@@ -2480,8 +2453,7 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
     p.beta = fuse->beta, p.dgamma = fuse->dgamma, p.dbeta = fuse->dbeta, p.inv_n = 1.f / (float)n_out;
     p.dyp_bytes = (unsigned)(4 * fuse->n_pool * ldy), p.i2o_bytes = (unsigned)(4 * n_out);
     MINK_REQUIRE(!fuse->b16 || bf16_stream, "wgrad_bn_relu_pool_b16: needs bf16 math (mink_conv_set_math(1))");
-    if (fuse->b16 && cout == 64 && ldx == 32 && !g_b16t_off && !(g_stagger & 32)) wgrad_stream_b16t_kernel<true><<<grid, 256, 0, st>>>(p);
-    else if (fuse->b16 && cout == 64 && ldx == 32 && !g_b16t_off) wgrad_stream_b16t_kernel<false><<<grid, 256, 0, st>>>(p);  // (bit 11: the 2-byte-gather kernel, A/B tests)
+    if (fuse->b16 && cout == 64 && ldx == 32 && !g_b16t_off) wgrad_stream_b16t_kernel<<<grid, 256, 0, st>>>(p);  // (bit 11: the 2-byte-gather kernel, A/B tests)
     else if (fuse->b16) wgrad_stream_bf16_kernel<true, true><<<grid, 256, 0, st>>>(p);
     else if (bf16_stream) wgrad_stream_bf16_kernel<true><<<grid, 256, 0, st>>>(p);  // (four row pairs in flight: 2 / 6 / 8 measured, DESIGN appendix)
     else if (flat) wgrad_stream_kernel<4, true, true><<<grid, 256, 0, st>>>(p);

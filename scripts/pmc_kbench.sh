@@ -11,7 +11,7 @@ for pass in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_I
             "SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LDS_DATA_FIFO_FULL GRBM_GUI_ACTIVE" \
             "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $pass -d $out/p$i -o pmc --output-format csv -- python3 scripts/kbench.py $mode 3 > $out/p$i.log 2>&1 || { tail -5 $out/p$i.log; exit 1; }
+  rocprofv3 --pmc $pass -d $out/p$i -o pmc --output-format csv -- python3 ${KB_SCRIPT:-scripts/kbench.py} $mode 3 > $out/p$i.log 2>&1 || { tail -5 $out/p$i.log; exit 1; }
 done
 python3 - <<'PY'
 import csv, glob, collections, os, re
