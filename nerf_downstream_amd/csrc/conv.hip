@@ -2172,7 +2172,9 @@ int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_cl
       if (row_classes && zs == 4 && blocks <= 640) score = (double)blocks;  // quarters slightly over a round are fine
     }
     else if (row_classes) score = zs == 1;
-    else score = zs > 7 ? 0.0 : (double)blocks / (512.0 * cdiv(blocks, 512)) - 0.01 * zs;
+    // (bf16 math: the matrix work is a sixteenth, so a slab's write + reduce weighs five times as much against it --
+    //  layer1 at B=16, scripts/ksplit_sweep.py: 7 slabs 65 us, 3 slabs 56)
+    else score = zs > 7 ? 0.0 : (double)blocks / (512.0 * cdiv(blocks, 512)) - (g_math == 1 ? 0.05 : 0.01) * zs;
     if (score > best_score) best_score = score, best = zs;
   }
   return best;
