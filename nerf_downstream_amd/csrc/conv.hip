@@ -1987,9 +1987,19 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
   __shared__ float s_part[4][64];
   const int lane = threadIdx.x >> 6, o = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 64 + o;
-  float s = 0.f;
-  if (i < count)
-    for (int z = lane; z < nslab; z += 4) s += ws[(int64_t)z * count + i];
+  // four independent chains per thread (slabs z, z + 4, z + 8, z + 12 of its lane): sixteen loads in flight instead of the
+  // one-after-the-other adds of a single chain -- the stem's 168-slab reduce is the LAST kernel of a training step
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < count) {
+    const float *q = ws + i;
+    int z = lane;
+    for (; z + 12 < nslab; z += 16) {
+      const float a = q[(int64_t)z * count], b = q[(int64_t)(z + 4) * count], c = q[(int64_t)(z + 8) * count], d = q[(int64_t)(z + 12) * count];
+      s0 += a, s1 += b, s2 += c, s3 += d;
+    }
+    for (; z < nslab; z += 4) s0 += q[(int64_t)z * count];
+  }
+  const float s = (s0 + s1) + (s2 + s3);
   s_part[lane][o] = s;
   __syncthreads();
   if (lane == 0 && i < count) out[i] = (s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o]);
