@@ -232,9 +232,8 @@ __device__ __forceinline__ uint64_t blk_hash(uint64_t key) {
   return h;
 }
 
-__global__ __launch_bounds__(kBlock) void blk_insert_kernel(const int *__restrict__ coords, int64_t n, int ts,
-                                                            unsigned long long *table, uint64_t mask,
-                                                            int *__restrict__ slot_of_row) {
+__device__ __forceinline__ void blk_insert_body(const int *__restrict__ coords, int64_t n, int ts, unsigned long long *table,
+                                                uint64_t mask, int *__restrict__ slot_of_row) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const int4 c = reinterpret_cast<const int4 *>(coords)[i];
@@ -256,10 +255,10 @@ __global__ __launch_bounds__(kBlock) void blk_insert_kernel(const int *__restric
 // its own workgroup and hands every leader its start.  No atomics (a single counter word takes ~90 adds per
 // microsecond: 70 k leaders on it serialise for longer than the rest of the build), deterministic layout.
 template <bool ASSIGN>
-__global__ __launch_bounds__(kBlock) void blk_leader_kernel(const int *__restrict__ coords, int64_t n, int ts,
-                                                            const unsigned long long *__restrict__ table,
-                                                            const int *__restrict__ slot_of_row, int *__restrict__ base,
-                                                            int *__restrict__ wg_counts) {
+__device__ __forceinline__ void blk_leader_body(const int *__restrict__ coords, int64_t n, int ts,
+                                                const unsigned long long *__restrict__ table,
+                                                const int *__restrict__ slot_of_row, int *__restrict__ base,
+                                                int *__restrict__ wg_counts) {
   __shared__ int s_wave[kBlock / 64];
   const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool live = i0 < n;
@@ -300,10 +299,9 @@ __global__ __launch_bounds__(kBlock) void blk_leader_kernel(const int *__restric
   if (leader) base[s] = before + incl - cnt;
 }
 
-__global__ __launch_bounds__(kBlock) void blk_fill_kernel(const int *__restrict__ coords, int64_t n, int ts,
-                                                          const unsigned long long *__restrict__ table,
-                                                          const int *__restrict__ slot_of_row,
-                                                          const int *__restrict__ base, int *__restrict__ rowids) {
+__device__ __forceinline__ void blk_fill_body(const int *__restrict__ coords, int64_t n, int ts,
+                                              const unsigned long long *__restrict__ table, const int *__restrict__ slot_of_row,
+                                              const int *__restrict__ base, int *__restrict__ rowids) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const int4 c = reinterpret_cast<const int4 *>(coords)[i];
@@ -315,13 +313,55 @@ __global__ __launch_bounds__(kBlock) void blk_fill_kernel(const int *__restrict_
   rowids[base[s] + __popcll(m & ((1ull << local) - 1ull))] = (int)i;
 }
 
+// The block indices of ALL input maps of a batch's plan are built by four launches, not four per map (blockIdx.y = map):
+// the builds are independent of each other, and a prepared batch has six of them.
+constexpr int kMaxBatch = 8;
+struct BlkBuild {
+  const int *coords;
+  int64_t n;
+  unsigned long long *table;
+  uint64_t mask;
+  int *slot, *base, *rowids;
+  int ts;
+};
+struct BlkBuildBatch {
+  BlkBuild e[kMaxBatch];
+};
+__global__ __launch_bounds__(kBlock) void blk_insert_kernel(BlkBuildBatch b) {
+  const BlkBuild &e = b.e[blockIdx.y];
+  if ((int64_t)blockIdx.x * kBlock >= e.n) return;
+  blk_insert_body(e.coords, e.n, e.ts, e.table, e.mask, e.slot);
+}
+template <bool ASSIGN>
+__global__ __launch_bounds__(kBlock) void blk_leader_kernel(BlkBuildBatch b) {
+  const BlkBuild &e = b.e[blockIdx.y];
+  if ((int64_t)blockIdx.x * kBlock >= e.n) return;  // (whole workgroups: the barriers below are reached by all or none)
+  blk_leader_body<ASSIGN>(e.coords, e.n, e.ts, e.table, e.slot, e.base, e.rowids);  // (workgroup counts live in the head of rowids)
+}
+__global__ __launch_bounds__(kBlock) void blk_fill_kernel(BlkBuildBatch b) {
+  const BlkBuild &e = b.e[blockIdx.y];
+  if ((int64_t)blockIdx.x * kBlock >= e.n) return;
+  blk_fill_body(e.coords, e.n, e.ts, e.table, e.slot, e.base, e.rowids);
+}
+// 0xFF fill of up to sixteen buffers (sizes multiples of 16 bytes) in one launch: blockIdx.y = buffer
+struct FillBatch {
+  uint4 *ptr[16];
+  int64_t n16[16];
+};
+__global__ __launch_bounds__(kBlock) void fill_ff_kernel(FillBatch f) {
+  uint4 *p = f.ptr[blockIdx.y];
+  const int64_t n = f.n16[blockIdx.y];
+  const uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = v;
+}
+
 // Same result as kernel_map_kernel, through the block index.  Thread per (output row, offset): the 27 look-ups of a
 // row sit in adjacent lanes and hit the same one to eight block entries.
-__global__ __launch_bounds__(kBlock) void kernel_map_blk_kernel(const unsigned long long *__restrict__ table,
-                                                                const int *__restrict__ base,
-                                                                const int *__restrict__ rowids, uint64_t mask, int ts,
-                                                                const int *__restrict__ out_coords, int64_t n_out, int K,
-                                                                Offsets off, int *__restrict__ nbr, int *nbr_t) {
+template <class OFF>
+__device__ __forceinline__ void kernel_map_blk_body(const unsigned long long *__restrict__ table, const int *__restrict__ base,
+                                                    const int *__restrict__ rowids, uint64_t mask, int ts,
+                                                    const int *__restrict__ out_coords, int64_t n_out, int K, const OFF &off,
+                                                    int *__restrict__ nbr, int *nbr_t) {
   const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n_out * K) return;
   const int64_t o = idx / K;
@@ -352,11 +392,10 @@ __global__ __launch_bounds__(kBlock) void kernel_map_blk_kernel(const unsigned l
 // bit tests and popcounts: ~20 instructions per neighbour instead of ~300 for one probe chain each.  Results are
 // staged in LDS and written as one contiguous run per workgroup.
 template <bool HAS_T>
-__global__ __launch_bounds__(kBlock) void kernel_map_blk27_kernel(const unsigned long long *__restrict__ table,
-                                                                  const int *__restrict__ base,
-                                                                  const int *__restrict__ rowids, uint64_t mask, int ts,
-                                                                  const int *__restrict__ out_coords, int64_t n_out,
-                                                                  int *__restrict__ nbr, int *nbr_t) {
+__device__ __forceinline__ void kernel_map_blk27_body(const unsigned long long *__restrict__ table, const int *__restrict__ base,
+                                                      const int *__restrict__ rowids, uint64_t mask, int ts,
+                                                      const int *__restrict__ out_coords, int64_t n_out, int *__restrict__ nbr,
+                                                      int *nbr_t) {
   __shared__ int s_out[kBlock * 27];
   const int64_t o0 = (int64_t)blockIdx.x * kBlock;
   const int64_t o = o0 + threadIdx.x;
@@ -423,6 +462,51 @@ __global__ __launch_bounds__(kBlock) void kernel_map_blk27_kernel(const unsigned
   const int64_t rows = n_out - o0 < kBlock ? n_out - o0 : kBlock;
   const int total = (int)rows * 27;
   for (int e = threadIdx.x; e < total; e += kBlock) nbr[o0 * 27 + e] = s_out[e];
+}
+
+__global__ __launch_bounds__(kBlock) void kernel_map_blk_kernel(const unsigned long long *__restrict__ table,
+                                                                const int *__restrict__ base,
+                                                                const int *__restrict__ rowids, uint64_t mask, int ts,
+                                                                const int *__restrict__ out_coords, int64_t n_out, int K,
+                                                                Offsets off, int *__restrict__ nbr, int *nbr_t) {
+  kernel_map_blk_body(table, base, rowids, mask, ts, out_coords, n_out, K, off, nbr, nbr_t);
+}
+struct SmallOffsets {  // up to eight offsets (pooling 2^3, 1x1x1)
+  int d[24];
+};
+struct KMapS {
+  const unsigned long long *table;
+  const int *base, *rowids, *out_coords;
+  uint64_t mask;
+  int64_t n_out;
+  int *nbr, *nbr_t;
+  int ts, K;
+  SmallOffsets off;
+};
+struct KMapSBatch {
+  KMapS e[kMaxBatch];
+};
+__global__ __launch_bounds__(kBlock) void kernel_map_blk_small_kernel(KMapSBatch b) {  // blockIdx.y = table
+  const KMapS &e = b.e[blockIdx.y];
+  if ((int64_t)blockIdx.x * kBlock >= e.n_out * e.K) return;
+  kernel_map_blk_body(e.table, e.base, e.rowids, e.mask, e.ts, e.out_coords, e.n_out, e.K, e.off, e.nbr, e.nbr_t);
+}
+struct KMap27 {
+  const unsigned long long *table;
+  const int *base, *rowids, *out_coords;
+  uint64_t mask;
+  int64_t n_out;
+  int *nbr, *nbr_t;
+  int ts;
+};
+struct KMap27Batch {
+  KMap27 e[kMaxBatch];
+};
+template <bool HAS_T>
+__global__ __launch_bounds__(kBlock) void kernel_map_blk27_kernel(KMap27Batch b) {  // blockIdx.y = table
+  const KMap27 &e = b.e[blockIdx.y];
+  if ((int64_t)blockIdx.x * kBlock >= e.n_out) return;
+  kernel_map_blk27_body<HAS_T>(e.table, e.base, e.rowids, e.mask, e.ts, e.out_coords, e.n_out, e.nbr, e.nbr_t);
 }
 
 // -------------------------------------------------------------------------- rulebook
@@ -798,43 +882,110 @@ int mink_kernel_map(const uint64_t *in_table_keys, const int32_t *in_table_vals,
 int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
   MINK_REQUIRE(n >= 0 && (n == 0 || d), "kernel_map_batch: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  // One batch's plan is ~6 block indices and ~14 tables over independent maps: the 0xFF fills, the four passes of the
+  // index builds and the table kernels are each issued as ONE launch over all of them (blockIdx.y = map), in that order.
+  // ---- pass 0: validation, fills
+  FillBatch fills;
+  int n_fill = 0;
+  int64_t fill_max = 0;
+  auto flush_fills = [&]() -> int {
+    if (n_fill == 0) return MINK_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(fill_max, kBlock), 2048);
+    fill_ff_kernel<<<dim3((unsigned)blocks, (unsigned)n_fill), kBlock, 0, st>>>(fills);
+    MINK_CHECK_LAUNCH();
+    n_fill = 0, fill_max = 0;
+    return MINK_OK;
+  };
+  auto add_fill = [&](void *ptr, int64_t bytes) -> int {
+    if (bytes <= 0) return MINK_OK;
+    if (((uintptr_t)ptr & 15) || (bytes & 15)) {  // (not a run of 16-byte words: the runtime's fill)
+      MINK_HIP(hipMemsetAsync(ptr, 0xFF, (size_t)bytes, st));
+      return MINK_OK;
+    }
+    fills.ptr[n_fill] = (uint4 *)ptr, fills.n16[n_fill] = bytes >> 4;
+    fill_max = std::max(fill_max, bytes >> 4);
+    if (++n_fill == 16) return flush_fills();
+    return MINK_OK;
+  };
   for (int i = 0; i < n; ++i) {
     const MinkKernelMapDesc &e = d[i];
-    if (e.nbr_t && e.n_in > 0) MINK_HIP(hipMemsetAsync(e.nbr_t, 0xFF, sizeof(int32_t) * e.n_in * e.K, st));
+    if (e.nbr_t && e.n_in > 0) {
+      int rc = add_fill(e.nbr_t, (int64_t)sizeof(int32_t) * e.n_in * e.K);
+      if (rc) return rc;
+    }
+    if (!e.blk_table) continue;
+    MINK_REQUIRE(e.K >= 1 && e.K <= 27 && e.n_out >= 0 && e.n_in >= 0 && e.n_out * e.K < (1ll << 31) && e.in_ts >= 1,
+                 "kernel_map_batch: bad shape in descriptor %d", i);
+    MINK_REQUIRE(e.blk_cap >= 64 && (e.blk_cap & (e.blk_cap - 1)) == 0 && e.blk_cap >= 2 * e.n_in && e.blk_base && e.blk_slot &&
+                     e.blk_rowids && e.blk_counter && e.in_coords && ((uintptr_t)e.blk_table & 15) == 0,
+                 "kernel_map_batch: bad block-index buffers in descriptor %d", i);
+    MINK_REQUIRE(e.n_out == 0 || (e.out_coords && e.nbr && ((uintptr_t)e.out_coords & 15) == 0), "kernel_map_batch: NULL/misaligned pointer");
+    if (e.blk_build) {
+      int rc = add_fill(e.blk_table, (int64_t)sizeof(uint64_t) * 2 * e.blk_cap);
+      if (rc) return rc;
+    }
+  }
+  {
+    int rc = flush_fills();
+    if (rc) return rc;
+  }
+  // ---- pass 1: block indices (insert, two leader passes, fill)
+  for (int i0 = 0; i0 < n;) {
+    BlkBuildBatch bb;
+    int nb = 0;
+    int64_t nmax = 0;
+    int i = i0;
+    for (; i < n && nb < kMaxBatch; ++i) {
+      const MinkKernelMapDesc &e = d[i];
+      if (!e.blk_table || !e.blk_build || e.n_in <= 0) continue;
+      BlkBuild &q = bb.e[nb++];
+      q.coords = e.in_coords, q.n = e.n_in, q.table = (unsigned long long *)e.blk_table, q.mask = (uint64_t)e.blk_cap - 1;
+      q.slot = e.blk_slot, q.base = e.blk_base, q.rowids = e.blk_rowids, q.ts = e.in_ts;
+      nmax = std::max(nmax, e.n_in);
+    }
+    i0 = i;
+    if (nb == 0) continue;
+    const dim3 g((unsigned)cdiv(nmax, kBlock), (unsigned)nb);
+    blk_insert_kernel<<<g, kBlock, 0, st>>>(bb);
+    MINK_CHECK_LAUNCH();
+    blk_leader_kernel<false><<<g, kBlock, 0, st>>>(bb);
+    MINK_CHECK_LAUNCH();
+    blk_leader_kernel<true><<<g, kBlock, 0, st>>>(bb);
+    MINK_CHECK_LAUNCH();
+    blk_fill_kernel<<<g, kBlock, 0, st>>>(bb);
+    MINK_CHECK_LAUNCH();
+  }
+  // ---- pass 2: tables.  3x3x3 unit-offset tables (with / without the transposed table) and the small ones (pooling, 1x1x1)
+  // in one launch per kind; anything else one launch per table
+  KMap27Batch b27[2];
+  KMapSBatch bs;
+  int n27[2] = {0, 0}, ns = 0;
+  int64_t max27[2] = {0, 0}, maxs = 0;
+  auto flush27 = [&](int t) -> int {
+    if (n27[t] == 0) return MINK_OK;
+    const dim3 g((unsigned)cdiv(max27[t], kBlock), (unsigned)n27[t]);
+    if (t) kernel_map_blk27_kernel<true><<<g, kBlock, 0, st>>>(b27[1]);
+    else kernel_map_blk27_kernel<false><<<g, kBlock, 0, st>>>(b27[0]);
+    MINK_CHECK_LAUNCH();
+    n27[t] = 0, max27[t] = 0;
+    return MINK_OK;
+  };
+  auto flush_small = [&]() -> int {
+    if (ns == 0) return MINK_OK;
+    kernel_map_blk_small_kernel<<<dim3((unsigned)cdiv(maxs, kBlock), (unsigned)ns), kBlock, 0, st>>>(bs);
+    MINK_CHECK_LAUNCH();
+    ns = 0, maxs = 0;
+    return MINK_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const MinkKernelMapDesc &e = d[i];
     if (!e.blk_table) {  // per-voxel hash map
       int rc = mink_kernel_map(e.in_table_keys, e.in_table_vals, e.in_cap, e.out_coords, e.n_out, e.offsets, e.K, e.nbr, e.nbr_t,
                                stream);
       if (rc) return rc;
       continue;
     }
-    MINK_REQUIRE(e.K >= 1 && e.K <= 27 && e.n_out >= 0 && e.n_in >= 0 && e.n_out * e.K < (1ll << 31) && e.in_ts >= 1,
-                 "kernel_map_batch: bad shape in descriptor %d", i);
-    MINK_REQUIRE(e.blk_cap >= 64 && (e.blk_cap & (e.blk_cap - 1)) == 0 && e.blk_cap >= 2 * e.n_in && e.blk_base && e.blk_slot &&
-                     e.blk_rowids && e.blk_counter && e.in_coords && ((uintptr_t)e.blk_table & 15) == 0,
-                 "kernel_map_batch: bad block-index buffers in descriptor %d", i);
-    if (e.blk_build) {
-      MINK_HIP(hipMemsetAsync(e.blk_table, 0xFF, sizeof(uint64_t) * 2 * e.blk_cap, st));
-      if (e.n_in > 0) {
-        const dim3 g((unsigned)cdiv(e.n_in, kBlock));
-        blk_insert_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (unsigned long long *)e.blk_table,
-                                                (uint64_t)e.blk_cap - 1, e.blk_slot);
-        MINK_CHECK_LAUNCH();
-        // (the two passes keep the workgroup counts in the head of blk_rowids, which the fill pass overwrites only after
-        //  they have been turned into per-block bases)
-        int *wg_counts = e.blk_rowids;
-        blk_leader_kernel<false><<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table,
-                                                       e.blk_slot, e.blk_base, wg_counts);
-        MINK_CHECK_LAUNCH();
-        blk_leader_kernel<true><<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table,
-                                                      e.blk_slot, e.blk_base, wg_counts);
-        MINK_CHECK_LAUNCH();
-        blk_fill_kernel<<<g, kBlock, 0, st>>>(e.in_coords, e.n_in, e.in_ts, (const unsigned long long *)e.blk_table, e.blk_slot,
-                                              e.blk_base, e.blk_rowids);
-        MINK_CHECK_LAUNCH();
-      }
-    }
     if (e.n_out == 0) continue;
-    MINK_REQUIRE(e.out_coords && e.nbr && ((uintptr_t)e.out_coords & 15) == 0, "kernel_map_batch: NULL/misaligned pointer");
     Offsets off;
     memset(&off, 0, sizeof off);
     memcpy(off.d, e.offsets, sizeof(int) * 3 * e.K);
@@ -843,22 +994,40 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
       unit27 = off.d[3 * k] == (k % 3 - 1) * e.in_ts && off.d[3 * k + 1] == ((k / 3) % 3 - 1) * e.in_ts &&
                off.d[3 * k + 2] == (k / 9 - 1) * e.in_ts;
     if (unit27) {
-      const dim3 g((unsigned)cdiv(e.n_out, kBlock));
-      if (e.nbr_t)
-        kernel_map_blk27_kernel<true><<<g, kBlock, 0, st>>>((const unsigned long long *)e.blk_table, e.blk_base, e.blk_rowids,
-                                                           (uint64_t)e.blk_cap - 1, e.in_ts, e.out_coords, e.n_out, e.nbr,
-                                                           e.nbr_t);
-      else
-        kernel_map_blk27_kernel<false><<<g, kBlock, 0, st>>>((const unsigned long long *)e.blk_table, e.blk_base, e.blk_rowids,
-                                                            (uint64_t)e.blk_cap - 1, e.in_ts, e.out_coords, e.n_out, e.nbr,
-                                                            nullptr);
-      MINK_CHECK_LAUNCH();
+      const int t = e.nbr_t ? 1 : 0;
+      KMap27 &q = b27[t].e[n27[t]++];
+      q.table = (const unsigned long long *)e.blk_table, q.base = e.blk_base, q.rowids = e.blk_rowids, q.out_coords = e.out_coords;
+      q.mask = (uint64_t)e.blk_cap - 1, q.n_out = e.n_out, q.nbr = e.nbr, q.nbr_t = e.nbr_t, q.ts = e.in_ts;
+      max27[t] = std::max(max27[t], e.n_out);
+      if (n27[t] == kMaxBatch) {
+        int rc = flush27(t);
+        if (rc) return rc;
+      }
+      continue;
+    }
+    if (e.K <= 8) {
+      KMapS &q = bs.e[ns++];
+      q.table = (const unsigned long long *)e.blk_table, q.base = e.blk_base, q.rowids = e.blk_rowids, q.out_coords = e.out_coords;
+      q.mask = (uint64_t)e.blk_cap - 1, q.n_out = e.n_out, q.nbr = e.nbr, q.nbr_t = e.nbr_t, q.ts = e.in_ts, q.K = e.K;
+      memset(&q.off, 0, sizeof q.off);
+      memcpy(q.off.d, e.offsets, sizeof(int) * 3 * e.K);
+      maxs = std::max(maxs, e.n_out * e.K);
+      if (ns == kMaxBatch) {
+        int rc = flush_small();
+        if (rc) return rc;
+      }
       continue;
     }
     kernel_map_blk_kernel<<<dim3((unsigned)cdiv(e.n_out * e.K, kBlock)), kBlock, 0, st>>>(
         (const unsigned long long *)e.blk_table, e.blk_base, e.blk_rowids, (uint64_t)e.blk_cap - 1, e.in_ts, e.out_coords, e.n_out,
         e.K, off, e.nbr, e.nbr_t);
     MINK_CHECK_LAUNCH();
+  }
+  {
+    int rc = flush27(0);
+    if (!rc) rc = flush27(1);
+    if (!rc) rc = flush_small();
+    if (rc) return rc;
   }
   return MINK_OK;
 }
