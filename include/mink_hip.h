@@ -171,6 +171,17 @@ int64_t mink_class_partition_rows(int64_t n, int32_t pad);
 int64_t mink_class_partition_workspace_bytes(int64_t n);
 int mink_class_partition(const int32_t *coords, int64_t n, int32_t ts, int32_t pad, int32_t *perm,
                          void *workspace, int64_t workspace_bytes, void *stream);
+/* The same for up to eight maps in four launches (fill, count, scan, place; blockIdx.y = map) instead of four per map:
+ * what a prepared batch asks for (one permutation per strided convolution of the network). */
+typedef struct MinkClassPartitionDesc {
+  const int32_t *coords; /* [n][4] */
+  int64_t n;
+  int32_t ts, pad;
+  int32_t *perm;         /* mink_class_partition_rows(n, pad) entries */
+  void *workspace;       /* mink_class_partition_workspace_bytes(n), 256-byte aligned */
+  int64_t workspace_bytes;
+} MinkClassPartitionDesc;
+int mink_class_partition_batch(int32_t n_maps, const MinkClassPartitionDesc *descs, void *stream);
 
 /* Row ranges of each batch index in a coordinate list whose batch column is
  * non-decreasing (guaranteed by ME.utils.sparse_collate, data/utils.py:25-30).

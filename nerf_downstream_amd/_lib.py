@@ -59,6 +59,12 @@ class BasicBlock(ctypes.Structure):
                 ("yd", _p), ("sd", _p), ("out", _p), ("g_out", _p), ("g_x", _p), ("g_tmp", _p)]
 
 
+class ClassPartitionDesc(ctypes.Structure):
+    """MinkClassPartitionDesc"""
+
+    _fields_ = [("coords", _p), ("n", _i64), ("ts", _i32), ("pad", _i32), ("perm", _p), ("workspace", _p), ("workspace_bytes", _i64)]
+
+
 class TimingEntry(ctypes.Structure):
     """MinkTimingEntry"""
 
@@ -138,6 +144,7 @@ SIGNATURES = {
     "mink_activation": (ctypes.c_int, [_p, _p, _p, _i32, _i64, _i32, _f32, _p, _p]),
     "mink_block_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
     "mink_block_grad_scratch_floats": (_i64, [_i64, _i64, _i32, _i32, _i32]),
+    "mink_class_partition_batch": (ctypes.c_int, [_i32, _p, _p]),
     "mink_rows_to_bf16": (ctypes.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "mink_stem_conv_bf16s_supported": (ctypes.c_int, [_i64, _i64, _i32, _i32, _i32]),
     "mink_stem_conv_bf16s_stats_rows": (_i32, []),

@@ -107,8 +107,7 @@ __global__ __launch_bounds__(kBlock) void flag_kernel(const int *__restrict__ tv
 // fills the register files -- the stem convolution runs while the next batch's maps are built -- it was seen waiting
 // 590 us for that to happen.)
 constexpr int kScanBlock = 256;
-__global__ __launch_bounds__(kScanBlock) void scan_kernel(const int *__restrict__ in, int *__restrict__ out, int64_t n,
-                                                          int *total_out) {
+__device__ __forceinline__ void scan_body(const int *__restrict__ in, int *__restrict__ out, int64_t n, int *total_out) {
   constexpr int IT = 16;
   __shared__ int s_wave[kScanBlock / 64];
   __shared__ int s_carry;
@@ -149,6 +148,18 @@ __global__ __launch_bounds__(kScanBlock) void scan_kernel(const int *__restrict_
     __syncthreads();
   }
   if (threadIdx.x == 0 && total_out) *total_out = s_carry;
+}
+__global__ __launch_bounds__(kScanBlock) void scan_kernel(const int *__restrict__ in, int *__restrict__ out, int64_t n,
+                                                          int *total_out) {
+  scan_body(in, out, n, total_out);
+}
+struct ScanBatch {  // one workgroup per array
+  const int *in[8];
+  int *out[8], *total[8];
+  int64_t n[8];
+};
+__global__ __launch_bounds__(kScanBlock) void scan_batch_kernel(ScanBatch b) {
+  scan_body(b.in[blockIdx.x], b.out[blockIdx.x], b.n[blockIdx.x], b.total[blockIdx.x]);
 }
 
 __global__ __launch_bounds__(kBlock) void assign_kernel(const uint64_t *__restrict__ keys,
@@ -560,11 +571,9 @@ __device__ __forceinline__ int parity_class(int4 c, int ts) {
 }
 
 template <bool FILL>
-__global__ __launch_bounds__(kBlock) void class_partition_kernel(const int *__restrict__ coords, int64_t n, int ts,
-                                                                 int64_t nchunk, int pad,
-                                                                 int *__restrict__ chunk_counts,
-                                                                 const int *__restrict__ chunk_offsets,
-                                                                 const int *__restrict__ total, int *__restrict__ perm) {
+__device__ __forceinline__ void class_partition_body(const int *__restrict__ coords, int64_t n, int ts, int64_t nchunk, int pad,
+                                                     int *__restrict__ chunk_counts, const int *__restrict__ chunk_offsets,
+                                                     const int *__restrict__ total, int *__restrict__ perm) {
   __shared__ int s_cnt[kBlock / 64][8];
   __shared__ int s_shift[8];
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -601,6 +610,31 @@ __global__ __launch_bounds__(kBlock) void class_partition_kernel(const int *__re
 }
 
 // --------------------------------------------------------------------- batch offsets
+
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void class_partition_kernel(const int *__restrict__ coords, int64_t n, int ts,
+                                                                 int64_t nchunk, int pad,
+                                                                 int *__restrict__ chunk_counts,
+                                                                 const int *__restrict__ chunk_offsets,
+                                                                 const int *__restrict__ total, int *__restrict__ perm) {
+  class_partition_body<FILL>(coords, n, ts, nchunk, pad, chunk_counts, chunk_offsets, total, perm);
+}
+struct ClassPart {
+  const int *coords;
+  int64_t n, nchunk;
+  int *chunk_counts, *chunk_offsets, *total, *perm;
+  int ts, pad;
+};
+struct ClassPartBatch {
+  ClassPart e[8];
+};
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void class_partition_batch_kernel(ClassPartBatch b) {  // blockIdx.y = map
+  const ClassPart &e = b.e[blockIdx.y];
+  if ((int64_t)blockIdx.x >= e.nchunk) return;
+  class_partition_body<FILL>(e.coords, e.n, e.ts, e.nchunk, e.pad, e.chunk_counts, e.chunk_offsets, e.total, e.perm);
+}
+
 __global__ __launch_bounds__(kBlock) void batch_offsets_kernel(const int *__restrict__ coords, int64_t n, int B,
                                                                int *__restrict__ batch_offsets, uint32_t *status) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1094,6 +1128,50 @@ int mink_class_partition(const int32_t *coords, int64_t n, int32_t ts, int32_t p
   scan_kernel<<<1, kScanBlock, 0, st>>>(chunk_counts, chunk_offsets, nchunk * 8, total);
   MINK_CHECK_LAUNCH();
   class_partition_kernel<true><<<grid, kBlock, 0, st>>>(coords, n, ts, nchunk, pad, nullptr, chunk_offsets, total, perm);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_class_partition_batch(int32_t n_maps, const MinkClassPartitionDesc *d, void *stream) {
+  MINK_REQUIRE(n_maps >= 0 && n_maps <= 8 && (n_maps == 0 || d), "class_partition_batch: 0..8 maps per call");
+  hipStream_t st = (hipStream_t)stream;
+  FillBatch fills;
+  ClassPartBatch cb;
+  ScanBatch sb;
+  int nf = 0, nb = 0;
+  int64_t fill_max = 0, chunk_max = 0;
+  for (int i = 0; i < n_maps; ++i) {
+    const MinkClassPartitionDesc &e = d[i];
+    MINK_REQUIRE(e.n >= 0 && e.ts >= 1 && e.pad >= 1 && e.perm, "class_partition_batch: bad arguments in descriptor %d", i);
+    MINK_REQUIRE(e.n == 0 || e.workspace_bytes >= mink_class_partition_workspace_bytes(e.n),
+                 "class_partition_batch: workspace of %lld bytes, %lld needed", (long long)e.workspace_bytes,
+                 (long long)mink_class_partition_workspace_bytes(e.n));
+    const int64_t bytes = (int64_t)sizeof(int32_t) * mink_class_partition_rows(e.n, e.pad);
+    if (((uintptr_t)e.perm & 15) || (bytes & 15)) MINK_HIP(hipMemsetAsync(e.perm, 0xFF, (size_t)bytes, st));
+    else if (bytes > 0) fills.ptr[nf] = (uint4 *)e.perm, fills.n16[nf] = bytes >> 4, fill_max = std::max(fill_max, bytes >> 4), ++nf;
+    if (e.n == 0) continue;
+    MINK_REQUIRE(e.coords && e.workspace && ((uintptr_t)e.coords & 15) == 0 && ((uintptr_t)e.workspace & 255) == 0,
+                 "class_partition_batch: NULL/misaligned pointer in descriptor %d", i);
+    ClassPart &q = cb.e[nb];
+    q.coords = e.coords, q.n = e.n, q.nchunk = cdiv(e.n, kBlock), q.ts = e.ts, q.pad = e.pad, q.perm = e.perm;
+    q.chunk_counts = (int *)e.workspace;
+    q.chunk_offsets = (int *)((char *)e.workspace + align_up(4 * q.nchunk * 8, 256));
+    q.total = q.chunk_offsets + q.nchunk * 8;
+    sb.in[nb] = q.chunk_counts, sb.out[nb] = q.chunk_offsets, sb.total[nb] = q.total, sb.n[nb] = q.nchunk * 8;
+    chunk_max = std::max(chunk_max, q.nchunk);
+    ++nb;
+  }
+  if (nf) {
+    fill_ff_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv(fill_max, kBlock), 2048), (unsigned)nf), kBlock, 0, st>>>(fills);
+    MINK_CHECK_LAUNCH();
+  }
+  if (nb == 0) return MINK_OK;
+  const dim3 grid((unsigned)chunk_max, (unsigned)nb);
+  class_partition_batch_kernel<false><<<grid, kBlock, 0, st>>>(cb);
+  MINK_CHECK_LAUNCH();
+  scan_batch_kernel<<<dim3((unsigned)nb), kScanBlock, 0, st>>>(sb);
+  MINK_CHECK_LAUNCH();
+  class_partition_batch_kernel<true><<<grid, kBlock, 0, st>>>(cb);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

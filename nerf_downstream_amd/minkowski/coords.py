@@ -175,6 +175,7 @@ class CoordinateManager:
 
     def _replay_ops(self, plan):
         self._build_tables_batched([op for op in plan if op[0] == "ktable"])
+        self._build_perms_batched([op for op in plan if op[0] == "perm"])
         for op in plan:
             if op[0] == "stride":
                 self.stride(CoordinateMapKey(op[1]), op[2])
@@ -184,6 +185,27 @@ class CoordinateManager:
                 self.class_perm(CoordinateMapKey(op[1]), op[2])
             elif op[0] == "boff":
                 self.batch_offsets(CoordinateMapKey(op[1]))
+
+    def _build_perms_batched(self, ops):
+        """All parity-class permutations of a plan with one native call (four launches, not four per map)."""
+        import ctypes
+
+        from .._lib import ClassPartitionDesc
+
+        L = lib()
+        todo = [(ts, pad) for _, ts, pad in dict.fromkeys(ops) if ts in self.levels and ("perm", ts, pad) not in self.tables]
+        for i0 in range(0, len(todo), 8):
+            part = todo[i0 : i0 + 8]
+            descs = (ClassPartitionDesc * len(part))()
+            for d, (ts, pad) in zip(descs, part):
+                lev = self.levels[ts]
+                perm = self._take(int(L.mink_class_partition_rows(lev.n, pad)), torch.int32)
+                ws = self._take(int(L.mink_class_partition_workspace_bytes(lev.n)), torch.uint8)
+                d.coords, d.n, d.ts, d.pad, d.perm = lev.coords.data_ptr(), lev.n, ts, pad, perm.data_ptr()
+                d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+                self.tables[("perm", ts, pad)] = perm
+                self._note_lazy(perm)
+            check(L.mink_class_partition_batch(len(part), ctypes.byref(descs), _stream()))
 
     def _build_tables_batched(self, ops):
         """All neighbour tables of a plan with one allocation and one native call."""

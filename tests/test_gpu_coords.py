@@ -228,3 +228,46 @@ def test_block_index_tables_equal_the_per_voxel_hash():
         torch.cuda.synchronize()
         assert torch.equal(nbr, ref), (kin.ts, kout.ts, ks)
         assert (nbr_t is None) == (ref_t is None) and (ref_t is None or torch.equal(nbr_t, ref_t)), (kin.ts, kout.ts, ks)
+
+
+def test_class_partition_batch_equals_the_per_map_calls():
+    """mink_class_partition_batch (four launches over all maps of a plan) against mink_class_partition map by map: the same
+    permutations, bit for bit -- maps of very different sizes in one batch, an empty one included."""
+    import ctypes
+
+    from nerf_downstream_amd import minkowski as ME
+    from nerf_downstream_amd._lib import ClassPartitionDesc, check, lib
+
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    coords, feats = batch_scenes([3, 4, 5], grid=48, cin=4)
+    x = ME.TensorField(coordinates=coords.cuda(), features=feats.cuda()).sparse()
+    m = x.coordinate_manager
+    levels = [(1, m.levels[1])]
+    for ts in (1, 2, 4):
+        m.stride(ME.CoordinateMapKey(ts), 2)
+        levels.append((2 * ts, m.levels[2 * ts]))
+    pad = 128
+    want, keep = [], []
+    descs = (ClassPartitionDesc * (len(levels) + 1))()
+    got = []
+    for d, (ts, lev) in zip(descs, levels):
+        rows = int(L.mink_class_partition_rows(lev.n, pad))
+        wsb = int(L.mink_class_partition_workspace_bytes(lev.n))
+        ref = torch.empty(rows, dtype=torch.int32, device="cuda")
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        check(L.mink_class_partition(lev.coords.data_ptr(), lev.n, ts, pad, ref.data_ptr(), ws.data_ptr(), wsb, st))
+        want.append(ref)
+        out, ws2 = torch.full((rows,), 7, dtype=torch.int32, device="cuda"), torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        d.coords, d.n, d.ts, d.pad, d.perm, d.workspace, d.workspace_bytes = lev.coords.data_ptr(), lev.n, ts, pad, out.data_ptr(), ws2.data_ptr(), wsb
+        got.append(out)
+        keep.append(ws2)
+    e = descs[len(levels)]  # an empty map: only its (empty) permutation is filled
+    empty = torch.full((int(L.mink_class_partition_rows(0, pad)) + 4,), 7, dtype=torch.int32, device="cuda")
+    e.coords, e.n, e.ts, e.pad, e.perm, e.workspace, e.workspace_bytes = None, 0, 1, pad, empty.data_ptr(), None, 0
+    check(L.mink_class_partition_batch(len(levels) + 1, ctypes.byref(descs), st))
+    torch.cuda.synchronize()
+    for (ts, lev), a, b in zip(levels, want, got):
+        assert torch.equal(a, b), (ts, lev.n)
+        assert sorted(b[b >= 0].tolist()) == list(range(lev.n))
+    assert bool((empty[-4:] == 7).all())
