@@ -21,11 +21,28 @@ void set_error(const char *fmt, ...) {
 constexpr int kBlock = 256;  // 4 waves
 
 // ------------------------------------------------------------------------------ keys
+__device__ __forceinline__ uint64_t dev_table_capacity(int64_t n) {
+  uint64_t cap = 64;
+  while (cap < (uint64_t)(2 * n)) cap <<= 1;
+  return cap;
+}
+
+// clear_keys / clear_vals (optional): the hash map these keys are about to be inserted into is emptied by the same launch
+// (clear_cap slots, or the capacity for the device-resident row count) -- one launch per level less in the pyramid
 template <int MODE>  // 0 = float field rows, 1 = int32 rows
 __global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restrict__ coords, int64_t n_host,
                                                            const int *__restrict__ n_dev, int out_ts,
-                                                           uint64_t *__restrict__ keys, uint32_t *status) {
+                                                           uint64_t *__restrict__ keys, uint32_t *status,
+                                                           unsigned long long *__restrict__ clear_keys = nullptr,
+                                                           int *__restrict__ clear_vals = nullptr, uint64_t clear_cap = 0) {
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;  // device-resident row count (level chains)
+  if (clear_keys) {
+    const uint64_t cap = n_dev ? dev_table_capacity(n) : clear_cap;
+    for (uint64_t s = (uint64_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (uint64_t)gridDim.x * kBlock) {
+      clear_keys[s] = kEmptyKey;
+      clear_vals[s] = 0x7F7F7F7F;
+    }
+  }
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   int b, x, y, z;
@@ -50,20 +67,6 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restric
 // the device, and so is the capacity of the next level's map -- sized for the rows it really receives, not for the
 // field's row count (a 2 M-slot table per level for 173 k / 37 k / 8 k ... rows cost 125 MB of clearing per batch and
 // scattered the few keys over 25 MB each).
-__device__ __forceinline__ uint64_t dev_table_capacity(int64_t n) {
-  uint64_t cap = 64;
-  while (cap < (uint64_t)(2 * n)) cap <<= 1;
-  return cap;
-}
-
-__global__ __launch_bounds__(kBlock) void clear_table_kernel(unsigned long long *__restrict__ tkeys, int *__restrict__ tvals,
-                                                             const int *__restrict__ n_dev) {
-  const uint64_t cap = dev_table_capacity(*n_dev);
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * kBlock) {
-    tkeys[i] = kEmptyKey;
-    tvals[i] = 0x7F7F7F7F;
-  }
-}
 
 __global__ __launch_bounds__(kBlock) void insert_kernel(const uint64_t *__restrict__ keys, int64_t n_host,
                                                         const int *__restrict__ n_dev, unsigned long long *tkeys,
@@ -872,18 +875,15 @@ int mink_coords_build_levels(const void *coords, int mode, int64_t n, int32_t nl
                  "build_levels: NULL level buffer");
     const void *src = l == 0 ? coords : (const void *)out_coords[l - 1];
     const int *n_dev = l == 0 ? nullptr : meta + (l - 1);
+    // (the level's hash map is emptied by the same launch: level 0 all `cap` slots, the others only the
+    //  mink_table_capacity(n_{l-1}) slots they use -- the row count is on the device)
     if (l == 0 && mode == 0)
-      make_keys_kernel<0><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status);
+      make_keys_kernel<0><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status, (unsigned long long *)table_keys[l],
+                                                  table_vals[l], (uint64_t)cap);
     else
-      make_keys_kernel<1><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status);
+      make_keys_kernel<1><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status, (unsigned long long *)table_keys[l],
+                                                  table_vals[l], (uint64_t)cap);
     MINK_CHECK_LAUNCH();
-    if (l == 0) {
-      MINK_HIP(hipMemsetAsync(table_keys[l], 0xFF, cap * sizeof(uint64_t), st));
-      MINK_HIP(hipMemsetAsync(table_vals[l], 0x7F, cap * sizeof(int32_t), st));
-    } else {  // only the mink_table_capacity(n_{l-1}) slots this level uses (row count on the device)
-      clear_table_kernel<<<dim3(512), kBlock, 0, st>>>((unsigned long long *)table_keys[l], table_vals[l], n_dev);
-      MINK_CHECK_LAUNCH();
-    }
     // index_a: first-occurrence rows (optional, kept for level 0), index_b: inverse / in2out
     int rc = unique_launch(keys, n, n_dev, table_keys[l], table_vals[l], cap, out_coords[l],
                            index_a[l], index_b[l], meta + l, uws, st);
