@@ -119,6 +119,9 @@ def cpu_baseline(model_name, cin, num_classes, grid, state_dict, seconds_budget=
     }
 
 
+PMC_CONFIG = "fp32"  # which committed PMC profile `roofline.traffic` may quote: "fp32", "bf16s", None (no profile of this configuration)
+
+
 def pmc_traffic(tag, meta):
     """(HBM bytes per launch of the dominant kernel, {"profile", "git_head_of_profile"}) from the newest committed PMC
     summary (profiles/*_pmc.json, produced by scripts/pmc_summary.py from separate rocprofv3 --pmc passes;
@@ -130,15 +133,18 @@ def pmc_traffic(tag, meta):
     def natural(path):  # r02_v10 after r02_v9
         return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(path))]
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=natural)
-    if not files:
+    # a profile of the configuration that is running: profiles/<tag>_pmc.json for the default (fp32) bench,
+    # profiles/<tag>_bf16s_pmc.json for --math bf16 --storage bf16 (scripts/profile_round.sh with BENCH_ARGS)
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))
+                    if f.endswith("_bf16s_pmc.json") == (PMC_CONFIG == "bf16s")), key=natural)
+    if not files or PMC_CONFIG is None:
         return None, None
     source = {"profile": os.path.basename(files[-1]), "git_head_of_profile": "unknown"}
     meta_file = files[-1].replace(".json", ".meta.json")
     if os.path.exists(meta_file):
         source["git_head_of_profile"] = json.load(open(meta_file)).get("git_head", "unknown")
     stem_wgrad = tag.startswith("wgrad") and meta["cin"] <= 32 and meta["K"] == 27
-    want = "wgrad_stream_kernel" if stem_wgrad else "wgrad_kernel" if tag.startswith("wgrad") else "gather_gemm2_kernel"
+    want = "wgrad_stream" if stem_wgrad else "wgrad_kernel" if tag.startswith("wgrad") else "gather_gemm2_kernel"
     best = None
     for e in json.load(open(files[-1])):
         if want in e["kernel"] and "hbm_traffic_bytes_per_launch" in e:
@@ -287,6 +293,8 @@ def main():
     if args.storage == "bf16" and args.math != "bf16":
         raise SystemExit("--storage bf16 needs --math bf16")
     Fn.set_conv_storage(args.storage)
+    global PMC_CONFIG
+    PMC_CONFIG = "bf16s" if args.storage == "bf16" else "fp32" if (args.math == "fp32" and args.model == "ResNet14" and args.batch == 16) else None
     if os.environ.get("BENCH_COMPUTE_STREAM", "0") != "0":
         # compute on a stream of its own instead of the legacy default stream: a CU-subset stream
         # (hipExtStreamCreateWithCUMask has no non-blocking flag) synchronises implicitly with the default stream
