@@ -357,16 +357,24 @@ __global__ __launch_bounds__(kBlock) void blk_fill_kernel(BlkBuildBatch b) {
   if ((int64_t)blockIdx.x * kBlock >= e.n) return;
   blk_fill_body(e.coords, e.n, e.ts, e.table, e.slot, e.base, e.rowids);
 }
-// 0xFF fill of up to sixteen buffers (sizes multiples of 16 bytes) in one launch: blockIdx.y = buffer
+// 0xFF fill of up to sixteen int32 buffers in one launch (blockIdx.y = buffer): 16-byte stores over the aligned body, single
+// words before and behind it (a hipMemsetAsync per buffer is one launch each, two when the size is not a multiple of 16)
 struct FillBatch {
-  uint4 *ptr[16];
-  int64_t n16[16];
+  unsigned *ptr[16];
+  int64_t nwords[16];
 };
 __global__ __launch_bounds__(kBlock) void fill_ff_kernel(FillBatch f) {
-  uint4 *p = f.ptr[blockIdx.y];
-  const int64_t n = f.n16[blockIdx.y];
+  unsigned *p = f.ptr[blockIdx.y];
+  const int64_t n = f.nwords[blockIdx.y];
+  const int64_t head = min(n, (int64_t)(((16u - (unsigned)((uintptr_t)p & 15u)) & 15u) >> 2));
+  const int64_t n16 = (n - head) >> 2, tail0 = head + 4 * n16;
+  uint4 *body = reinterpret_cast<uint4 *>(p + head);
   const uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) p[i] = v;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (int64_t)gridDim.x * kBlock) body[i] = v;
+  if (blockIdx.x == 0) {
+    if ((int64_t)threadIdx.x < head) p[threadIdx.x] = 0xFFFFFFFFu;
+    if (tail0 + (int64_t)threadIdx.x < n) p[tail0 + threadIdx.x] = 0xFFFFFFFFu;
+  }
 }
 
 // Same result as kernel_map_kernel, through the block index.  Thread per (output row, offset): the 27 look-ups of a
@@ -924,7 +932,7 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
   int64_t fill_max = 0;
   auto flush_fills = [&]() -> int {
     if (n_fill == 0) return MINK_OK;
-    const int64_t blocks = std::min<int64_t>(cdiv(fill_max, kBlock), 2048);
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(cdiv(fill_max, kBlock), 2048));
     fill_ff_kernel<<<dim3((unsigned)blocks, (unsigned)n_fill), kBlock, 0, st>>>(fills);
     MINK_CHECK_LAUNCH();
     n_fill = 0, fill_max = 0;
@@ -932,11 +940,11 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
   };
   auto add_fill = [&](void *ptr, int64_t bytes) -> int {
     if (bytes <= 0) return MINK_OK;
-    if (((uintptr_t)ptr & 15) || (bytes & 15)) {  // (not a run of 16-byte words: the runtime's fill)
+    if (((uintptr_t)ptr & 3) || (bytes & 3)) {  // (not a run of 32-bit words: the runtime's fill)
       MINK_HIP(hipMemsetAsync(ptr, 0xFF, (size_t)bytes, st));
       return MINK_OK;
     }
-    fills.ptr[n_fill] = (uint4 *)ptr, fills.n16[n_fill] = bytes >> 4;
+    fills.ptr[n_fill] = (unsigned *)ptr, fills.nwords[n_fill] = bytes >> 2;
     fill_max = std::max(fill_max, bytes >> 4);
     if (++n_fill == 16) return flush_fills();
     return MINK_OK;
@@ -1147,8 +1155,7 @@ int mink_class_partition_batch(int32_t n_maps, const MinkClassPartitionDesc *d, 
                  "class_partition_batch: workspace of %lld bytes, %lld needed", (long long)e.workspace_bytes,
                  (long long)mink_class_partition_workspace_bytes(e.n));
     const int64_t bytes = (int64_t)sizeof(int32_t) * mink_class_partition_rows(e.n, e.pad);
-    if (((uintptr_t)e.perm & 15) || (bytes & 15)) MINK_HIP(hipMemsetAsync(e.perm, 0xFF, (size_t)bytes, st));
-    else if (bytes > 0) fills.ptr[nf] = (uint4 *)e.perm, fills.n16[nf] = bytes >> 4, fill_max = std::max(fill_max, bytes >> 4), ++nf;
+    if (bytes > 0) fills.ptr[nf] = (unsigned *)e.perm, fills.nwords[nf] = bytes >> 2, fill_max = std::max(fill_max, bytes >> 4), ++nf;
     if (e.n == 0) continue;
     MINK_REQUIRE(e.coords && e.workspace && ((uintptr_t)e.coords & 15) == 0 && ((uintptr_t)e.workspace & 255) == 0,
                  "class_partition_batch: NULL/misaligned pointer in descriptor %d", i);
@@ -1162,7 +1169,7 @@ int mink_class_partition_batch(int32_t n_maps, const MinkClassPartitionDesc *d, 
     ++nb;
   }
   if (nf) {
-    fill_ff_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv(fill_max, kBlock), 2048), (unsigned)nf), kBlock, 0, st>>>(fills);
+    fill_ff_kernel<<<dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(fill_max, kBlock), 2048)), (unsigned)nf), kBlock, 0, st>>>(fills);
     MINK_CHECK_LAUNCH();
   }
   if (nb == 0) return MINK_OK;
