@@ -271,3 +271,35 @@ def test_class_partition_batch_equals_the_per_map_calls():
         assert torch.equal(a, b), (ts, lev.n)
         assert sorted(b[b >= 0].tolist()) == list(range(lev.n))
     assert bool((empty[-4:] == 7).all())
+
+
+def test_batched_map_construction_beyond_one_batch_equals_table_by_table():
+    """mink_kernel_map_batch issues one launch per kind over up to eight maps; a plan with more (ten block indices, ten 3x3x3
+    tables, nine strided ones with their transposed tables, nine pooling tables) takes the flush-and-continue path.  Every
+    table must equal the one a fresh manager builds alone (single-descriptor calls), bit for bit."""
+    from nerf_downstream_amd import minkowski as ME
+
+    coords, feats = batch_scenes([8, 9], grid=40, cin=4)
+
+    def manager():
+        x = ME.TensorField(coordinates=coords.cuda(), features=feats.cuda()).sparse()
+        m = x.coordinate_manager
+        ts = 1
+        for _ in range(9):
+            m.stride(ME.CoordinateMapKey(ts), 2)
+            ts *= 2
+        return m
+
+    tss = [2 ** i for i in range(10)]
+    ops = [("ktable", t, t, 3, 1, False) for t in tss] + [("ktable", t, 2 * t, 3, 1, True) for t in tss[:-1]] + \
+          [("ktable", t, 2 * t, 2, 1, False) for t in tss[:-1]]
+    batched = manager()
+    batched._build_tables_batched(ops)
+    single = manager()
+    for _, ti, to, ks, dil, tr in ops:
+        a = batched.tables[(ti, to, ks, dil)]
+        b = single.kernel_table(ME.CoordinateMapKey(ti), ME.CoordinateMapKey(to), ks, dil, transposed=tr)
+        assert torch.equal(a[0], b[0]), (ti, to, ks)
+        assert int((a[0] >= 0).sum()) > 0
+        if tr:
+            assert torch.equal(a[1], b[1]), (ti, to, ks, "transposed")
