@@ -225,6 +225,7 @@ int mink_conv_set_stagger(int units);
  *   "bf16 mixed precision"), 3 = split-bf16 (hi/lo, three products; ~1e-5 relative).
  * HBM tensors stay fp32 in every mode.  Returns the previous mode. */
 int mink_conv_set_math(int mode);
+int mink_conv_get_math(void); /* the current mode, unchanged */
 /* Split-K factor the library recommends for a layer (1 for large row counts).  row_classes != 0:
  * the launch will pass a class-partitioned row_perm (stride-2 dgrad), n_out = its n_virtual. */
 int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_classes);

@@ -97,6 +97,7 @@ SIGNATURES = {
         [_p, _i32, _p, _i64, _i32, _i64, _p, _i32, _p, _p, ctypes.c_uint64, _p, _p, _p, _i64, _p, _p, _i64, _p],
     ),
     "mink_conv_set_stagger": (ctypes.c_int, [ctypes.c_int]),
+    "mink_conv_get_math": (ctypes.c_int, []),
     "mink_conv_set_math": (ctypes.c_int, [ctypes.c_int]),
     "mink_conv_plan_ksplit": (ctypes.c_int, [_i64, _i32, _i32, _i32]),
     "mink_conv_plan": (ctypes.c_int, [_i64, _i32, _i32, _i32, _i32]),

@@ -2152,6 +2152,8 @@ int64_t mink_conv_timing_fetch(MinkTimingEntry *out, int64_t max) {
   return n;
 }
 
+int mink_conv_get_math(void) { return g_math; }
+
 int mink_conv_set_math(int mode) {
   const int old = g_math;
   if (mode == 0 || mode == 1 || mode == 3) g_math = mode;

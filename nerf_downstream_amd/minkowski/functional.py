@@ -88,10 +88,7 @@ def rows_to_bf16(x):
 
 def conv_math():
     """The current mode name of set_conv_math (read without changing it)."""
-    L = lib()
-    old = L.mink_conv_set_math(0)
-    L.mink_conv_set_math(old)
-    return {0: "fp32", 1: "bf16", 3: "bf16x3"}[old]
+    return {0: "fp32", 1: "bf16", 3: "bf16x3"}[lib().mink_conv_get_math()]
 
 
 # ---------------------------------------------------------------------- kernel timing
