@@ -377,6 +377,7 @@ def compute_streams(device):
 
 
 _BRANCH_FORK = True
+_TRUNK_BRANCH_ON_SIDE = False  # data parallelism: the native trunk runs its shortcut branch on the weight-gradient stream
 
 
 def set_branch_fork(on=True):
@@ -388,6 +389,14 @@ def set_branch_fork(on=True):
 
 def branch_fork_enabled():
     return _BRANCH_FORK
+
+
+def set_trunk_branch_on_side(on=True):
+    """The native trunk's shortcut branch on the weight-gradient stream instead of a stream of its own (data parallelism:
+    the process group's streams already take hardware queues; the module-by-module path then does not fork at all)."""
+    global _TRUNK_BRANCH_ON_SIDE
+    old, _TRUNK_BRANCH_ON_SIDE = _TRUNK_BRANCH_ON_SIDE, bool(on)
+    return old
 
 
 def branch_stream(device, home=None):

@@ -163,6 +163,11 @@ def _table(m, ts_in, ts_out, ks, transposed=False):
     return m.kernel_table(CoordinateMapKey(ts_in), CoordinateMapKey(ts_out), ks, 1, transposed=transposed)
 
 
+def _branch(dev, cur):
+    """The stream of the shortcut branch: its own, or (data parallelism) the weight-gradient stream."""
+    return Fn._side_stream(dev) if Fn._TRUNK_BRANCH_ON_SIDE else Fn.branch_stream(dev, home=cur)
+
+
 def _exec(plan, cur, br, side, nbytes, device):
     ws_c = Fn._scratch(nbytes, device, "trunk")
     ws_b = Fn._scratch(nbytes, device, "trunk", br) if br != cur else ws_c
@@ -212,7 +217,7 @@ class TrunkFunction(torch.autograd.Function):
         i2o = m.in2out[(1, 2)] if m.prepared else m.stride_map(CoordinateMapKey(1), CoordinateMapKey(2))
         n0, n1 = x.shape[0], nbr_pool.shape[0]
         cur = torch.cuda.current_stream(dev)
-        br = Fn.branch_stream(dev, home=cur) if (fork and m.prepared) else cur
+        br = _branch(dev, cur) if (fork and m.prepared) else cur
         # rows per stage and the scratch the largest stage needs
         need, n_in, ts = _ws_need(L, n0, n0, cin, C0)[0], n1, 2
         shapes = []
@@ -301,7 +306,7 @@ class TrunkFunction(torch.autograd.Function):
                     break
             overlap = overlap and not torch.is_grad_enabled()
         cur = torch.cuda.current_stream(dev)
-        br = Fn.branch_stream(dev, home=cur) if (ctx.fork and m.prepared) else cur
+        br = _branch(dev, cur) if (ctx.fork and m.prepared) else cur
         side = Fn._side_stream(dev) if overlap else cur
         C0 = w0p.shape[-1]
         n0 = x.shape[0]

@@ -103,10 +103,13 @@ class BucketedGradAllReduce:
                     Fn.set_wgrad_overlap(False)
                     Fn.set_branch_fork(False)
                 else:
-                    # the shortcut-branch stream stays off under data parallelism: with the process group's streams
-                    # in the picture it gains nothing (4.85 ms/step either way with six hardware queues) and, given
-                    # eight or more queues, costs a factor (8.3 ms; scripts/hostprof_dp.py)
+                    # a shortcut-branch stream of its own stays off under data parallelism: with the process group's
+                    # streams in the picture it gains nothing at six or seven hardware queues and costs a factor at
+                    # eight (5.8 ms/step; DESIGN Appendix A).  The native trunk runs the branch on the weight-gradient
+                    # stream instead, which is idle in forward and has room in backward: 4.00 -> 3.88 ms with a one-rank
+                    # RCCL group (3.82 without the data-parallel machinery)
                     Fn.set_branch_fork(False)
+                    Fn.set_trunk_branch_on_side(True)
                     # convolution weight gradients are written straight into the flat buffer by the
                     # weight-gradient stream (no per-layer accumulate + join on the compute stream), batch-norm
                     # scale / shift gradients by their backward kernel (no accumulate launch per parameter)

@@ -113,11 +113,14 @@ def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink):
         labels.append(torch.tensor([j, 1 + j, 2 + j], device=dev))
     out = {}
     try:
-        for mode, (multi, lazy_fork) in {"single": (False, False), "multi": (True, False), "multi-lazy": (True, True)}.items():
+        # "multi-side": the data-parallel schedule of the native trunk -- the shortcut branch on the weight-gradient stream
+        for mode, (multi, lazy_fork) in {"single": (False, False), "multi": (True, False), "multi-lazy": (True, True),
+                                          "multi-side": (True, False)}.items():
             torch.manual_seed(5)
             m = get_model("ResNet14", 28, 5).to(dev)
             reducer = BucketedGradAllReduce(m) if sink else None
             _schedule(m, multi, lazy_fork)
+            Fn.set_trunk_branch_on_side(mode == "multi-side")
             native = trunk_node(m(m.process_input(batches[0]))) is not None
             assert native == (grid >= 64), (grid, native)
             out[mode] = _train_steps(m, batches, labels, 5, reducer)
@@ -126,9 +129,11 @@ def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink):
         Fn._SKEW = 0
         Fn.set_wgrad_overlap(True)
         Fn.set_grad_sink(None)
+        Fn.set_trunk_branch_on_side(False)
     assert torch.isfinite(out["multi"]).all()
     assert torch.equal(out["single"], out["multi"])
     assert torch.equal(out["single"], out["multi-lazy"])
+    assert torch.equal(out["single"], out["multi-side"])
 
 
 def _free_port():
