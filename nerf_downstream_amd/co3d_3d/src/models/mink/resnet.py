@@ -103,7 +103,7 @@ class ResNetBase(MinkowskiBaseModel):
                 self._trunk_plan = trunk.plan_for(self) or False
             xs = x.sparse()
             if self._trunk_plan and trunk.usable(self, self._trunk_plan, xs):
-                fork = getattr(self.layer1[0], "_fork", False) and (trunk.Fn.branch_fork_enabled() or trunk.Fn._TRUNK_BRANCH_ON_SIDE)
+                fork = getattr(self.layer1[0], "_fork", False) and trunk.Fn.trunk_branch_mode() is not None
                 feats = trunk.TrunkFunction.apply(xs.F, self._trunk_plan, xs.coordinate_manager, fork, *self._trunk_plan.params)
                 out = self._ME.SparseTensor(feats, trunk.out_key_of(self._trunk_plan), xs.coordinate_manager)
                 return self._head(out)

@@ -391,6 +391,17 @@ def branch_fork_enabled():
     return _BRANCH_FORK
 
 
+def trunk_branch_mode():
+    """Where the native trunk runs the shortcut branch of its residual blocks: "own" (a stream of its own), "side" (the
+    weight-gradient stream: data parallelism with fp32 matrix math, where that stream has room -- under bf16 math its
+    fp32 weight gradients are the long pole and the branch behind them stalls the chain: 2.64 -> 2.69 ms) or None."""
+    if _BRANCH_FORK:
+        return "own"
+    if _TRUNK_BRANCH_ON_SIDE and conv_math() != "bf16":
+        return "side"
+    return None
+
+
 def set_trunk_branch_on_side(on=True):
     """The native trunk's shortcut branch on the weight-gradient stream instead of a stream of its own (data parallelism:
     the process group's streams already take hardware queues; the module-by-module path then does not fork at all)."""

@@ -165,7 +165,7 @@ def _table(m, ts_in, ts_out, ks, transposed=False):
 
 def _branch(dev, cur):
     """The stream of the shortcut branch: its own, or (data parallelism) the weight-gradient stream."""
-    return Fn._side_stream(dev) if Fn._TRUNK_BRANCH_ON_SIDE else Fn.branch_stream(dev, home=cur)
+    return Fn._side_stream(dev) if Fn.trunk_branch_mode() == "side" else Fn.branch_stream(dev, home=cur)
 
 
 def _exec(plan, cur, br, side, nbytes, device):

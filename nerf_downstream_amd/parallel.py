@@ -107,7 +107,7 @@ class BucketedGradAllReduce:
                     # streams in the picture it gains nothing at six or seven hardware queues and costs a factor at
                     # eight (5.8 ms/step; DESIGN Appendix A).  The native trunk runs the branch on the weight-gradient
                     # stream instead, which is idle in forward and has room in backward: 4.00 -> 3.88 ms with a one-rank
-                    # RCCL group (3.82 without the data-parallel machinery)
+                    # RCCL group (3.82 without the data-parallel machinery); fp32 math only (Fn.trunk_branch_mode)
                     Fn.set_branch_fork(False)
                     Fn.set_trunk_branch_on_side(True)
                     # convolution weight gradients are written straight into the flat buffer by the

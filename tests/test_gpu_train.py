@@ -121,6 +121,9 @@ def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink):
             reducer = BucketedGradAllReduce(m) if sink else None
             _schedule(m, multi, lazy_fork)
             Fn.set_trunk_branch_on_side(mode == "multi-side")
+            if mode == "multi-side":
+                Fn.set_branch_fork(False)  # (as a data-parallel reducer leaves it)
+                assert Fn.trunk_branch_mode() == "side"
             native = trunk_node(m(m.process_input(batches[0]))) is not None
             assert native == (grid >= 64), (grid, native)
             out[mode] = _train_steps(m, batches, labels, 5, reducer)
@@ -130,6 +133,7 @@ def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink):
         Fn.set_wgrad_overlap(True)
         Fn.set_grad_sink(None)
         Fn.set_trunk_branch_on_side(False)
+        Fn.set_branch_fork(True)
     assert torch.isfinite(out["multi"]).all()
     assert torch.equal(out["single"], out["multi"])
     assert torch.equal(out["single"], out["multi-lazy"])
