@@ -30,11 +30,10 @@ __device__ __forceinline__ uint64_t dev_table_capacity(int64_t n) {
 // clear_keys / clear_vals (optional): the hash map these keys are about to be inserted into is emptied by the same launch
 // (clear_cap slots, or the capacity for the device-resident row count) -- one launch per level less in the pyramid
 template <int MODE>  // 0 = float field rows, 1 = int32 rows
-__global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restrict__ coords, int64_t n_host,
-                                                           const int *__restrict__ n_dev, int out_ts,
-                                                           uint64_t *__restrict__ keys, uint32_t *status,
-                                                           unsigned long long *__restrict__ clear_keys = nullptr,
-                                                           int *__restrict__ clear_vals = nullptr, uint64_t clear_cap = 0) {
+__device__ __forceinline__ void make_keys_body(const void *__restrict__ coords, int64_t n_host, const int *__restrict__ n_dev,
+                                               int out_ts, uint64_t *__restrict__ keys, uint32_t *status,
+                                               unsigned long long *__restrict__ clear_keys, int *__restrict__ clear_vals,
+                                               uint64_t clear_cap) {
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;  // device-resident row count (level chains)
   if (clear_keys) {
     const uint64_t cap = n_dev ? dev_table_capacity(n) : clear_cap;
@@ -60,6 +59,14 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restric
     key = 0;  // keep the pipeline well-defined; the host raises on the status word
   }
   keys[i] = key;
+}
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restrict__ coords, int64_t n_host,
+                                                           const int *__restrict__ n_dev, int out_ts,
+                                                           uint64_t *__restrict__ keys, uint32_t *status,
+                                                           unsigned long long *__restrict__ clear_keys = nullptr,
+                                                           int *__restrict__ clear_vals = nullptr, uint64_t clear_cap = 0) {
+  make_keys_body<MODE>(coords, n_host, n_dev, out_ts, keys, status, clear_keys, clear_vals, clear_cap);
 }
 
 // ---------------------------------------------------------------------------- unique
@@ -194,6 +201,29 @@ __global__ __launch_bounds__(kBlock) void inverse_kernel(const int *__restrict__
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) inverse[i] = tvals[slot_of_row[i]];
+}
+
+// Level chains: the inverse map of level l and the keys of level l + 1 (made from level l's unique rows, with level l + 1's
+// hash map emptied on the way) are independent row-parallel passes behind the same launch (assign of level l): one kernel.
+// The last level's call carries the batch count instead (last_out).
+__global__ __launch_bounds__(kBlock) void inverse_next_keys_kernel(const int *__restrict__ tvals, const int *__restrict__ slot_of_row,
+                                                                   int64_t n_host, const int *__restrict__ n_dev,
+                                                                   int *__restrict__ inverse, const void *__restrict__ next_coords,
+                                                                   const int *__restrict__ next_n, int next_ts,
+                                                                   uint64_t *__restrict__ keys, uint32_t *status,
+                                                                   unsigned long long *__restrict__ next_tkeys,
+                                                                   int *__restrict__ next_tvals, const int *__restrict__ coords0,
+                                                                   const int *__restrict__ n0, int *last_out) {
+  {
+    const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) inverse[i] = tvals[slot_of_row[i]];
+  }
+  if (last_out && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int n = *n0;
+    *last_out = n > 0 ? coords0[4 * (n - 1)] + 1 : 0;  // batch column is non-decreasing (checked by batch_offsets)
+  }
+  if (next_coords) make_keys_body<1>(next_coords, n_host, next_n, next_ts, keys, status, next_tkeys, next_tvals, 0);
 }
 
 __global__ void last_batch_kernel(const int *__restrict__ coords0, const int *__restrict__ n0, int *out) {
@@ -786,7 +816,7 @@ static int64_t unique_nblocks(int64_t n) { return cdiv(n > 0 ? n : 1, kBlock); }
 // enqueue the five kernels of insert_and_map; n_dev (optional) holds the row count on the device
 static int unique_launch(const uint64_t *keys, int64_t n, const int *n_dev, uint64_t *table_keys, int32_t *table_vals,
                          int64_t cap, int32_t *out_coords, int32_t *unique_index, int32_t *inverse, int32_t *n_unique,
-                         void *workspace, hipStream_t st) {
+                         void *workspace, hipStream_t st, bool skip_inverse = false) {
   const int64_t nb = unique_nblocks(n);
   char *ws = (char *)workspace;
   int *slot_of_row = (int *)ws;
@@ -807,6 +837,7 @@ static int unique_launch(const uint64_t *keys, int64_t n, const int *n_dev, uint
   assign_kernel<<<grid, kBlock, 0, st>>>(keys, flags, slot_of_row, block_offsets, n, n_dev, table_vals, out_coords,
                                          unique_index);
   MINK_CHECK_LAUNCH();
+  if (skip_inverse) return MINK_OK;  // (the caller fuses it with the next level's first pass)
   inverse_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, n_dev, inverse);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
@@ -878,28 +909,35 @@ int mink_coords_build_levels(const void *coords, int mode, int64_t n, int32_t nl
   uint32_t *status = (uint32_t *)(meta + nlev);
   MINK_HIP(hipMemsetAsync(meta, 0, sizeof(int32_t) * (nlev + 2), st));
   const dim3 grid((unsigned)cdiv(n, kBlock));
+  const int *slot_of_row = (const int *)uws;  // (first region of the unique workspace: unique_launch)
   for (int l = 0; l < nlev; ++l) {
     MINK_REQUIRE(table_keys[l] && table_vals[l] && out_coords[l] && index_b[l] && (l > 0 || index_a[0]),
                  "build_levels: NULL level buffer");
     const void *src = l == 0 ? coords : (const void *)out_coords[l - 1];
     const int *n_dev = l == 0 ? nullptr : meta + (l - 1);
-    // (the level's hash map is emptied by the same launch: level 0 all `cap` slots, the others only the
-    //  mink_table_capacity(n_{l-1}) slots they use -- the row count is on the device)
-    if (l == 0 && mode == 0)
-      make_keys_kernel<0><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status, (unsigned long long *)table_keys[l],
-                                                  table_vals[l], (uint64_t)cap);
-    else
-      make_keys_kernel<1><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status, (unsigned long long *)table_keys[l],
-                                                  table_vals[l], (uint64_t)cap);
-    MINK_CHECK_LAUNCH();
+    if (l == 0) {
+      // (the level's hash map is emptied by the same launch; levels > 0: by the fused pass at the end of the previous level)
+      if (mode == 0)
+        make_keys_kernel<0><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status, (unsigned long long *)table_keys[l],
+                                                    table_vals[l], (uint64_t)cap);
+      else
+        make_keys_kernel<1><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status, (unsigned long long *)table_keys[l],
+                                                    table_vals[l], (uint64_t)cap);
+      MINK_CHECK_LAUNCH();
+    }
     // index_a: first-occurrence rows (optional, kept for level 0), index_b: inverse / in2out
     int rc = unique_launch(keys, n, n_dev, table_keys[l], table_vals[l], cap, out_coords[l],
-                           index_a[l], index_b[l], meta + l, uws, st);
+                           index_a[l], index_b[l], meta + l, uws, st, true);
     if (rc) return rc;
+    // inverse of this level + keys (and emptied hash map) of the next; the last level: + batch count
+    // (meta[nlev] = status word, meta[nlev+1] = batch index of the last input row + 1)
+    const bool last = l + 1 == nlev;
+    inverse_next_keys_kernel<<<grid, kBlock, 0, st>>>(
+        table_vals[l], slot_of_row, n, n_dev, index_b[l], last ? nullptr : (const void *)out_coords[l], last ? nullptr : meta + l,
+        last ? 1 : out_ts_host[l + 1], keys, status, last ? nullptr : (unsigned long long *)table_keys[l + 1],
+        last ? nullptr : table_vals[l + 1], (const int *)out_coords[0], meta, last ? meta + nlev + 1 : nullptr);
+    MINK_CHECK_LAUNCH();
   }
-  // meta[nlev] = status word, meta[nlev+1] = batch index of the last input row + 1
-  last_batch_kernel<<<1, 1, 0, st>>>((const int *)out_coords[0], meta, meta + nlev + 1);
-  MINK_CHECK_LAUNCH();
   return MINK_OK;
 }
 
