@@ -484,6 +484,12 @@ def main():
                 torch.cuda.synchronize()
                 fwd_ms = (time.perf_counter() - t1) / fwd_steps * 1e3
             fwd_bytes = sum(r["algorithmic_mb"] for r in layer_table if r["op"].startswith("fwd")) * 1e6
+            stem_w = [r for r in layer_table if r["op"].startswith("wgrad") and r["cin"] <= 32 and r["op"].split("x")[1].startswith("27")]
+            if args.storage == "bf16" and stem_w and not any(r["op"].startswith("fwd") and r["cin"] <= 32 for r in layer_table):
+                # the bf16-storage stem forward (stem16.hip) is not one of the instrumented gather-GEMM calls: its algorithmic
+                # bytes with 2-byte rows in and out (SURVEY 8d with the storage type: x, y, fp32 weights, table)
+                r = stem_w[0]
+                fwd_bytes += 2.0 * (r["n_in"] * r["cin"] + r["n_out"] * r["cout"]) + 4.0 * 27 * r["cin"] * r["cout"] + 8.0 * r["pairs"]
             res.setdefault("roofline", {})["forward_only"] = {
                 "voxels_per_s": vox_per_step[0] / (fwd_ms * 1e-3), "ms": fwd_ms,
                 "conv_algorithmic_bytes": fwd_bytes,
