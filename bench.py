@@ -220,8 +220,10 @@ def main():
     ap.add_argument("--num-classes", type=int, default=51)
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16", "bf16x3"],
                     help="matrix-core arithmetic of conv forward/dgrad (fp32 = exact, the headline; bf16 = BASELINE config #3)")
-    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
-                    help="HBM storage of the full-resolution stage (input features, stem output) under --math bf16")
+    ap.add_argument("--storage", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="HBM storage of the full-resolution stage (input features, stem output): bf16 needs --math bf16 and is "
+                    "what 'auto' picks there (mixed precision = bf16 matrix operands AND bf16 activations where they are large); "
+                    "fp32 everywhere else")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only (CPU test): rendezvous over gloo, one all-reduce, print ranks_seen; no compute, no number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -294,6 +296,8 @@ def main():
 
     _lib.lib()  # fail loudly if the HIP backend is missing
     Fn.set_conv_math(args.math)
+    if args.storage == "auto":
+        args.storage = "bf16" if args.math == "bf16" else "fp32"
     if args.storage == "bf16" and args.math != "bf16":
         raise SystemExit("--storage bf16 needs --math bf16")
     Fn.set_conv_storage(args.storage)
@@ -453,9 +457,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 (MFMA operands of forward, data gradient and the stem weight gradient; fp32 accumulate and storage, mid-layer wgrad fp32)",
-                      "bf16x3": "f32 via split-bf16 MFMA (3 products)"}[args.math]
-            + (" -- bf16 STORAGE of the input features and the stem output" if args.storage == "bf16" else ""),
+            "dtype": {"fp32": "f32",
+                      "bf16": "bf16 (MFMA operands of forward, data gradient and the stem weight gradient; fp32 accumulate; "
+                      + ("bf16 storage of the input features and the stem output, fp32 storage below" if args.storage == "bf16" else "fp32 storage")
+                      + "; mid-layer weight gradients fp32)",
+                      "bf16x3": "f32 via split-bf16 MFMA (3 products)"}[args.math],
             "data": "synthetic",
             "config": {
                 "workload": f"Mink-{args.model} full CO3D-category classification ({args.num_classes} classes), "
