@@ -92,12 +92,14 @@ def _train_steps(model, batches, labels, steps, reducer=None):
     return torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
 
 
-@pytest.mark.parametrize("grid,sink", [(32, False), (64, False), (64, True)])
-def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink):
+@pytest.mark.parametrize("grid,sink,math", [(32, False, "fp32"), (64, False, "fp32"), (64, True, "fp32"), (64, True, "bf16s")])
+def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink, math):
     """Five training steps with every stream overlap on and the auxiliary streams skewed ==
     the same five steps on a single stream, bit for bit (all kernels are deterministic).  32^3 scenes take the
     module-by-module path, 64^3 scenes (~63 k voxels per batch) the native trunk -- asserted; `sink`: the flat gradient
-    buffer of a one-rank reducer as the gradient sink of the backward kernels, which is how bench.py and train.py run."""
+    buffer of a one-rank reducer as the gradient sink of the backward kernels, which is how bench.py and train.py run;
+    "bf16s": bf16 matrix math with bf16 storage of the full-resolution stage, whose bf16 copy of the input rows is made
+    AHEAD on the (skewed) prepare stream."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import batch_scenes, trunk_node
 
@@ -112,6 +114,9 @@ def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink):
         batches.append({"coordinates": coords.to(dev), "features": feats.to(dev)})
         labels.append(torch.tensor([j, 1 + j, 2 + j], device=dev))
     out = {}
+    from nerf_downstream_amd import minkowski as ME
+
+    old_math, old_storage = ME.set_conv_math("bf16" if math == "bf16s" else math), ME.set_conv_storage("bf16" if math == "bf16s" else "fp32")
     try:
         # "multi-side": the data-parallel schedule of the native trunk -- the shortcut branch on the weight-gradient stream
         for mode, (multi, lazy_fork) in {"single": (False, False), "multi": (True, False), "multi-lazy": (True, True),
@@ -123,9 +128,12 @@ def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink):
             Fn.set_trunk_branch_on_side(mode == "multi-side")
             if mode == "multi-side":
                 Fn.set_branch_fork(False)  # (as a data-parallel reducer leaves it)
-                assert Fn.trunk_branch_mode() == "side"
-            native = trunk_node(m(m.process_input(batches[0]))) is not None
+                assert Fn.trunk_branch_mode() == ("side" if math == "fp32" else None)  # (bf16 math: no branch at all under data parallelism)
+            node = trunk_node(m(m.process_input(batches[0])))
+            native = node is not None
             assert native == (grid >= 64), (grid, native)
+            if math == "bf16s":
+                assert node.saved[0][7] is True  # bf16 storage taken
             out[mode] = _train_steps(m, batches, labels, 5, reducer)
             Fn.set_grad_sink(None)
     finally:
@@ -134,6 +142,7 @@ def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink):
         Fn.set_grad_sink(None)
         Fn.set_trunk_branch_on_side(False)
         Fn.set_branch_fork(True)
+        ME.set_conv_math(old_math), ME.set_conv_storage(old_storage)
     assert torch.isfinite(out["multi"]).all()
     assert torch.equal(out["single"], out["multi"])
     assert torch.equal(out["single"], out["multi-lazy"])
