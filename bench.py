@@ -36,6 +36,9 @@ elif int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BENCH_FORCE_R
     # streams on one queue serialise (measured with a one-rank group: 5.5 ms/step against 4.85 with a queue for each).
     # The HIP runtime reads it when it is loaded -- before `import torch`.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # (this pool's host driver only supports dmabuf IPC: without it RCCL fails in hipIpcGetMemHandle; already exported on the
+    #  boxes -- kept here for an environment that lost it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -193,6 +193,7 @@ def train(
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on hosts without the legacy path)
         dist.init_process_group("nccl" if device.type == "cuda" else "gloo")
     os.makedirs(save_path, exist_ok=True)
 
