@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -74,3 +76,29 @@ def test_undersized_workspace_is_refused_before_any_launch():
     assert L.mink_bn_stats(P, 1000, 64, 1e-5, 0.1, P, P, None, None, P, 16, None) == -1
     assert L.mink_class_partition(P, 1000, 2, 128, P, P, 8, None) == -1
     assert b"workspace" in L.mink_last_error()
+
+
+def test_trunk_branch_policy():
+    """Where the native trunk runs its shortcut branch (minkowski/functional.py: trunk_branch_mode): a stream of its own by
+    default; under a data-parallel reducer (fork off, branch-on-side on) the weight-gradient stream with fp32 / split-bf16
+    math and no branch at all with bf16 math.  Host logic only: the math mode is read through the C ABI, no kernel runs."""
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    old_fork, old_side, old_math = Fn.set_branch_fork(True), Fn.set_trunk_branch_on_side(False), Fn.set_conv_math("fp32")
+    try:
+        assert Fn.conv_math() == "fp32" and Fn.trunk_branch_mode() == "own"
+        Fn.set_branch_fork(False)
+        assert Fn.trunk_branch_mode() is None
+        Fn.set_trunk_branch_on_side(True)
+        assert Fn.trunk_branch_mode() == "side"
+        Fn.set_conv_math("bf16x3")
+        assert Fn.trunk_branch_mode() == "side"
+        Fn.set_conv_math("bf16")
+        assert Fn.conv_math() == "bf16" and Fn.trunk_branch_mode() is None
+        Fn.set_branch_fork(True)
+        assert Fn.trunk_branch_mode() == "own"
+    finally:
+        Fn.set_branch_fork(old_fork), Fn.set_trunk_branch_on_side(old_side), Fn.set_conv_math(old_math)
+    assert Fn.set_conv_storage("bf16") == "fp32" and Fn.set_conv_storage("fp32") == "bf16"
+    with pytest.raises(ValueError):
+        Fn.set_conv_storage("fp16")
