@@ -1,6 +1,6 @@
 #!/bin/bash
 # step time of the other configurations BASELINE.json names (and the shapes a data-parallel run puts on one GPU)
-for args in "--model ResNet34 --batch 4" "--batch 8" "--math bf16" "--math bf16x3" "--model ResNet34" "--batch 32"; do
+for args in "--model ResNet34 --batch 4" "--batch 8" "--math bf16" "--math bf16 --storage fp32" "--math bf16x3" "--model ResNet34" "--batch 32" "--math bf16 --model ResNet34 --batch 4"; do
   python bench.py --steps 30 --warmup 8 --no-cpu-baseline $args 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d.get('roofline', {})
