@@ -222,7 +222,7 @@ def main():
     ap.add_argument("--in-channel", type=int, default=28)
     ap.add_argument("--num-classes", type=int, default=51)
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16", "bf16x3"],
-                    help="matrix-core arithmetic of conv forward/dgrad (fp32 = exact, the headline; bf16 = BASELINE config #3)")
+                    help="matrix-core arithmetic of conv forward/dgrad (fp32 = exact, the headline; bf16 = BASELINE config #4)")
     ap.add_argument("--storage", default="auto", choices=["auto", "fp32", "bf16"],
                     help="HBM storage of the full-resolution stage (input features, stem output): bf16 needs --math bf16 and is "
                     "what 'auto' picks there (mixed precision = bf16 matrix operands AND bf16 activations where they are large); "

@@ -548,6 +548,68 @@ int mink_stem_backward(const MinkStem *s, const MinkExec *ex);
 int mink_block_forward(const MinkBasicBlock *b, const MinkExec *ex);
 int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex);
 
+/* ------------------------------------------------------------------ the whole trunk as one call
+ * Stem + every BasicBlock of a Mink-ResNet (the reference's ResNetBase.forward up to layer4:
+ * co3d_3d/src/models/mink/resnet.py:107-161 `_make_layer`, :163-175 `forward`) in ONE host call per direction.
+ * mink_net_forward / mink_net_backward sequence exactly what mink_stem_* and mink_block_* sequence (they call them),
+ * block after block; what they add is the binding of every block to this batch -- rows, neighbour tables, activation
+ * and gradient addresses -- from a handful of per-LEVEL records, so the host's per-step work no longer grows with the
+ * depth of the network (Mink-ResNet34 at four scenes per GPU, BASELINE config #3's per-GPU shape: 3.6 ms of host per
+ * 4.7 ms step with one call per block).
+ *
+ * Levels: level 0 is the stem's output (tensor stride 2), level l + 1 the map a stride-2 block takes level l to.
+ * A block with conv1.stride == 2 goes from its level to the next and must carry a shortcut convolution (kernel
+ * volume 1); a block with stride 1 stays on its level with an identity shortcut.
+ *
+ * The caller fills, once: every block's static fields (w, dw, K, cin, cout, stride of the three convolutions; gamma, beta,
+ * running statistics, dgamma, dbeta, momentum, eps of the three norms) and the stem's; per step: the level records, the
+ * stem's x / nbr / nbr_pool / in2out / n / n_pool / y / out / norm.mean / norm.invstd (the stem's activations stay
+ * caller-owned: their layout depends on the storage type).  The library fills everything else in `blocks`.
+ *
+ * Activation arena (forward writes, backward reads; mink_net_sizes gives the size): per block, 256-byte aligned,
+ * [y1 | h1 | y2 | out | (yd | sd)] [n_out][C] each, then six [C] statistics vectors.  The trunk's output is the last
+ * block's `out` (net->out, net->out_rows).  Gradient arena (backward scratch): per block its mink_block_grad_scratch
+ * floats and the gradient of its input.
+ *
+ * done_events (backward, optional; n_blocks entries from mink_event_create, NULL entries skipped): event i is recorded on
+ * ex->wgrad once EVERY parameter gradient of block i (weights on `wgrad`, batch-norm scale / shift on `compute` /
+ * `branch`) has been queued and ordered before it -- what a data-parallel caller makes a bucket's all-reduce wait for,
+ * instead of for the tail of the streams (the whole backward pass is queued by the time this call returns).
+ *
+ * mink_set_stage_hook: instrumentation (race tests, timelines): called on the host before the stem (stage -1) and before
+ * every block (stage i) of forward (backward = 0) and backward (= 1; there the stem comes last).  NULL = off. */
+typedef struct {
+  int64_t n;               /* rows of this level */
+  const int32_t *nbr3;     /* [n][27] 3^3 stride-1 table of the level onto itself */
+  const int32_t *down3;    /* [n][27] 3^3 stride-2 table from the finer level into this one (NULL at level 0) */
+  const int32_t *down1;    /* [n][1] the shortcut's table (kernel volume 1, stride 2) */
+  const int32_t *down3_t;  /* backward: [n_finer][27] transposed `down3` */
+  const int32_t *perm;     /* backward: parity-class row order of the finer level (mink_class_partition), or NULL */
+  int64_t n_perm;
+} MinkLevelMaps;
+
+typedef struct {
+  MinkStem stem;
+  MinkBasicBlock *blocks;
+  int32_t n_blocks;
+  int32_t with_stem;       /* 0: the caller runs mink_stem_forward / _backward itself (stem.out / stem.n_pool still describe level 0) */
+  float *out;              /* written by mink_net_forward: [out_rows][C of the last block] */
+  int64_t out_rows;
+  const float *g_stem_out; /* written by mink_net_backward: gradient of the stem's output (in the gradient arena) */
+} MinkNet;
+
+typedef void (*MinkStageHook)(int32_t stage, int32_t backward);
+int mink_set_stage_hook(MinkStageHook hook);
+int mink_event_create(void **event_out);
+int mink_event_destroy(void *event);
+int mink_stream_wait_event(void *stream, void *event);
+int mink_net_sizes(const MinkNet *net, const MinkLevelMaps *levels, int32_t n_levels, int64_t *act_floats, int64_t *grad_floats,
+                   int64_t *ws_bytes);
+int mink_net_forward(MinkNet *net, const MinkLevelMaps *levels, int32_t n_levels, float *arena, int64_t arena_floats,
+                     const MinkExec *ex);
+int mink_net_backward(MinkNet *net, const MinkLevelMaps *levels, int32_t n_levels, float *arena, int64_t arena_floats,
+                      const float *g_out, float *grad_arena, int64_t grad_floats, const MinkExec *ex, void *const *done_events);
+
 /* ------------------------------------------------------------------ bf16 storage of the full-resolution stage
  * BASELINE config "bf16 mixed precision", storage form: the network input and the stem convolution's output -- three
  * quarters of the activation bytes of a Mink-ResNet step -- are kept in HBM as bf16; the pooled level and everything

@@ -59,6 +59,22 @@ class BasicBlock(ctypes.Structure):
                 ("yd", _p), ("sd", _p), ("out", _p), ("g_out", _p), ("g_x", _p), ("g_tmp", _p)]
 
 
+class LevelMaps(ctypes.Structure):
+    """MinkLevelMaps"""
+
+    _fields_ = [("n", _i64), ("nbr3", _p), ("down3", _p), ("down1", _p), ("down3_t", _p), ("perm", _p), ("n_perm", _i64)]
+
+
+class Net(ctypes.Structure):
+    """MinkNet"""
+
+    _fields_ = [("stem", Stem), ("blocks", ctypes.POINTER(BasicBlock)), ("n_blocks", _i32), ("with_stem", _i32), ("out", _p),
+                ("out_rows", _i64), ("g_stem_out", _p)]
+
+
+STAGE_HOOK = ctypes.CFUNCTYPE(None, _i32, _i32)  # MinkStageHook
+
+
 class ClassPartitionDesc(ctypes.Structure):
     """MinkClassPartitionDesc"""
 
@@ -161,6 +177,13 @@ SIGNATURES = {
     "mink_stem_backward": (ctypes.c_int, [_p, _p]),
     "mink_block_forward": (ctypes.c_int, [_p, _p]),
     "mink_block_backward": (ctypes.c_int, [_p, _p]),
+    "mink_set_stage_hook": (ctypes.c_int, [_p]),
+    "mink_event_create": (ctypes.c_int, [_p]),
+    "mink_event_destroy": (ctypes.c_int, [_p]),
+    "mink_stream_wait_event": (ctypes.c_int, [_p, _p]),
+    "mink_net_sizes": (ctypes.c_int, [_p, _p, _i32, _p, _p, _p]),
+    "mink_net_forward": (ctypes.c_int, [_p, _p, _i32, _p, _i64, _p]),
+    "mink_net_backward": (ctypes.c_int, [_p, _p, _i32, _p, _i64, _p, _p, _i64, _p, _p]),
     "mink_stream_create_cu_subset": (ctypes.c_int, [_i32, _i32, _i32, _p]),
     "mink_stream_destroy": (ctypes.c_int, [_p]),
     "mink_conv_timing": (ctypes.c_int, [_i32, _i32, _i32, _i32, _i32]),

@@ -803,7 +803,7 @@ __global__ __launch_bounds__(kBlock) void decode_plenoxel_kernel(
 extern "C" {
 
 const char *mink_last_error(void) { return g_err; }
-int mink_abi_version(void) { return 3; }  // 2: every scratch buffer is passed with its size; 3: MinkStem.xb (bf16 storage)
+int mink_abi_version(void) { return 4; }  // 2: every scratch buffer is passed with its size; 3: MinkStem.xb (bf16 storage); 4: mink_net_* (the whole trunk per call)
 
 int64_t mink_table_capacity(int64_t n) {
   int64_t cap = 64;

@@ -6,6 +6,9 @@
 // training step is ~300 launches; issued from a Python autograd graph one operator at a time they cost ~20 us
 // each (4 ms per step, as much as the GPU needs for the step); issued from here they cost the ~3.5 us of
 // hipLaunchKernel.
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace mink {
@@ -42,6 +45,8 @@ int order_after(hipStream_t waiter, hipStream_t producer, int slot) {
   MINK_HIP(hipStreamWaitEvent(waiter, g_ev[slot], 0));
   return MINK_OK;
 }
+
+MinkStageHook g_stage_hook = nullptr;  // test / timeline instrumentation between the stages of mink_net_*
 
 #define TRY(expr)        \
   do {                   \
@@ -317,6 +322,181 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
   if (!down) return mink_eltwise(g_xa, g_res, ni, 2, b->g_x, st);
   if (br != st) MINK_HIP(hipStreamWaitEvent(st, g_ev[6], 0));
   return mink_rows_scatter_add(g_sc, b->down.nbr, b->n_out, cin, b->g_x, st);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------- the whole trunk
+namespace {
+
+constexpr int64_t kNetAlign = 64;  // floats: every block's region starts on a 256-byte boundary
+
+struct BlockShape {
+  int64_t n_in, n_out, act, stats, gtmp, gx;  // floats: activations, statistics, gradient scratch, input gradient
+  int level_in, level_out;
+  bool down;
+};
+
+int block_shape(const MinkNet *net, const MinkLevelMaps *levels, int32_t n_levels, int i, int &level, BlockShape &sh) {
+  const MinkBasicBlock &b = net->blocks[i];
+  const int stride = b.conv1.stride;
+  MINK_REQUIRE(stride == 1 || stride == 2, "net: block %d has stride %d", i, stride);
+  sh.level_in = level;
+  if (stride == 2) ++level;
+  sh.level_out = level;
+  MINK_REQUIRE(level < n_levels, "net: block %d needs level %d, %d given", i, level, n_levels);
+  sh.down = b.down.w != nullptr;
+  sh.n_in = levels[sh.level_in].n, sh.n_out = levels[sh.level_out].n;
+  MINK_REQUIRE(sh.n_in >= 1 && sh.n_out >= 1, "net: empty level at block %d", i);
+  const int C = b.conv1.cout;
+  sh.act = align_up((sh.down ? 6 : 4) * sh.n_out * C, kNetAlign);
+  sh.stats = align_up(6 * C, kNetAlign);
+  sh.gtmp = align_up(mink_block_grad_scratch_floats(sh.n_in, sh.n_out, b.conv1.cin, C, sh.down ? 1 : 0), kNetAlign);
+  sh.gx = align_up(sh.n_in * b.conv1.cin, kNetAlign);
+  return MINK_OK;
+}
+
+// points block i's per-step fields at its region of the activation arena and at this batch's maps
+int bind_block(MinkBasicBlock &b, const BlockShape &sh, const MinkLevelMaps *levels, float *region, const float *x) {
+  const MinkLevelMaps &lo = levels[sh.level_out];
+  const int C = b.conv1.cout;
+  const int64_t cnt = sh.n_out * C;
+  b.n_in = sh.n_in, b.n_out = sh.n_out, b.x = x;
+  b.y1 = region, b.h1 = region + cnt, b.y2 = region + 2 * cnt, b.out = region + 3 * cnt;
+  b.yd = sh.down ? region + 4 * cnt : nullptr, b.sd = sh.down ? region + 5 * cnt : nullptr;
+  float *st = region + sh.act;
+  b.norm1.mean = st, b.norm1.invstd = st + C, b.norm2.mean = st + 2 * C, b.norm2.invstd = st + 3 * C;
+  b.normd.mean = st + 4 * C, b.normd.invstd = st + 5 * C;
+  b.conv2.nbr = lo.nbr3, b.conv2.nbr_t = nullptr, b.conv2.perm = nullptr, b.conv2.n_perm = 0;
+  if (b.conv1.stride == 2) {
+    b.conv1.nbr = lo.down3, b.conv1.nbr_t = lo.down3_t, b.conv1.perm = lo.perm, b.conv1.n_perm = lo.perm ? lo.n_perm : 0;
+    MINK_REQUIRE(sh.down && lo.down1, "net: a strided block needs its shortcut convolution and the k=1 table");
+    b.down.nbr = lo.down1, b.down.nbr_t = nullptr, b.down.perm = nullptr, b.down.n_perm = 0;
+  } else {
+    MINK_REQUIRE(!sh.down, "net: a stride-1 block with a shortcut convolution is not sequenced here");
+    b.conv1.nbr = lo.nbr3, b.conv1.nbr_t = nullptr, b.conv1.perm = nullptr, b.conv1.n_perm = 0;
+  }
+  MINK_REQUIRE(b.conv1.nbr && b.conv2.nbr, "net: missing neighbour table at level %d", sh.level_out);
+  return MINK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mink_set_stage_hook(MinkStageHook hook) {
+  g_stage_hook = hook;
+  return MINK_OK;
+}
+
+int mink_event_create(void **event_out) {
+  MINK_REQUIRE(event_out, "event_create: NULL");
+  hipEvent_t ev = nullptr;
+  MINK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  *event_out = (void *)ev;
+  return MINK_OK;
+}
+
+int mink_event_destroy(void *event) {
+  if (event) MINK_HIP(hipEventDestroy((hipEvent_t)event));
+  return MINK_OK;
+}
+
+int mink_stream_wait_event(void *stream, void *event) {
+  MINK_REQUIRE(event, "stream_wait_event: NULL event");
+  MINK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return MINK_OK;
+}
+
+int mink_net_sizes(const MinkNet *net, const MinkLevelMaps *levels, int32_t n_levels, int64_t *act_floats, int64_t *grad_floats,
+                   int64_t *ws_bytes) {
+  MINK_REQUIRE(net && levels && n_levels >= 1 && net->n_blocks >= 1 && net->blocks, "net_sizes: bad arguments");
+  int64_t act = 0, grad = 0, ws = 0;
+  int level = 0;
+  for (int i = 0; i < net->n_blocks; ++i) {
+    BlockShape sh;
+    TRY(block_shape(net, levels, n_levels, i, level, sh));
+    act += sh.act + sh.stats, grad += sh.gtmp + sh.gx;
+    ws = std::max(ws, mink_block_workspace_bytes(sh.n_in, sh.n_out, net->blocks[i].conv1.cin, net->blocks[i].conv1.cout));
+  }
+  if (act_floats) *act_floats = act;
+  if (grad_floats) *grad_floats = grad;
+  if (ws_bytes) *ws_bytes = ws;
+  return MINK_OK;
+}
+
+int mink_net_forward(MinkNet *net, const MinkLevelMaps *levels, int32_t n_levels, float *arena, int64_t arena_floats,
+                     const MinkExec *ex) {
+  MINK_REQUIRE(net && levels && arena && ex && net->blocks && net->n_blocks >= 1, "net_forward: bad arguments");
+  if (g_stage_hook) g_stage_hook(-1, 0);
+  if (net->with_stem) TRY(mink_stem_forward(&net->stem, ex));
+  MINK_REQUIRE(net->stem.out && net->stem.n_pool == levels[0].n, "net_forward: the stem output must be level 0 (%lld rows, %lld given)",
+               (long long)net->stem.n_pool, (long long)levels[0].n);
+  const float *x = net->stem.out;
+  int level = 0;
+  int64_t off = 0;
+  for (int i = 0; i < net->n_blocks; ++i) {
+    BlockShape sh;
+    TRY(block_shape(net, levels, n_levels, i, level, sh));
+    MINK_REQUIRE(off + sh.act + sh.stats <= arena_floats, "net_forward: activation arena of %lld floats is too small (mink_net_sizes)",
+                 (long long)arena_floats);
+    MinkBasicBlock &b = net->blocks[i];
+    TRY(bind_block(b, sh, levels, arena + off, x));
+    b.g_out = nullptr, b.g_x = nullptr, b.g_tmp = nullptr;
+    if (g_stage_hook) g_stage_hook(i, 0);
+    TRY(mink_block_forward(&b, ex));
+    x = b.out;
+    off += sh.act + sh.stats;
+  }
+  net->out = const_cast<float *>(x);
+  net->out_rows = levels[level].n;
+  return MINK_OK;
+}
+
+int mink_net_backward(MinkNet *net, const MinkLevelMaps *levels, int32_t n_levels, float *arena, int64_t arena_floats,
+                      const float *g_out, float *grad_arena, int64_t grad_floats, const MinkExec *ex, void *const *done_events) {
+  MINK_REQUIRE(net && levels && arena && g_out && grad_arena && ex && net->blocks && net->n_blocks >= 1, "net_backward: bad arguments");
+  TRY(ensure_events());
+  // the layout of the forward pass, recomputed (another forward pass of the same net may have re-bound the descriptors)
+  std::vector<BlockShape> shapes(net->n_blocks);
+  std::vector<int64_t> offs(net->n_blocks);
+  int level = 0;
+  int64_t off = 0, goff_total = 0;
+  for (int i = 0; i < net->n_blocks; ++i) {
+    TRY(block_shape(net, levels, n_levels, i, level, shapes[i]));
+    offs[i] = off;
+    off += shapes[i].act + shapes[i].stats;
+    goff_total += shapes[i].gtmp + shapes[i].gx;
+  }
+  MINK_REQUIRE(off <= arena_floats && goff_total <= grad_floats, "net_backward: arena too small (mink_net_sizes)");
+  hipStream_t st = (hipStream_t)ex->compute, wst = (hipStream_t)ex->wgrad;
+  const float *g = g_out;
+  int64_t goff = 0;
+  for (int i = net->n_blocks - 1; i >= 0; --i) {
+    const BlockShape &sh = shapes[i];
+    MinkBasicBlock &b = net->blocks[i];
+    const float *x = i == 0 ? net->stem.out : arena + offs[i - 1] + 3 * shapes[i - 1].n_out * net->blocks[i - 1].conv1.cout;
+    TRY(bind_block(b, sh, levels, arena + offs[i], x));
+    b.g_out = g, b.g_tmp = grad_arena + goff, b.g_x = grad_arena + goff + sh.gtmp;
+    if (g_stage_hook) g_stage_hook(i, 1);
+    TRY(mink_block_backward(&b, ex));
+    if (done_events && done_events[i]) {
+      // everything this block wrote into parameter-gradient buffers is complete once this event fires: the weight
+      // gradients run on `wgrad`, the batch-norm gradients on `compute` / `branch`
+      TRY(order_after(wst, st, 7));
+      if ((hipStream_t)ex->branch != st && (hipStream_t)ex->branch != wst) TRY(order_after(wst, (hipStream_t)ex->branch, 4));
+      MINK_HIP(hipEventRecord((hipEvent_t)done_events[i], wst));
+    }
+    g = b.g_x;
+    goff += sh.gtmp + sh.gx;
+  }
+  if (g_stage_hook) g_stage_hook(-1, 1);
+  if (net->with_stem) {
+    net->stem.g_out = g;
+    TRY(mink_stem_backward(&net->stem, ex));
+  }
+  net->g_stem_out = g;
+  return MINK_OK;
 }
 
 }  // extern "C"

@@ -1,38 +1,40 @@
-"""The Mink-ResNet trunk (stem + BasicBlocks) as ONE autograd node whose forward / backward issue one native call
-per stage (`mink_stem_*` / `mink_block_*`, include/mink_hip.h) instead of one Python autograd node and one FFI call
-per operator.  Same kernels in the same order as the module-by-module path (which stays, and is what the tests
-compare this against bit for bit); what changes is the host cost: ~300 launches per training step at ~20 us of
-Python each were as slow as the GPU's own 4 ms, here a stage costs one descriptor + ~12 x hipLaunchKernel.
+"""The Mink-ResNet trunk (stem + BasicBlocks) as ONE autograd node whose forward and backward are ONE native call each
+(`mink_net_forward` / `mink_net_backward`, include/mink_hip.h) instead of one Python autograd node and one FFI call per
+operator -- or, as until round 3, one call per residual block.  Same kernels in the same order as the module-by-module
+path (which stays, and is what the tests compare this against bit for bit); what changes is the host cost: ~300 launches
+per training step at ~20 us of Python each were as slow as the GPU's own 4 ms; one call per block still cost Mink-ResNet34
+at four scenes per GPU (BASELINE config #3's per-GPU shape) 3.6 ms of host per 4.7 ms step.  Here the host's per-step work
+is a handful of per-LEVEL map records, two allocations and two calls, whatever the depth.
 
-Reference composition this mirrors: models/mink/resnet.py:58-64,163-177 (stem, layer1..4) and
+Reference composition this mirrors: models/mink/resnet.py:58-64,107-161,163-177 (stem, _make_layer, layer1..4) and
 modules/resnet_block.py:53-69 (BasicBlock).
 
-Host cost is the whole point, so the descriptors are persistent ctypes objects: what never changes between steps
-(weight / batch-norm pointers, shapes) is written once, per step only the map pointers, row counts and activation
-addresses are stored -- plain integer arithmetic on one arena per stage, no tensor views."""
+The descriptors are persistent ctypes objects: what never changes between steps (weight / batch-norm pointers, shapes,
+gradient-sink addresses) is written once; per step only the level records and the stem's few fields are stored."""
 import ctypes
 
 import torch
 
+from .._lib import STAGE_HOOK, Exec, LevelMaps, Net
 from .._lib import BasicBlock as _BlockDesc
-from .._lib import Exec
-from .._lib import Stem as _StemDesc
 from .._lib import check, lib
 from . import functional as Fn
 from .coords import CoordinateMapKey
 
 _KEEPALIVE = []  # gradient scratch of the running backward pass: the weight-gradient stream reads it until the final join
 Fn._AFTER_JOIN.append(_KEEPALIVE.clear)
+_ALIGN = 64  # floats: kNetAlign of csrc/trunk.hip (every block's region starts on a 256-byte boundary)
 
 
 class _Stage:
     """One residual block: its modules, where its parameters sit in the flat parameter list, its descriptor."""
 
-    __slots__ = ("conv1", "norm1", "conv2", "norm2", "down", "normd", "pidx", "np", "stride", "cin", "C", "desc")
+    __slots__ = ("conv1", "norm1", "conv2", "norm2", "down", "normd", "pidx", "np", "stride", "cin", "C", "desc", "level")
 
 
 class _Plan:
-    __slots__ = ("stages", "params", "norms", "stem", "out_ts", "ptrs", "ex", "sources")
+    __slots__ = ("stages", "params", "norms", "stem", "out_ts", "ptrs", "ex", "sources", "net", "blocks", "levels", "n_levels",
+                 "sizes", "grad_key", "events", "need_nbr3")
 
 
 def plan_for(model):
@@ -51,7 +53,7 @@ def plan_for(model):
             and model.pool.kernel_size == 2 and model.pool.stride == 2):
         return None
     plan = _Plan()
-    params, stages, ts = [model.conv1.kernel, model.bn1.bn.weight, model.bn1.bn.bias], [], 2
+    params, stages, ts, level = [model.conv1.kernel, model.bn1.bn.weight, model.bn1.bn.bias], [], 2, 0
     for li in range(1, 5):
         for blk in getattr(model, f"layer{li}"):
             if type(blk).__name__ != "BasicBlock" or not (conv_ok(blk.conv1, 3) and conv_ok(blk.conv2, 3, 1)
@@ -75,8 +77,9 @@ def plan_for(model):
             if st.down is not None:
                 params += [st.down.kernel, st.normd.bn.weight, st.normd.bn.bias]
             st.np = len(params) - st.pidx
-            st.desc = _BlockDesc()
             ts *= st.stride
+            level += st.stride == 2
+            st.level = level
             stages.append(st)
     plan.stages, plan.params, plan.out_ts = stages, params, ts
     # where every parameter lives (module, attribute), in the order of `params`: `stale()` compares identities
@@ -88,7 +91,19 @@ def plan_for(model):
             src += [(st.down, "kernel"), (st.normd.bn, "weight"), (st.normd.bn, "bias")]
     plan.sources = src
     plan.norms = [model.bn1] + [n for s in stages for n in (s.norm1, s.norm2, s.normd) if n is not None]
-    plan.stem, plan.ptrs, plan.ex = _StemDesc(), None, Exec()
+    # the native descriptors: one MinkNet over a contiguous array of blocks, one level record per tensor stride
+    plan.blocks = (_BlockDesc * len(stages))()
+    for i, st in enumerate(stages):
+        st.desc = plan.blocks[i]  # (a view of the array element)
+    plan.net = Net()
+    plan.net.blocks = ctypes.cast(plan.blocks, ctypes.POINTER(_BlockDesc))
+    plan.net.n_blocks, plan.net.with_stem = len(stages), 1
+    plan.stem = plan.net.stem  # (a view of the embedded MinkStem)
+    plan.n_levels = level + 1
+    plan.levels = (LevelMaps * plan.n_levels)()
+    plan.need_nbr3 = [any(s.level == lv for s in stages) for lv in range(plan.n_levels)]
+    plan.need_nbr3[0] = any(s.level == 0 for s in stages)  # (only a stride-1 block on the stem's own level needs it)
+    plan.ptrs, plan.ex, plan.sizes, plan.grad_key, plan.events = None, Exec(), {}, None, None
     return plan
 
 
@@ -179,19 +194,99 @@ def _exec(plan, cur, br, side, nbytes, device):
     return ctypes.byref(ex)
 
 
-_WS_CACHE = {}
+_STEM_WS = {}
 
 
-def _ws_need(L, n_in, n_out, cin, cout):
-    key = (n_in, n_out, cin, cout)
-    v = _WS_CACHE.get(key)
+def _stem_ws(L, n0, cin, C0):
+    key = (n0, cin, C0)
+    v = _STEM_WS.get(key)
     if v is None:
-        if len(_WS_CACHE) > 4096:
-            _WS_CACHE.clear()
-        v = _WS_CACHE[key] = (int(L.mink_block_workspace_bytes(n_in, n_out, cin, cout)),
-                              int(L.mink_block_grad_scratch_floats(n_in, n_out, cin, cout, 0)),
-                              int(L.mink_block_grad_scratch_floats(n_in, n_out, cin, cout, 1)))
+        if len(_STEM_WS) > 4096:
+            _STEM_WS.clear()
+        v = _STEM_WS[key] = int(L.mink_block_workspace_bytes(n0, n0, cin, C0))
     return v
+
+
+def _sizes(L, plan, rows):
+    """(activation floats, gradient floats, scratch bytes per stream) of the blocks for these level row counts."""
+    v = plan.sizes.get(rows)
+    if v is None:
+        if len(plan.sizes) > 4096:
+            plan.sizes.clear()
+        a, g, w = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(L.mink_net_sizes(ctypes.byref(plan.net), plan.levels, plan.n_levels, ctypes.byref(a), ctypes.byref(g), ctypes.byref(w)))
+        v = plan.sizes[rows] = (a.value, g.value, w.value)
+    return v
+
+
+# ---- instrumentation between the stages of a native call (race tests: skewed auxiliary streams; bench.py --timeline)
+_HOOK_STATE = {"installed": False, "cur": None, "fwd_skew": (), "bwd_skew": ()}
+
+
+def _stage_hook(stage, backward):
+    st = _HOOK_STATE
+    if backward:
+        if stage < 0:
+            Fn.log_phase("stem_backward_begin", st["cur"])
+        else:
+            for s_ in st["bwd_skew"]:
+                Fn.skew(s_)
+    elif stage < 0:
+        Fn.log_phase("stem_forward_begin", st["cur"])
+    else:
+        if stage == 0:
+            Fn.log_phase("stem_forward", st["cur"])
+        for s_ in st["fwd_skew"]:
+            Fn.skew(s_)
+
+
+_HOOK_C = STAGE_HOOK(_stage_hook)
+
+
+def _arm_hook(L, cur, fwd_skew=(), bwd_skew=()):
+    want = bool(Fn._SKEW) or Fn._PHASE_LOG is not None
+    st = _HOOK_STATE
+    if want:
+        st["cur"], st["fwd_skew"], st["bwd_skew"] = cur, fwd_skew, bwd_skew
+    if want != st["installed"]:
+        check(L.mink_set_stage_hook(ctypes.cast(_HOOK_C, ctypes.c_void_p) if want else None))
+        st["installed"] = want
+
+
+def _align(v):
+    return -(-v // _ALIGN) * _ALIGN
+
+
+class _Saved:
+    """What the forward pass keeps for backward, indexable the way the tests read it: [0] = the stem's tuple
+    (x, w0, arena0, nbr0, nbr_pool, i2o, pad, bf16 storage?, bf16 input copy), [1 + i] = block i's
+    (activations [y1 | h1 | y2 | out | ...] as a view of the one arena, nbr1, nbr2, nbrd, ts_in, ts_out, n_in, n_out)."""
+
+    def __init__(self, stem, arena, rows, tables, plan):
+        self.stem, self.arena, self.rows, self.tables, self.plan = stem, arena, rows, tables, plan
+
+    def __len__(self):
+        return 1 + len(self.plan.stages)
+
+    def _stage(self, i):
+        off = 0
+        for j, st in enumerate(self.plan.stages):
+            n_out = self.rows[st.level]
+            width = (6 if st.down is not None else 4) * n_out * st.C
+            if j == i:
+                lv_in = st.level - (st.stride == 2)
+                t = self.tables[st.level]
+                return (self.arena[off : off + width], t[1] if st.stride == 2 else t[0], t[0], t[2] if st.stride == 2 else None,
+                        2 << lv_in, 2 << st.level, self.rows[lv_in], n_out)
+            off += _align(width) + _align(6 * st.C)
+        raise IndexError(i)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        return self.stem if i == 0 else self._stage(i - 1)
 
 
 class TrunkFunction(torch.autograd.Function):
@@ -201,7 +296,7 @@ class TrunkFunction(torch.autograd.Function):
         dev = x.device
         m = manager
         _refresh(plan)
-        # ---- stem
+        # ---- stem: its activations are laid out here (their size depends on the storage type)
         w0 = params[0]
         cin = x.shape[1]
         pad = (-cin) % 4
@@ -218,18 +313,30 @@ class TrunkFunction(torch.autograd.Function):
         n0, n1 = x.shape[0], nbr_pool.shape[0]
         cur = torch.cuda.current_stream(dev)
         br = _branch(dev, cur) if (fork and m.prepared) else cur
-        # rows per stage and the scratch the largest stage needs
-        need, n_in, ts = _ws_need(L, n0, n0, cin, C0)[0], n1, 2
-        shapes = []
-        for st in plan.stages:
-            ts_out = ts * st.stride
-            if st.stride != 1:
-                m.stride(CoordinateMapKey(ts), st.stride)
-            n_out = m.levels[ts_out].n
-            shapes.append((ts, ts_out, n_in, n_out))
-            need = max(need, _ws_need(L, n_in, n_out, st.cin, st.C)[0])
-            ts, n_in = ts_out, n_out
-        exp = _exec(plan, cur, br, cur, need, dev)
+        # ---- the level records of this batch (level l = tensor stride 2 << l)
+        lv, tables, rows = plan.levels, [], []
+        for li in range(plan.n_levels):
+            ts = 2 << li
+            if li:
+                m.stride(CoordinateMapKey(ts >> 1), 2)
+            rec = lv[li]
+            n = m.levels[ts].n
+            rec.n = n
+            rows.append(n)
+            t3 = _table(m, ts, ts, 3)[0] if plan.need_nbr3[li] else None
+            rec.nbr3 = t3.data_ptr() if t3 is not None else None
+            if li:
+                d3, d1 = _table(m, ts >> 1, ts, 3)[0], _table(m, ts >> 1, ts, 1)[0]
+                rec.down3, rec.down1 = d3.data_ptr(), d1.data_ptr()
+                tables.append((t3, d3, d1))
+            else:
+                rec.down3 = rec.down1 = None
+                tables.append((t3, None, None))
+            rec.down3_t = rec.perm = None
+            rec.n_perm = 0
+        rows = tuple(rows)
+        act_floats, _, ws_net = _sizes(L, plan, rows)
+        exp = _exec(plan, cur, br, cur, max(ws_net, _stem_ws(L, n0, cin, C0)), dev)
         # bf16 storage of the full-resolution stage (Fn.set_conv_storage): y in bf16 and a bf16 copy of x behind it
         b16 = bool(Fn._STORAGE_B16 and Fn.conv_math() == "bf16" and L.mink_stem_conv_bf16s_supported(n0, n0, w0.shape[0], cin, C0))
         ny = (n0 * C0 // 2 + 16 * n0 + 3) // 4 * 4 if b16 else n0 * C0  # floats of the y (+ xb) region: 16-byte multiples
@@ -246,43 +353,18 @@ class TrunkFunction(torch.autograd.Function):
             sd.xb, sd.xb_ready = xb_pre[1].data_ptr(), 1  # made beside the previous step (TensorField.finish)
         else:
             xb_pre = None
-        Fn.log_phase("stem_forward_begin", cur)
-        check(L.mink_stem_forward(ctypes.byref(sd), exp))
-        Fn.log_phase("stem_forward", cur)
-        Fn.note_table(nbr0)
-        saved = [(x, w0, arena0, nbr0, nbr_pool, i2o, pad, b16, xb_pre)]
-        # ---- residual blocks
-        hp = a0 + 4 * ny
-        skew = Fn._SKEW and br != cur
-        arena = None
-        for st, (ts_in, ts_out, n_in, n_out) in zip(plan.stages, shapes):
-            nbr1 = _table(m, ts_in, ts_out, 3)[0]
-            nbr2 = _table(m, ts_out, ts_out, 3)[0]
-            has_down = st.down is not None
-            C = st.C
-            cnt = n_out * C
-            arena = torch.empty((6 if has_down else 4) * cnt + 6 * C, dtype=torch.float32, device=dev)
-            a = arena.data_ptr()
-            s0 = a + 4 * (6 if has_down else 4) * cnt
-            d = st.desc
-            d.conv1.nbr, d.conv2.nbr = nbr1.data_ptr(), nbr2.data_ptr()
-            d.norm1.mean, d.norm1.invstd, d.norm2.mean, d.norm2.invstd = s0, s0 + 4 * C, s0 + 8 * C, s0 + 12 * C
-            d.n_in, d.n_out, d.x = n_in, n_out, hp
-            d.y1, d.h1, d.y2, d.out = a, a + 4 * cnt, a + 8 * cnt, a + 12 * cnt
-            nbrd = None
-            if has_down:
-                nbrd = _table(m, ts_in, ts_out, 1)[0]
-                d.down.nbr, d.yd, d.sd = nbrd.data_ptr(), a + 16 * cnt, a + 20 * cnt
-                d.normd.mean, d.normd.invstd = s0 + 16 * C, s0 + 20 * C
-            d.g_out = d.g_x = d.g_tmp = None
-            if skew:
-                Fn.skew(br)
-            check(L.mink_block_forward(ctypes.byref(d), exp))
-            Fn.note_table(nbr1, nbr2, nbrd)
-            saved.append((arena, nbr1, nbr2, nbrd, ts_in, ts_out, n_in, n_out, hp))
-            hp = a + 12 * cnt
-        out = arena[3 * cnt : 4 * cnt].view(n_out, C)
-        ctx.plan, ctx.manager, ctx.saved, ctx.fork = plan, m, saved, fork
+        arena = torch.empty(act_floats, dtype=torch.float32, device=dev)
+        _arm_hook(L, cur, fwd_skew=(br,) if (Fn._SKEW and br != cur) else ())
+        net = plan.net
+        check(L.mink_net_forward(ctypes.byref(net), lv, plan.n_levels, arena.data_ptr(), act_floats, exp))
+        if Fn._TIMING_MODE == 1:
+            Fn.note_table(nbr0, *[t for ts_ in tables for t in ts_])
+        last = plan.stages[-1]
+        n_out = net.out_rows
+        off = (net.out - arena.data_ptr()) // 4
+        out = arena[off : off + n_out * last.C].view(n_out, last.C)
+        ctx.plan, ctx.manager, ctx.fork = plan, m, fork
+        ctx.saved = _Saved((x, w0, arena0, nbr0, nbr_pool, i2o, pad, b16, xb_pre), arena, rows, tables, plan)
         ctx.params = params  # keys of the data-parallel gradient sink; deciding where the weight gradients may run
         return out
 
@@ -293,7 +375,8 @@ class TrunkFunction(torch.autograd.Function):
         dev = g_out.device
         g_out = Fn._f32c(g_out)
         sink = Fn._GRAD_SINK
-        x, w0p, arena0, nbr0, nbr_pool, i2o, pad, b16, xb_pre = saved[0]
+        x, w0p, arena0, nbr0, nbr_pool, i2o, pad, b16, xb_pre = saved.stem
+        arena, rows, tables = saved.arena, saved.rows, saved.tables
         views = Fn._sink_views(*params) if (sink is not None and pad == 0) else None
         # the weight gradients may run on the side stream (joined once, at the end of backward) when nothing consumes a
         # gradient earlier: the gradient buffer's owner (the sink) has them written in place, or autograd merely
@@ -310,107 +393,100 @@ class TrunkFunction(torch.autograd.Function):
         side = Fn._side_stream(dev) if overlap else cur
         C0 = w0p.shape[-1]
         n0 = x.shape[0]
-        need = _ws_need(L, n0, n0, x.shape[1], C0)[0]
-        for st, sv in zip(plan.stages, saved[1:]):
-            need = max(need, _ws_need(L, sv[6], sv[7], st.cin, st.C)[0])
-        exp = _exec(plan, cur, br, side, need, dev)
+        # ---- the level records again (another forward pass of this model may have run in between), with the transposed
+        # tables and parity-class orders the strided data gradients use
+        lv = plan.levels
+        bwd_tables = []
+        for li in range(plan.n_levels):
+            rec = lv[li]
+            t3, d3, d1 = tables[li]
+            rec.n = rows[li]
+            rec.nbr3 = t3.data_ptr() if t3 is not None else None
+            if li:
+                ts = 2 << li
+                rec.down3, rec.down1 = d3.data_ptr(), d1.data_ptr()
+                nbr_t = _table(m, ts >> 1, ts, 3, transposed=True)[1]
+                perm = m.tables.get(("perm", ts >> 1, 128)) if m.prepared else None
+                if perm is None:
+                    perm = m.class_perm(CoordinateMapKey(ts >> 1))
+                rec.down3_t, rec.perm, rec.n_perm = nbr_t.data_ptr(), perm.data_ptr(), perm.numel()
+                bwd_tables += [nbr_t, perm]
+            else:
+                rec.down3 = rec.down1 = rec.down3_t = rec.perm = None
+                rec.n_perm = 0
+        act_floats, grad_floats, ws_net = _sizes(L, plan, rows)
+        exp = _exec(plan, cur, br, side, max(ws_net, _stem_ws(L, n0, x.shape[1], C0)), dev)
         if overlap:
             Fn._defer_join()
-        skew = [s_ for s_ in {br, side} - {cur}] if Fn._SKEW else ()
+        # ---- where the parameter gradients go
         grads = [None] * len(params)
-        g, gp = g_out, g_out.data_ptr()
-        for si in range(len(plan.stages) - 1, -1, -1):
-            st = plan.stages[si]
-            arena, nbr1, nbr2, nbrd, ts_in, ts_out, n_in, n_out, hp = saved[si + 1]
-            has_down = st.down is not None
-            C, cin = st.C, st.cin
-            d = st.desc
-            if views is not None:
-                gs = views[st.pidx : st.pidx + st.np]
-            else:  # one fresh buffer for the stage's parameter gradients, handed to autograd as views of it
-                like = params[st.pidx : st.pidx + st.np]
-                flat = torch.empty(sum(t.numel() for t in like), dtype=torch.float32, device=dev)
-                if side != cur:
-                    flat.record_stream(side)
-                gs, off = [], 0
-                for t in like:
-                    gs.append(flat[off : off + t.numel()].view(t.shape))
-                    off += t.numel()
-            d.conv1.dw, d.norm1.dgamma, d.norm1.dbeta = gs[0].data_ptr(), gs[1].data_ptr(), gs[2].data_ptr()
-            d.conv2.dw, d.norm2.dgamma, d.norm2.dbeta = gs[3].data_ptr(), gs[4].data_ptr(), gs[5].data_ptr()
-            nbr1_t = None
-            if st.stride == 2:
-                nbr1_t = _table(m, ts_in, ts_out, 3, transposed=True)[1]
-                perm1 = m.tables.get(("perm", ts_in, 128)) if m.prepared else None
-                if perm1 is None:
-                    perm1 = m.class_perm(CoordinateMapKey(ts_in))
-                d.conv1.nbr_t, d.conv1.perm, d.conv1.n_perm = nbr1_t.data_ptr(), perm1.data_ptr(), perm1.numel()
-            if has_down:  # (its data gradient goes through the forward table: no transposed table)
-                d.down.dw = gs[6].data_ptr()
-                d.normd.dgamma, d.normd.dbeta = gs[7].data_ptr(), gs[8].data_ptr()
-            # (the descriptor still holds this batch's forward fields: the activations it points at are kept in `saved`)
-            if d.y1 != arena.data_ptr():  # another forward pass ran on this model in between: restore this batch's fields
-                TrunkFunction._restore(st, saved[si + 1])
-            ntmp = _ws_need(L, n_in, n_out, cin, C)[2 if has_down else 1]
-            g_buf = torch.empty(ntmp + n_in * cin, dtype=torch.float32, device=dev)
-            gb = g_buf.data_ptr()
-            d.g_out, d.g_tmp, d.g_x = gp, gb, gb + 4 * ntmp
-            for s_ in skew:
-                Fn.skew(s_)
-            check(L.mink_block_backward(ctypes.byref(d), exp))
-            Fn.note_table(nbr1, nbr2, nbrd, nbr1_t)
-            _KEEPALIVE.append((g_buf, g))  # (never the gradients handed to autograd: a second reference makes it clone them at once)
-            if views is not None:
-                for i in range(st.pidx, st.pidx + st.np):
-                    sink.ready(params[i])
-                if C <= 128:  # a wide-and-shallow stage is queued (static rule, the same on every rank): the host has time
-                    sink.flush()
-            else:
-                grads[st.pidx : st.pidx + st.np] = gs
-            g, gp = g_buf, gb + 4 * ntmp
-        # ---- stem
+        flat = None
         if views is not None:
-            gs = views[:3]
-        else:
-            gw = torch.empty(w0p.shape, dtype=torch.float32, device=dev)
-            gbn = torch.empty(2 * C0, dtype=torch.float32, device=dev)
-            gs = [gw, gbn[:C0], gbn[C0:]]
+            gkey = (id(sink), views[0].data_ptr(), views[-1].data_ptr())
+            ptrs = None if plan.grad_key == gkey else [v.data_ptr() for v in views]
+            plan.grad_key = gkey
+        else:  # one fresh buffer for all parameter gradients of the trunk, handed to autograd as views of it
+            sizes = [_align(p.numel()) for p in params]
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            if side != cur:
+                flat.record_stream(side)
+            base, ptrs, off = flat.data_ptr(), [], 0
+            for i, p in enumerate(params):
+                ptrs.append(base + 4 * off)
+                if not (i == 0 and pad):
+                    grads[i] = flat[off : off + p.numel()].view(p.shape)
+                off += sizes[i]
+            plan.grad_key = None
+        gw_pad = None
+        if ptrs is not None:
+            for st in plan.stages:
+                d, q = st.desc, ptrs[st.pidx : st.pidx + st.np]
+                d.conv1.dw, d.norm1.dgamma, d.norm1.dbeta, d.conv2.dw, d.norm2.dgamma, d.norm2.dbeta = q[:6]
+                if st.down is not None:
+                    d.down.dw, d.normd.dgamma, d.normd.dbeta = q[6:9]
         sd = plan.stem
         if sd.x != x.data_ptr() or sd.y != arena0.data_ptr():
-            TrunkFunction._restore_stem(plan, saved[0])
-        sd.conv.dw, sd.norm.dgamma, sd.norm.dbeta, sd.g_out = gs[0].data_ptr(), gs[1].data_ptr(), gs[2].data_ptr(), gp
-        Fn.log_phase("stem_backward_begin", torch.cuda.current_stream(dev))
-        check(L.mink_stem_backward(ctypes.byref(sd), exp))
-        Fn.log_phase("stem_backward_end", torch.cuda.current_stream(dev))
-        Fn.note_table(nbr0)
-        _KEEPALIVE.append(g)
+            TrunkFunction._restore_stem(plan, saved.stem)
         if views is not None:
+            sd.conv.dw, sd.norm.dgamma, sd.norm.dbeta = views[0].data_ptr(), views[1].data_ptr(), views[2].data_ptr()
+        else:
+            if pad:  # the padded stem kernel's gradient has its own buffer; the caller gets the un-padded columns
+                gw_pad = torch.empty(w0p.shape, dtype=torch.float32, device=dev)
+            sd.conv.dw = gw_pad.data_ptr() if pad else ptrs[0]
+            sd.norm.dgamma, sd.norm.dbeta = ptrs[1], ptrs[2]
+        g_buf = torch.empty(grad_floats, dtype=torch.float32, device=dev)
+        collect = views is not None and getattr(sink, "_collect", False)
+        evp = None
+        if collect:
+            if plan.events is None:
+                plan.events = (ctypes.c_void_p * len(plan.stages))()
+                for i in range(len(plan.stages)):
+                    check(L.mink_event_create(ctypes.byref(plan.events, i * ctypes.sizeof(ctypes.c_void_p))))
+            evp = plan.events
+        _arm_hook(L, cur, bwd_skew=tuple({br, side} - {cur}) if Fn._SKEW else ())
+        check(L.mink_net_backward(ctypes.byref(plan.net), lv, plan.n_levels, arena.data_ptr(), act_floats, g_out.data_ptr(),
+                                  g_buf.data_ptr(), grad_floats, exp, evp))
+        Fn.log_phase("stem_backward_end", cur)
+        if Fn._TIMING_MODE == 1:
+            Fn.note_table(nbr0, *[t for ts_ in tables for t in ts_], *bwd_tables)
+        _KEEPALIVE.append((g_buf, g_out, flat, gw_pad, bwd_tables))  # (never the gradients handed to autograd: a second reference makes it clone them at once)
+        if collect:
+            # every block's gradients are queued: report them in backward order, each with the event behind which they are
+            # complete, so that a bucket's all-reduce waits for exactly its own blocks and overlaps the rest of backward
+            for si in range(len(plan.stages) - 1, -1, -1):
+                st = plan.stages[si]
+                sink.stage_event = evp[si]
+                for i in range(st.pidx, st.pidx + st.np):
+                    sink.ready(params[i])
+            sink.stage_event = None
             sink.flush()  # everything complete so far goes out beside the stem's weight gradient (0.9 ms)
             for i in range(3):
                 sink.ready(params[i])
-        else:
-            grads[0] = gs[0][:, : gs[0].shape[1] - pad].contiguous() if pad else gs[0]
-            grads[1], grads[2] = gs[1], gs[2]
+        if views is None and pad:
+            grads[0] = gw_pad[:, : gw_pad.shape[1] - pad].contiguous()
         if not overlap:
             _KEEPALIVE.clear()
         return (None, None, None, None, *grads)
-
-    @staticmethod
-    def _restore(st, sv):
-        """Point a stage descriptor back at the batch whose backward is running (a second forward pass of the same
-        model overwrote the per-step fields)."""
-        arena, nbr1, nbr2, nbrd, ts_in, ts_out, n_in, n_out, hp = sv
-        d, C = st.desc, st.C
-        cnt = n_out * C
-        a = arena.data_ptr()
-        s0 = a + 4 * (6 if st.down is not None else 4) * cnt
-        d.conv1.nbr, d.conv2.nbr = nbr1.data_ptr(), nbr2.data_ptr()
-        d.norm1.mean, d.norm1.invstd, d.norm2.mean, d.norm2.invstd = s0, s0 + 4 * C, s0 + 8 * C, s0 + 12 * C
-        d.n_in, d.n_out, d.x = n_in, n_out, hp
-        d.y1, d.h1, d.y2, d.out = a, a + 4 * cnt, a + 8 * cnt, a + 12 * cnt
-        if st.down is not None:
-            d.down.nbr, d.yd, d.sd = nbrd.data_ptr(), a + 16 * cnt, a + 20 * cnt
-            d.normd.mean, d.normd.invstd = s0 + 16 * C, s0 + 20 * C
 
     @staticmethod
     def _restore_stem(plan, sv):

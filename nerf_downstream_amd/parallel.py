@@ -80,13 +80,22 @@ class BucketedGradAllReduce:
             self.buckets.append((bstart, off, bcount))
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._next = 0  # buckets go out in ascending index order, whatever order they complete in (see _drain)
+        # The native trunk queues the WHOLE backward pass in one call and then reports its blocks' gradients one block at a
+        # time, each with the event (a raw hipEvent_t of libmink_hip.so) behind which that block's gradients are complete:
+        # `stage_event` is the event of the block being reported, `_bucket_event[b]` the one that completed bucket b.  Its
+        # all-reduce is then issued from a stream of its own that waits for that event only (`_launch`), not for the
+        # tail of the compute streams -- which by then is the end of backward.
+        self.stage_event = None
+        self._bucket_event = [None] * len(self.buckets)
+        self._launch_stream = None
+        self.launch_log = []  # (bucket, start, end) of every collective issued, in issue order (tests compare ranks)
         self._work = []
         self._hooks = []
         self._home = None  # the stream the step runs on (captured in zero_grad)
         # `defer` (switched on together with the gradient sink below): complete buckets wait for flush() / finish()
         # instead of being launched from inside the backward of the small deep layers
         self.defer = False
-        self._pending = []
         self._written = set()  # parameters whose gradient was written in place this step
         self._counted = set()  # parameters already counted towards their bucket this step
         self._collect = self.world > 1 or self.force  # buckets are all-reduced
@@ -145,6 +154,9 @@ class BucketedGradAllReduce:
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        self.launch_log.append((b, s, e))
+        if len(self.launch_log) > 4096:
+            del self.launch_log[:2048]
         if self.flat.is_cuda:
             # The gradients of one bucket may have been produced on several HIP streams (the step's
             # own stream, the shortcut-branch stream, the weight-gradient stream); the collective
@@ -153,6 +165,16 @@ class BucketedGradAllReduce:
             from .minkowski import functional as Fn
 
             dev = self.flat.device
+            ev = self._bucket_event[b]
+            if ev is not None:
+                from ._lib import check, lib
+
+                if self._launch_stream is None:
+                    self._launch_stream = torch.cuda.Stream(device=dev)
+                check(lib().mink_stream_wait_event(self._launch_stream.cuda_stream, ev))
+                with torch.cuda.stream(self._launch_stream):
+                    self._work.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
+                return
             cur = torch.cuda.current_stream(dev)
             side = Fn.side_stream_if_any(dev)
             launch_from = side if side is not None else cur
@@ -175,21 +197,32 @@ class BucketedGradAllReduce:
         self._counted.add(k)
         b = self._bucket_of[k]
         self._ready[b] += 1
-        if self._ready[b] == self.buckets[b][2] and not self._launched[b]:
-            if self.defer:
-                self._pending.append(b)
-            else:
-                self._launch(b)
+        if self._ready[b] == self.buckets[b][2]:
+            self._bucket_event[b] = self.stage_event
+            if not self.defer:
+                self._drain()
+
+    def _drain(self):
+        """Issue the collectives of the complete buckets IN ASCENDING BUCKET ORDER, stopping at the first incomplete one.
+        Every rank must issue its collectives in the same order (RCCL matches them by issue order per communicator),
+        and the order in which buckets COMPLETE is not the same on every rank: a rank whose batch is large enough for
+        the native trunk reports a stage's parameters in registration order after the stage's backward call, a rank on
+        the module path reports them in autograd order (norm2, conv2, shortcut, norm1, conv1) -- with a bucket boundary
+        inside a stage the two complete neighbouring buckets in opposite orders.  The flat buffer is laid out in reverse
+        registration order, so ascending bucket order is (nearly) completion order anyway: a bucket waits for its
+        predecessor for a few kernels at most."""
+        while self._next < len(self.buckets) and self._ready[self._next] == self.buckets[self._next][2]:
+            if not self._launched[self._next]:
+                self._launch(self._next)
+            self._next += 1
 
     def flush(self):
         """Launch the collectives of the buckets completed so far.  With `defer` (gradient-sink mode) a complete
         bucket is not launched from inside the backward of the small deep layers -- there the host is what the
         GPU waits for, and a launch costs it 60 us -- but at the first point where the GPU has a long kernel
         queued (the convolution backward calls this after queuing the kernels of a large layer)."""
-        pending, self._pending = self._pending, []
-        for b in pending:
-            if not self._launched[b]:
-                self._launch(b)
+        if self._collect:
+            self._drain()
 
     def zero_grad(self):
         """Gradients accumulate into the flat buffer; clear it with one memset per step."""
@@ -205,9 +238,10 @@ class BucketedGradAllReduce:
         self.flat.zero_()
         self._written.clear()
         self._counted.clear()
-        self._pending.clear()
+        self._next = 0
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._bucket_event = [None] * len(self.buckets)
 
     def finish(self):
         """Wait for the outstanding collectives (launching any bucket whose parameters did not

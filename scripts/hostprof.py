@@ -1,5 +1,5 @@
 """Host-side timeline of one pipelined training step (run on the GPU box): how long the HOST needs to queue each
-phase, against the wall time of the step.  usage: python scripts/hostprof.py [batch] [native_trunk 0/1]"""
+phase, against the wall time of the step.  usage: python scripts/hostprof.py [batch] [native_trunk 0/1] [model=ResNet14]"""
 import collections, cProfile, io, os, pstats, sys, time
 sys.path.insert(0, os.getcwd())
 import torch, torch.nn.functional as F
@@ -9,7 +9,8 @@ from nerf_downstream_amd.co3d_3d.src.models import get_model
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-model = get_model("ResNet14", 28, 51).to(dev)
+NAME = sys.argv[3] if len(sys.argv) > 3 else "ResNet14"
+model = get_model(NAME, 28, 51).to(dev)
 if len(sys.argv) > 2:
     model._native_trunk = sys.argv[2] != "0"
 opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=True)
@@ -40,7 +41,7 @@ for i in range(8, 8 + N): step(i, True)
 th = time.perf_counter() - t0
 torch.cuda.synchronize()
 tt = time.perf_counter() - t0
-print(f"B={B} native_trunk={model._native_trunk} host ms/step", {k: round(v / N * 1e3, 3) for k, v in T.items()}, "host total", round(th / N * 1e3, 3), "wall", round(tt / N * 1e3, 3))
+print(f"{NAME} B={B} native_trunk={model._native_trunk} host ms/step", {k: round(v / N * 1e3, 3) for k, v in T.items()}, "host total", round(th / N * 1e3, 3), "wall", round(tt / N * 1e3, 3))
 pr = cProfile.Profile(); pr.enable()
 for i in range(48, 58): step(i)
 torch.cuda.synchronize()

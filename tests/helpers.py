@@ -1,4 +1,6 @@
 """Seeded synthetic inputs shared by the CPU and GPU tests."""
+import os
+
 import numpy as np
 
 
@@ -43,3 +45,31 @@ def trunk_node(out):
             return fn
         stack += [f for f, _ in fn.next_functions]
     return None
+
+
+def host_threads(cap=16):
+    """Cores this process may really use: the scheduler affinity mask capped by the cgroup CPU quota -- never
+    os.cpu_count(), which on a shared GPU box reports the machine (128+) while the cgroup grants a fraction: oversubscribed
+    BLAS / OpenMP threads made the oracle 12x slower there (BENCH_r03.json cpu_baseline: 128 threads 39.6 k voxels/s, 12
+    threads 486.7 k)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(cap, n))

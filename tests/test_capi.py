@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f"{n} declared in mink_hip.h but not exported"
     handle = _lib.lib()
-    assert handle.mink_abi_version() == 3  # 2: every scratch buffer travels with its size; 3: MinkStem.xb (bf16 storage)
+    assert handle.mink_abi_version() == 4  # 2: every scratch buffer travels with its size; 3: MinkStem.xb (bf16 storage); 4: mink_net_*
     # pure host helpers can run without a GPU
     assert handle.mink_table_capacity(1000) == 2048
     assert handle.mink_conv_plan_ksplit(1_000_000, 27, 64, 0) == 1

@@ -82,6 +82,64 @@ def test_bucketed_allreduce_world2(tmp_path, oracle_maps):
     assert torch.allclose(r0["g"], ref, atol=1e-4 * float(ref.abs().max()), rtol=1e-3)
 
 
+def _imbalance_worker(rank, world, port, out):
+    """Rank 0: two scenes, gradients reported the way the module path reports them (autograd order, collectives issued
+    from the hooks); rank 1: twelve scenes, gradients reported the way the native trunk reports them (per residual stage,
+    in REGISTRATION order, after the stage's backward; deferred launches, a flush per stage)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import batch_scenes
+
+    from nerf_downstream_amd.parallel import BucketedGradAllReduce
+
+    torch.set_num_threads(2)
+    m = _model()
+    red = BucketedGradAllReduce(m, bucket_bytes=64 << 10)  # a bucket per weight tensor or two: boundaries fall inside the residual stages
+    assert len(red.buckets) > 8, len(red.buckets)
+    seeds = [200, 201] if rank == 0 else list(range(300, 312))  # (two scenes: batch norm needs two rows at the coarsest level)
+    coords, feats = batch_scenes(seeds, grid=24, cin=8)
+    labels = torch.arange(len(seeds)) % 3
+    for step in range(2):
+        red.zero_grad()
+        loss = F.cross_entropy(m(m.process_input({"coordinates": coords, "features": feats})), labels)
+        if rank == 0:
+            loss.backward()
+        else:
+            for h in red._hooks:
+                h.remove()
+            red._hooks, red.defer = [], True
+            loss.backward()
+            assert not red.launch_log or step > 0
+            stages = [m.final] + [blk for li in (4, 3, 2, 1) for blk in list(getattr(m, f"layer{li}"))[::-1]] + [m.bn1, m.conv1]
+            for st in stages:
+                for p_ in st.parameters():  # registration order inside the stage, as minkowski/trunk.py reports
+                    red.ready(p_)
+                red.flush()
+        red.finish()
+    g = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    torch.save({"g": g, "log": list(red.launch_log), "n": len(red.buckets)}, f"{out}/i{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_collectives_are_issued_in_one_order_under_imbalance(tmp_path, oracle_maps):
+    """The deadlock hazard of data parallelism with deferred launches is a rank-dependent ISSUE ORDER of the bucket
+    all-reduces (RCCL matches collectives by order).  Two ranks with very different batches (2 scenes vs 12) that report
+    their gradients in different orders -- the module path's autograd order on one, the native trunk's per-stage
+    registration order with static flush points on the other, as happens when only one rank's batch is large enough
+    for the trunk -- must issue the same sequence of (bucket, start, end), twice in a row, and end with the same mean
+    gradients.  (With launches in completion order this test hangs or mismatches: bucket k+1 completes before bucket k
+    on the trunk-style rank wherever a boundary falls inside a stage.)"""
+    mp.spawn(_imbalance_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "i0.pt"), torch.load(tmp_path / "i1.pt")
+    assert r0["log"] == r1["log"] and len(r0["log"]) == 2 * r0["n"]
+    assert [b for b, _, _ in r0["log"]] == 2 * list(range(r0["n"]))  # ascending bucket order, every step
+    assert torch.equal(r0["g"], r1["g"]) and bool(torch.isfinite(r0["g"]).all())
+
+
 def test_flat_buffer_layout_single_process():
     sys.path.insert(0, ROOT)
     from nerf_downstream_amd.parallel import BucketedGradAllReduce

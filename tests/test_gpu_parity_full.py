@@ -13,7 +13,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import batch_scenes, trunk_node
+from helpers import batch_scenes, host_threads, trunk_node
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -76,12 +76,14 @@ def _baseline_batch(batch=16, grid=128, cin=28):
     return collate_mink([ds[i] for i in range(batch)])  # exactly bench.py's first batch
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.long
+@pytest.mark.timeout(90)
 def test_baseline_batch_forward_and_maps_match_oracle(oracle_maps):
     """BASELINE config #2's own batch (B=16, 128^3, ~825 k voxels x 28 features)."""
     from nerf_downstream_amd import minkowski as ME
 
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    torch.set_num_threads(host_threads(16))
+    oracle_maps.set_threads(host_threads(16))
     b = _baseline_batch()
     coords, feats = b["coordinates"], b["features"]
     assert coords.shape[0] > 800_000
@@ -201,7 +203,8 @@ def _check_every_map(oracle_maps, field, coords, plan_ops):
     return len(want), n_tables, n_t, n_perm
 
 
-@pytest.mark.timeout(1200)
+@pytest.mark.long
+@pytest.mark.timeout(150)
 @pytest.mark.parametrize("name,batch,math", [("ResNet14", 16, "fp32"), ("ResNet34", 4, "fp32"), ("ResNet14", 16, "bf16"),
                                              ("ResNet14", 16, "bf16s")])
 def test_baseline_batch_backward_and_every_map_match_oracle(oracle_maps, name, batch, math):
@@ -217,7 +220,7 @@ def test_baseline_batch_backward_and_every_map_match_oracle(oracle_maps, name, b
     from nerf_downstream_amd.minkowski import functional as Fn
     from oracle import me_cpu as OME
 
-    threads = min(32, os.cpu_count() or 1)
+    threads = host_threads(32)
     torch.set_num_threads(threads)
     oracle_maps.set_threads(threads)
     b = _baseline_batch(batch=batch)
@@ -327,91 +330,36 @@ def test_baseline_batch_backward_and_every_map_match_oracle(oracle_maps, name, b
     assert nlev == 6 and ntab >= 14 and ntr >= 4 and nperm == 4, (nlev, ntab, ntr, nperm)
 
 
-SPLIT = dict(grid=64, sep=0.25, sigma=0.35, lr=0.003, steps=300, batch=8)  # picked with scripts/top1_parity.py
+from top1_recipe import N_VAL_STAT, SPLIT, fit as _fit, recipe_hash, stat_predictions, stat_val_batches, val_logits as _val_logits  # noqa: E402
+
+TOP1_FIXTURE = os.path.join(ROOT, "tests", "golden", "top1_oracle_v1.npz")
 
 
-def _split_batches(phase, n, batch, order):
-    from nerf_downstream_amd.co3d_3d.src.data.synthetic import SparseVoxelDataset
-    from nerf_downstream_amd.co3d_3d.src.data.utils import collate_mink
-
-    ds = SparseVoxelDataset(phase=phase, num_samples=512, num_classes=51, grid=SPLIT["grid"], features=["density", "sh"],
-                            class_sep=SPLIT["sep"], scene_sigma=SPLIT["sigma"])
-    assert len(ds) == n
-    cache = {}
-
-    def get(i):
-        if i not in cache:
-            cache[i] = ds[i]
-        return cache[i]
-
-    for s in range(0, len(order) - batch + 1, batch):
-        yield collate_mink([get(int(i)) for i in order[s : s + batch]])
-
-
-def _fit(ME, device, probe_steps=(), probe=None, seed=0):
-    """SURVEY 8d's fixed-split run: 512 training scenes, 300 steps of the co3d_cls recipe (SGD momentum 0.9, weight
-    decay 1e-4, cosine schedule stepped per iteration; configs/co3d_cls.gin), batch 8, fixed seeds.  `probe(step, model,
-    batch, loss)` is called after backward at the given steps."""
-    from nerf_downstream_amd.co3d_3d.src.models import get_model
-    from nerf_downstream_amd.co3d_3d.src.modules.classification_training import ClassificationTraining
-
-    torch.manual_seed(11 + 1000 * seed)  # initial weights
-    model = get_model("ResNet14", 28, 51, ME=ME) if ME is not None else get_model("ResNet14", 28, 51).to(device)
-    module = ClassificationTraining(model)
-    opt = torch.optim.SGD(model.parameters(), lr=SPLIT["lr"], momentum=0.9, weight_decay=1e-4)
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=SPLIT["steps"])
-    g = torch.Generator().manual_seed(1234 + seed)  # data order
-    order = torch.cat([torch.randperm(512, generator=g) for _ in range(1 + SPLIT["steps"] * SPLIT["batch"] // 512)]).numpy()
-    losses = []
-    model.train()
-    for step, b in enumerate(_split_batches("train", 512, SPLIT["batch"], order[: SPLIT["steps"] * SPLIT["batch"]])):
-        b = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()}
-        opt.zero_grad(set_to_none=True)
-        loss, _ = module.training_step(b)
-        loss.backward()
-        if step in probe_steps:
-            probe(step, model, b, loss)
-        opt.step()
-        sched.step()
-        losses.append(float(loss.detach()))
-    return model, np.array(losses)
-
-
-@torch.no_grad()
-def _val_logits(model, device):
-    model.eval()
-    outs, labels = [], []
-    for b in _split_batches("val", 128, 16, np.arange(128)):
-        labels.append(b["labels"].long())
-        b = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items()}
-        outs.append(model(model.process_input(b)).float().cpu())
-    model.train()
-    return torch.cat(outs), torch.cat(labels)
-
-
-@pytest.mark.timeout(1500)
+@pytest.mark.long
+@pytest.mark.timeout(120)
 def test_fixed_split_top1_matches_oracle(oracle_maps):
     """north_star: "top-1 on a fixed synthetic split matching reference +-0.1 %".  SURVEY 8d's split (512 training / 128
-    validation scenes, 51 classes, 300 steps, same seeds) on a task that does NOT saturate: the class signal is weakened
-    (class_sep) and a per-scene offset added (scene_sigma), so validation top-1 lands near 78 %.
+    validation scenes, 51 classes, 300 steps, same seeds; tests/top1_recipe.py) on a task that does NOT saturate: the class
+    signal is weakened (class_sep) and a per-scene offset added (scene_sigma), so validation top-1 lands near 78 %.
 
     What can be asserted depends on what is well posed.  fp32 training of this network is chaotic: the CPU oracle run
     twice with different thread counts (nothing but its own summation order changes) drifts apart from 5e-7 in the loss
-    at step 2 to 1e-3 at step 8 and 7e-2 at step 12 (asserted below), so NO second implementation -- not even the
-    reference against itself -- can reproduce a 300-step trajectory, and the trained top-1 of two runs differs by a few
-    validation scenes.  Hence three assertions:
+    at step 2 to 1e-3 at step 8 and 7e-2 at step 12 (test_reference_training_does_not_reproduce_itself), so NO second
+    implementation -- not even the reference against itself -- can reproduce a 300-step trajectory, and the trained top-1
+    of two runs differs by a few validation scenes.  Hence three assertions:
       1. every training step is the reference's step: at steps 0 / 100 / 200 / 299 of the HIP run, the oracle evaluated
          at the SAME weights and batch gives the same loss (1e-4) and the same gradient (relative L2 1e-3, or -- where
          ReLU inputs at zero make the fp32 gradient itself ambiguous -- no further from the float64 gradient than twice
          the oracle's own fp32 distance);
       2. top-1 of a given network is the reference's top-1: the HIP-trained weights evaluated on the whole validation
-         split by the HIP path and by the oracle agree within 0.1 points (in fact scene by scene);
-      3. the trained accuracy is statistically the reference's: several seeds each, a 1,024-scene validation split --
-         `test_fixed_split_top1_statistics` below."""
+         split by the HIP path and by the oracle agree within 0.1 points (in fact scene by scene) -- the reference's
+         "+-0.1 %" in the only form that is well posed;
+      3. the trained accuracy is statistically the reference's: `test_fixed_split_top1_statistics` below."""
     from nerf_downstream_amd.co3d_3d.src.models import get_model
     from oracle import me_cpu as OME
 
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    torch.set_num_threads(host_threads(16))
+    oracle_maps.set_threads(host_threads(16))
     dev = torch.device("cuda", 0)
     probes = {}
 
@@ -454,64 +402,61 @@ def test_fixed_split_top1_matches_oracle(oracle_maps):
     assert 100.0 / 51 * 5 < acc_o < 95.0, "the task must neither sit at chance nor saturate"
     assert abs(acc_h - acc_o) <= 0.1 and torch.equal(logits_h.argmax(1), logits_o.argmax(1))
     assert float((logits_h - logits_o).abs().max()) < 1e-3
-    # 3. the trained accuracy of a HIP run against an oracle run is a statistical statement: test_fixed_split_top1_statistics
 
 
-@pytest.mark.timeout(1500)
-def test_fixed_split_top1_statistics(oracle_maps):
+HIP_SEEDS = tuple(range(8))
+
+
+@pytest.mark.long
+@pytest.mark.timeout(150)
+def test_fixed_split_top1_statistics():
     """north_star: "top-1 on a fixed synthetic split matching reference +-0.1 %" as the statistical statement it can only
-    be (fp32 training of this network is chaotic: test_reference_training_does_not_reproduce_itself): THREE seeds (initial
-    weights and data order) each for the HIP trainer and for the CPU oracle, same recipe as above, every trained network
-    evaluated on a 1,024-scene validation split.  Evaluation runs on the HIP path for both families (that the HIP path
-    and the oracle give the same top-1 for the same weights is asserted scene by scene in the test above).
-    Asserted: |mean top-1 (HIP runs) - mean top-1 (oracle runs)| <= 2 x the pooled standard error of the two means,
-    sqrt((s_h^2 + s_o^2) / 3) with s the standard deviation over seeds, floored by the binomial resolution of the split
-    (sqrt(p (1 - p) / 1024 / 3): three 1,024-scene evaluations cannot resolve less).  Two, not one: a one-sigma band
-    rejects a third of all pairs of IDENTICAL implementations.  Also reported: the paired differences per seed."""
-    from nerf_downstream_amd.co3d_3d.src.data.synthetic import SparseVoxelDataset
-    from nerf_downstream_amd.co3d_3d.src.data.utils import collate_mink
-    from nerf_downstream_amd.co3d_3d.src.models import get_model
-    from oracle import me_cpu as OME
+    be (fp32 training of this network is chaotic: test_reference_training_does_not_reproduce_itself).
 
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    Oracle side: tests/golden/top1_oracle_v1.npz -- the CPU oracle trained with seeds 0..5 of the recipe and evaluated BY
+    THE ORACLE on the 1,024-scene validation split, generated once in the build container by oracle/make_top1_fixture.py
+    (~6 minutes per seed on eight cores: that work does not belong on the GPU box inside the driver's limit; in round 3 it
+    was there and the run was killed).  The fixture carries a hash of recipe and data which is recomputed here first.
+    HIP side: EIGHT seeds trained and evaluated here on the HIP path (seconds each).  That the HIP path and the oracle
+    give the same top-1 for the same weights is asserted scene by scene in the test above.
+
+    Asserted: |mean top-1 (HIP runs) - mean top-1 (oracle runs)| <= 2 x the standard error of that difference,
+    sqrt(s_h^2 / n_h + s_o^2 / n_o) with s the standard deviation over seeds, each term floored by the binomial resolution
+    of the split (p (1 - p) / 1024 per run).  Two, not one: a one-sigma band rejects a third of all pairs of IDENTICAL
+    implementations.  The result line is also appended to gpurun_out/top1_statistics.txt on the GPU box (kept as profiles/r04_top1_statistics.txt)."""
+    fx = np.load(TOP1_FIXTURE)
+    assert str(fx["recipe"]) == recipe_hash(), "tests/golden/top1_oracle_v1.npz was made for another recipe: rerun oracle/make_top1_fixture.py"
+    acc_o, labels = fx["top1"].astype(np.float64), fx["labels"].astype(np.int64)
+    assert len(acc_o) >= 5 and fx["preds"].shape == (len(acc_o), N_VAL_STAT)
+    assert np.allclose(acc_o, 100.0 * (fx["preds"] == labels[None]).mean(1))
     dev = torch.device("cuda", 0)
-    n_val, seeds = 1024, (0, 1, 2)
-    ds = SparseVoxelDataset(phase="val", num_samples=4 * n_val, num_classes=51, grid=SPLIT["grid"], features=["density", "sh"],
-                            class_sep=SPLIT["sep"], scene_sigma=SPLIT["sigma"])
-    assert len(ds) == n_val
-    val = []
-    for s0 in range(0, n_val, 32):
-        b = collate_mink([ds[i] for i in range(s0, s0 + 32)])
-        val.append(({"coordinates": b["coordinates"].to(dev), "features": b["features"].to(dev)}, b["labels"].long()))
-
-    @torch.no_grad()
-    def top1(model):
-        model.eval()
-        hits = sum(int((model(model.process_input(b)).argmax(1).cpu() == y).sum()) for b, y in val)
-        model.train()
-        return 100.0 * hits / n_val
-
-    acc_h, acc_o = [], []
-    for sd in seeds:
+    val = stat_val_batches()
+    assert np.array_equal(torch.cat([y for _, y in val]).numpy(), labels)
+    val = [({k: v.to(dev) for k, v in b.items()}, y) for b, y in val]
+    acc_h = []
+    for sd in HIP_SEEDS:
         hip, _ = _fit(None, dev, seed=sd)
-        acc_h.append(top1(hip))
-        omodel, _ = _fit(OME, torch.device("cpu"), seed=sd)
-        carrier = get_model("ResNet14", 28, 51).to(dev)  # the oracle-trained weights, evaluated by the HIP path
-        carrier.load_state_dict(omodel.state_dict())
-        acc_o.append(top1(carrier))
-    acc_h, acc_o = np.array(acc_h), np.array(acc_o)
+        acc_h.append(100.0 * float((stat_predictions(hip, val, dev) == labels).mean()))
+    acc_h = np.array(acc_h)
     diff = float(acc_h.mean() - acc_o.mean())
     p = float(np.concatenate([acc_h, acc_o]).mean()) / 100.0
-    se_seeds = float(np.sqrt((acc_h.var(ddof=1) + acc_o.var(ddof=1)) / len(seeds)))
-    se_floor = 100.0 * float(np.sqrt(p * (1.0 - p) / n_val / len(seeds)))
-    se = max(se_seeds, se_floor)
-    print(f"top-1 on {n_val} validation scenes, seeds {seeds}: HIP runs {np.round(acc_h, 2).tolist()} (mean {acc_h.mean():.2f}), "
-          f"oracle runs {np.round(acc_o, 2).tolist()} (mean {acc_o.mean():.2f}); difference of means {diff:+.2f} points, pooled standard "
-          f"error {se_seeds:.2f} (resolution of the split {se_floor:.2f}); paired differences {np.round(acc_h - acc_o, 2).tolist()}")
+    floor = 100.0 ** 2 * p * (1.0 - p) / N_VAL_STAT
+    se = float(np.sqrt(max(acc_h.var(ddof=1), floor) / len(acc_h) + max(acc_o.var(ddof=1), floor) / len(acc_o)))
+    line = (f"top-1 on {N_VAL_STAT} validation scenes (recipe {recipe_hash()}): HIP seeds {list(HIP_SEEDS)} {np.round(acc_h, 2).tolist()} "
+            f"(mean {acc_h.mean():.2f}, sd {acc_h.std(ddof=1):.2f}); oracle seeds {fx['seeds'].tolist()} {np.round(acc_o, 2).tolist()} "
+            f"(mean {acc_o.mean():.2f}, sd {acc_o.std(ddof=1):.2f}); difference of means {diff:+.2f} points, standard error {se:.2f}")
+    print(line)
+    for d in (os.path.join(ROOT, "gpurun_out"),):
+        if os.path.isdir(d) and os.access(d, os.W_OK):
+            with open(os.path.join(d, "top1_statistics.txt"), "a") as f:
+                f.write(line + "\n")
     assert 100.0 / 51 * 5 < 100.0 * p < 95.0, "the task must neither sit at chance nor saturate"
+    assert se <= 1.0, se
     assert abs(diff) <= 2.0 * se, (diff, se)
 
 
+@pytest.mark.long
+@pytest.mark.timeout(90)
 def test_reference_training_does_not_reproduce_itself(oracle_maps, monkeypatch):
     """Why the fixed-split criterion above is not "identical trajectories": the CPU oracle alone, run with two thread
     counts (only its summation order changes), leaves its own trajectory within a dozen steps of the same recipe."""
@@ -520,12 +465,14 @@ def test_reference_training_does_not_reproduce_itself(oracle_maps, monkeypatch):
     monkeypatch.setitem(SPLIT, "grid", 32)
     monkeypatch.setitem(SPLIT, "steps", 30)
     traj = {}
-    for threads in (8, 3):
+    hi = max(2, host_threads(8))
+    for threads in (hi, max(1, hi // 2 - 1) if hi > 2 else 1):
         torch.set_num_threads(threads)
         oracle_maps.set_threads(threads)
         traj[threads] = _fit(OME, torch.device("cpu"))[1]
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    oracle_maps.set_threads(min(16, os.cpu_count() or 1))
-    d = np.abs(traj[8] - traj[3])
+    torch.set_num_threads(host_threads(16))
+    oracle_maps.set_threads(host_threads(16))
+    a, b = traj.values()
+    d = np.abs(a - b)
     print("oracle vs oracle |loss difference| per step:", np.array2string(d, precision=6))
     assert d[0] < 1e-5 and d.max() > 1e-4

@@ -183,6 +183,21 @@ def _dp_worker(rank, world, port, out):
     red.finish()
     torch.cuda.synchronize()
     torch.save({"g": red.gradients().cpu(), "launched": launched, "tail_bytes": tail_bytes}, f"{out}/r{rank}.pt")
+    # imbalanced batches: rank 1's is large enough for the native trunk (which reports a stage's gradients in registration
+    # order after the stage), rank 0's takes the module path (autograd order): both must issue the same sequence of
+    # collectives (parallel.BucketedGradAllReduce._drain) and end with the same averaged gradients
+    from helpers import trunk_node
+
+    c2, f2 = batch_scenes([60, 61] if rank == 0 else list(range(70, 82)), grid=24 if rank == 0 else 48, cin=28)
+    l2 = (torch.arange(c2[:, 0].max().int().item() + 1) % 5).to(dev)
+    del red.launch_log[:]
+    red.zero_grad()
+    o2 = m(m.process_input({"coordinates": c2.to(dev), "features": f2.to(dev)}))
+    F.cross_entropy(o2, l2).backward()
+    red.finish()
+    torch.cuda.synchronize()
+    torch.save({"g": red.gradients().cpu(), "log": list(red.launch_log), "trunk": trunk_node(o2) is not None, "n": len(red.buckets),
+                "rows": int(c2.shape[0])}, f"{out}/imb{rank}.pt")
     # single-rank reference gradients of this rank's batch (fresh model, same seed)
     torch.manual_seed(3)
     m2 = get_model("ResNet14", 28, 5).to(dev)
@@ -204,6 +219,8 @@ def _dp_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.long
+@pytest.mark.timeout(120)
 def test_data_parallel_two_ranks_on_card(tmp_path):
     mp.spawn(_dp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
@@ -215,6 +232,10 @@ def test_data_parallel_two_ranks_on_card(tmp_path):
     for r in (0, 1):
         sched = torch.load(tmp_path / f"sched{r}.pt")
         assert sched["finite"] and sched["equal"], (r, sched)
+    i0, i1 = torch.load(tmp_path / "imb0.pt"), torch.load(tmp_path / "imb1.pt")
+    assert i1["trunk"] and not i0["trunk"], (i0["rows"], i1["rows"])  # the two ranks really took different paths
+    assert i0["log"] == i1["log"] and [b for b, _, _ in i0["log"]] == list(range(i0["n"]))
+    assert torch.equal(i0["g"], i1["g"]) and bool(torch.isfinite(i0["g"]).all())
 
 
 def _syncbn_worker(rank, world, port, out):
@@ -247,6 +268,8 @@ def _syncbn_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.long
+@pytest.mark.timeout(120)
 def test_sync_batch_norm_two_ranks(tmp_path):
     """MinkowskiSyncBatchNorm over 2 ranks == BatchNorm1d over the concatenated rows."""
     mp.spawn(_syncbn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
@@ -267,6 +290,8 @@ def test_sync_batch_norm_two_ranks(tmp_path):
     assert torch.allclose(r0["rm"], bn.running_mean, atol=1e-6) and torch.allclose(r1["rv"], bn.running_var, atol=1e-5)
 
 
+@pytest.mark.long
+@pytest.mark.timeout(120)
 def test_train_cli_with_dataloader_workers(tmp_path):
     """The CLI entry point end to end on the GPU: gin files, DataLoader worker processes running
     collate_mink (CPU-only, forked after HIP is initialised in the parent), checkpoints."""
@@ -277,7 +302,7 @@ def test_train_cli_with_dataloader_workers(tmp_path):
            "--ginb", "train.max_steps=6", "--ginb", "train.val_every_n_steps=6", "--ginb", "train.log_every_n_steps=2",
            "--ginb", "SparseVoxelDataset.grid=32", "--ginb", "SparseVoxelDataset.num_samples=32", "--ginb", "train.batch_size=4",
            "--ginb", "train.val_batch_size=4", "--ginb", "train.train_num_workers=2", "--ginb", "train.val_num_workers=2", "--ginb", "train.lr=0.01"]
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "val/acc1" in r.stdout
     assert (tmp_path / "cli" / "last.ckpt").exists() and (tmp_path / "cli" / "metrics.csv").exists()
@@ -366,7 +391,8 @@ def test_segmentation_and_augmented_training_runs(tmp_path):
     gin.clear_config()
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.long
+@pytest.mark.timeout(200)
 def test_bench_two_ranks_self_launched(tmp_path):
     """`python bench.py --gpus 2` as the driver would type it (no launcher): bench.py starts its own two ranks under
     torch.distributed.run and rank 0's JSON line comes back.  Rehearsal transport: gloo, both ranks on this one card
@@ -378,7 +404,7 @@ def test_bench_two_ranks_self_launched(tmp_path):
     env.update(BENCH_DIST_BACKEND="gloo", BENCH_DEVICE="0", MASTER_PORT=str(_free_port()))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "2",
            "--grid", "32", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=850)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["n_gpus"] == 2 and res["config"]["ranks_seen"] == 2 and res["config"]["parallelism"] == "dp2"
