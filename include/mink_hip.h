@@ -548,6 +548,45 @@ int mink_stem_backward(const MinkStem *s, const MinkExec *ex);
 int mink_block_forward(const MinkBasicBlock *b, const MinkExec *ex);
 int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex);
 
+/* ------------------------------------------------------------------ batch-norm finalize inside the apply pass
+ * mink_bn_apply_from_partials = mink_bn_stats_from_partials + mink_bn_apply (the reference's MinkowskiBatchNorm forward,
+ * co3d_3d/src/models/mink/modules/common.py:22-24) -- as ONE launch when `rows` is at most the fold limit (default 32, at most
+ * 128) and C is a multiple of 64: every workgroup of the apply pass sums the partial rows of its 64 channels itself, in the
+ * order of the finalize kernel (results are bit-identical to the two-call sequence; mean / invstd / running statistics are
+ * written by the first row chunk).  mink_bn_bwd folds its finalize into its apply pass under the same conditions.  Every
+ * workgroup re-reads rows x 1 KB of partials: worth a launch only where the rows are few (measured: folding at up to 128 rows
+ * made the B=16 step 5 % SLOWER -- DESIGN.md Appendix A).  mink_bn_set_fold(max_rows) sets the limit (0: never) and returns
+ * the previous one. */
+int mink_bn_set_fold(int32_t max_rows);
+int mink_bn_apply_from_partials(const float *x, int64_t n, int32_t C, const double *partial, int32_t rows, float eps, float momentum,
+                                const float *gamma, const float *beta, const float *residual, int32_t relu, float *y, float *mean,
+                                float *invstd, float *running_mean, float *running_var, void *stream);
+
+/* ------------------------------------------------------------------ few-row layers: batch norm in one launch
+ * Below mink_bn_small_rows() rows (1024; 0 when switched off with mink_bn_set_small(0)) a batch norm as three dependent launches
+ * (column partials, finalize, apply: the reference's MinkowskiBatchNorm = nn.BatchNorm1d, co3d_3d/src/models/mink/modules/
+ * common.py:22-24, resnet_block.py:53-69) is launch latency, not bytes.  Here a workgroup owns 16 channels and ALL rows:
+ *   mink_conv_gather_gemm_slabs  mink_conv_gather_gemm that LEAVES a split launch's partial slabs in `workspace`
+ *                                ([*slabs_out][n_out][cout]; *slabs_out == 1: y is complete) -- no bias
+ *   mink_bn_small_fwd            y = sum of `nslab` slabs (nslab == 0: y as given) -> batch statistics (mean, invstd, running
+ *                                statistics as mink_bn_stats) -> out = [relu](bn(y) [+ residual])
+ *   mink_bn_small_bwd            mink_bn_bwd in one launch; nslab > 0: the incoming gradient is the sum of `nslab` slabs at
+ *                                `dy` ([nslab][n][C]), written to dy_sum
+ * C must be a multiple of 16.  Results are deterministic; the summation order differs from the three-launch form (last-bit
+ * differences), which is why the module-by-module path, the yardstick of the bitwise tests, never takes these. */
+int32_t mink_bn_small_rows(void);
+int mink_bn_set_small(int32_t on);
+int mink_conv_gather_gemm_slabs(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
+                                int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, const int32_t *row_perm,
+                                int64_t n_virtual, float *y, int32_t ldy, int32_t cout, int32_t ksplit, float *workspace,
+                                int64_t workspace_bytes, int32_t *slabs_out, void *stream);
+int mink_bn_small_fwd(const float *slabs, int32_t nslab, int64_t n, int32_t C, float *y, float eps, float momentum,
+                      const float *gamma, const float *beta, const float *residual, int32_t relu, float *out, float *mean,
+                      float *invstd, float *running_mean, float *running_var, void *stream);
+int mink_bn_small_bwd(const float *dy, int32_t nslab, float *dy_sum, const float *x, const float *y, int64_t n, int32_t C,
+                      const float *mean, const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual,
+                      float *dgamma, float *dbeta, void *stream);
+
 /* ------------------------------------------------------------------ the whole trunk as one call
  * Stem + every BasicBlock of a Mink-ResNet (the reference's ResNetBase.forward up to layer4:
  * co3d_3d/src/models/mink/resnet.py:107-161 `_make_layer`, :163-175 `forward`) in ONE host call per direction.

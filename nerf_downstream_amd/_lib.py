@@ -177,6 +177,16 @@ SIGNATURES = {
     "mink_stem_backward": (ctypes.c_int, [_p, _p]),
     "mink_block_forward": (ctypes.c_int, [_p, _p]),
     "mink_block_backward": (ctypes.c_int, [_p, _p]),
+    "mink_bn_set_fold": (ctypes.c_int, [_i32]),
+    "mink_bn_apply_from_partials": (ctypes.c_int, [_p, _i64, _i32, _p, _i32, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
+    "mink_bn_small_rows": (_i32, []),
+    "mink_bn_set_small": (ctypes.c_int, [_i32]),
+    "mink_conv_gather_gemm_slabs": (
+        ctypes.c_int,
+        [_p, _i64, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _p, _p],
+    ),
+    "mink_bn_small_fwd": (ctypes.c_int, [_p, _i32, _i64, _i32, _p, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
+    "mink_bn_small_bwd": (ctypes.c_int, [_p, _i32, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
     "mink_set_stage_hook": (ctypes.c_int, [_p]),
     "mink_event_create": (ctypes.c_int, [_p]),
     "mink_event_destroy": (ctypes.c_int, [_p]),
@@ -224,6 +234,11 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
+        # A/B knobs of the launch fusions (scripts/ab_bn.py): MINK_BN_FOLD = fold limit in partial rows, MINK_BN_SMALL = 0 / 1 / 8 / 16
+        if os.environ.get("MINK_BN_FOLD"):
+            L.mink_bn_set_fold(int(os.environ["MINK_BN_FOLD"]))
+        if os.environ.get("MINK_BN_SMALL"):
+            L.mink_bn_set_small(int(os.environ["MINK_BN_SMALL"]))
         _lib = L
     return _lib
 

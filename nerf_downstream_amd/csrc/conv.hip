@@ -913,8 +913,19 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
   // ---- staging of the gathered rows: rows a_r + 32 i, float4 column a_cc
   const int a_cc = tid & 7, a_r = tid >> 3;
   const float *xcol = p.x + 4 * a_cc;
+  // The ring's global loads are issued through inline asm and waited for with hand-counted s_waitcnt: every step issues the
+  // same NA + NW loads in the same order, so "the rows of item it + 1 have arrived" is vmcnt(NA + 2 NW) and "the weights of
+  // item it" is vmcnt(3 NA + 2 NW) -- the loads of the last two steps stay in flight.  Left to the compiler (which merges the
+  // pending-load state of the loop's entry, its latch and the conditional steps conservatively) two of every three steps
+  // began with s_waitcnt vmcnt(0): a full memory round trip behind the loads issued at the END of the previous step, with
+  // the matrix pipe idle -- that, not the MFMAs, was the kernel's item time (pipe busy 0.40).  The compiler does not see
+  // these loads: their registers must not be copied between the load and its wait (they are only ever named as asm operands
+  // and MFMA / LDS-store sources behind the wait), and everything is drained before the ring's registers die.
+  constexpr int NW = W_T ? 2 : 8;  // weight loads per item
+  constexpr bool DBG_WAIT0 = false;
   f32x4 ga[CD][NA];  // (a native vector: copies of the HIP uint4 struct become memcpy calls that keep the ring in scratch)
-  float gw[CD][8];
+  float gw[CD][W_T ? 1 : 8];
+  f32x4 gwt[CD][W_T ? 2 : 1];  // W_T: the fragment as the two 16-byte loads deliver it (component e & 3 of load e >> 2)
   f32x4 acc[NBLK];
 #pragma unroll
   for (int i = 0; i < NBLK; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -996,8 +1007,10 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const int j = nib(act_lo, act_hi, ga_);
       const int c0 = (cbeg + g_cc) * BK;
 #pragma unroll
-      for (int i = 0; i < NA; ++i)
-        ga[slot][i] = *reinterpret_cast<const f32x4 *>(xcol + (int64_t)s_src[j * CM + a_r + 32 * i] * p.ldx + c0);
+      for (int i = 0; i < NA; ++i) {
+        const float *src = xcol + (int64_t)s_src[j * CM + a_r + 32 * i] * p.ldx + c0;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ga[slot][i]) : "v"(src));
+      }
     };
     auto gload_w = [&](int slot) __attribute__((always_inline)) {
       const int ga_ = min(g_ka, na - 1);
@@ -1005,16 +1018,26 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const int k = kof(ga_, j);
       const int kw = p.flip_k ? K - 1 - k : k;
       const int c0 = (cbeg + g_cc) * BK;
-      if (!W_T) {
+      if constexpr (!W_T) {
         const int so = 4 * ((kw * p.cin + c0) * p.cout + n0);
+        if constexpr (PERM) {  // (the compiler does not hold the item's offset in a scalar register there: it goes into the lane offset)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) gw[slot][e] = raw_load_f32(rw, wv[e], so, 0);
+          for (int e = 0; e < 8; ++e) {
+            const int vo = wv[e] + so;
+            asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(gw[slot][e]) : "v"(vo), "s"(rw));
+          }
+        } else {
+          const int sso = __builtin_amdgcn_readfirstlane(so);  // (uniform; an SGPR operand)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(gw[slot][e]) : "v"(wv[e]), "s"(rw), "s"(sso));
+        }
       } else {
-        const int so = 4 * ((kw * p.cout + n0) * p.cin + c0);
+        const int so = 4 * ((kw * p.cout + n0) * p.cin + c0);  // (added to the lane offset: see above)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const f32x4 t = raw_load_v4(rw, wv[h], so, 0);
-          gw[slot][4 * h + 0] = t[0], gw[slot][4 * h + 1] = t[1], gw[slot][4 * h + 2] = t[2], gw[slot][4 * h + 3] = t[3];
+          const int vo = wv[h] + so;
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(gwt[slot][h]) : "v"(vo), "s"(rw));
         }
       }
       if (g_ka < na && ++g_cc == ncc) g_cc = 0, ++g_ka;
@@ -1025,13 +1048,40 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&a[(a_r + 32 * i) * LDA + 4 * a_cc]) = ga[slot][i];
     };
 
+    static_assert(NA == 2, "the hand-counted waits name two row loads per item");
+    // "+v": the asm is the definition point of the registers for everything that follows (nothing that reads them may be
+    // scheduled above the wait)
+    auto wait_rows = [&](int sl) __attribute__((always_inline)) {  // the gathered rows of ring slot sl have arrived
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ga[sl][0]), "+v"(ga[sl][1]) : "n"(DBG_WAIT0 ? 0 : NA + 2 * NW));
+    };
+    auto wait_weights = [&](int sl) __attribute__((always_inline)) {  // the weight fragment of ring slot sl has arrived
+      if constexpr (W_T)
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(gwt[sl][0]), "+v"(gwt[sl][1]) : "n"(DBG_WAIT0 ? 0 : 3 * NA + 2 * NW));
+      else
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(gw[sl][0]), "+v"(gw[sl][1]), "+v"(gw[sl][2]), "+v"(gw[sl][3]), "+v"(gw[sl][4]), "+v"(gw[sl][5]), "+v"(gw[sl][6]),
+                       "+v"(gw[sl][7])
+                     : "n"(DBG_WAIT0 ? 0 : 3 * NA + 2 * NW));
+    };
+    auto drain = [&](int sl) __attribute__((always_inline)) {  // nothing of ring slot sl is in flight any more
+      if constexpr (W_T)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ga[sl][0]), "+v"(ga[sl][1]), "+v"(gwt[sl][0]), "+v"(gwt[sl][1]));
+      else
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(ga[sl][0]), "+v"(ga[sl][1]), "+v"(gw[sl][0]), "+v"(gw[sl][1]), "+v"(gw[sl][2]), "+v"(gw[sl][3]), "+v"(gw[sl][4]),
+                       "+v"(gw[sl][5]), "+v"(gw[sl][6]), "+v"(gw[sl][7]));
+    };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
     static_assert(CD == 3, "the steady-state loop is unrolled by hand");
     // items 0 .. CD - 1 requested (slot = item % CD), item 0 -> LDS
+    // every load the COMPILER tracks (table entries, row permutation) is complete before the ring starts: a pending score
+    // on a register the ring re-uses would make it insert s_waitcnt vmcnt(0) at the loop header -- a full drain every pass
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     if (n_items > 0) {  // uniform
       gload_a(0), gload_w(0), gload_a(1), gload_w(1), gload_a(2), gload_w(2);
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ga[0][0]), "+v"(ga[0][1]) : "n"(2 * NA + 3 * NW));
       sts(0, 0);
     }
     MINK_LDS_BARRIER();
@@ -1039,23 +1089,31 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
     auto step = [&](int it, auto slot_c, auto nslot_c) __attribute__((always_inline)) {
       constexpr int slot = decltype(slot_c)::value;
       const int j = nib(act_lo, act_hi, ka), nb = nib(nbs_lo, nbs_hi, ka);  // nb >= 1
-      sts(decltype(nslot_c)::value, (it + 1) & 1);  // item it + 1 (after the last item: a re-read copy nobody multiplies)
+      constexpr int nslot = decltype(nslot_c)::value;
+      wait_rows(nslot);
+      sts(nslot, (it + 1) & 1);  // item it + 1 (after the last item: a re-read copy nobody multiplies)
       const float *a = sA + (it & 1) * CM * LDA + n * LDA + 4 * kq;
-      const float (&wf)[8] = gw[slot];
       // item it + CD takes the registers of item it NOW, not after the MFMAs: the compiler's s_waitcnt before the next
       // step's LDS stores is vmcnt(0..9) where the ring would allow 18 (it merges the loop-carried load scores
       // conservatively), so a load issued at the end of a step was waited for a few hundred cycles later; issued here
       // it has this step's MFMAs to arrive
-      if (!(p.stagger & 16)) gload_a(slot);
+      gload_a(slot);
+      wait_weights(slot);
+      auto wf = [&](auto e_c) __attribute__((always_inline)) -> float {
+        constexpr int e = decltype(e_c)::value;
+        if constexpr (W_T) return gwt[slot][e >> 2][e & 3];
+        else return gw[slot][e];
+      };
       auto mfma8 = [&](f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], u0.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], u0.y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], u0.z, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], u0.w, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4], u1.x, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[5], u1.y, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[6], u1.z, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[7], u1.w, c, 0, 0, 0);
+        using std::integral_constant;
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 0>{}), u0.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 1>{}), u0.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 2>{}), u0.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 3>{}), u0.w, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 4>{}), u1.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 5>{}), u1.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 6>{}), u1.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 7>{}), u1.w, c, 0, 0, 0);
       };
       auto xr = [&](int blk, int half) __attribute__((always_inline)) { return *reinterpret_cast<const float4 *>(a + blk * 16 * LDA + 16 * half); };
       // The operands of every block are read up front (rows past the compacted count hold stale data that is read but
@@ -1097,7 +1155,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
           if (nb > 6) scatter(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
         }
       }
-      if (!(p.stagger & 16)) gload_w(slot);
+      gload_w(slot);
       MINK_LDS_BARRIER();
     };
     for (int base = 0; base < n_items; base += CD) {
@@ -1105,6 +1163,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       if (base + 1 < n_items) step(base + 1, S1{}, S2{});
       if (base + 2 < n_items) step(base + 2, S2{}, S0{});
     }
+    if (n_items > 0) drain(0), drain(1), drain(2);  // (uniform) the ring's last re-read loads
     if (!PERM) break;
   }
 
@@ -2257,7 +2316,10 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
                             int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, const int32_t *row_perm,
                             int64_t n_virtual, float *y, int32_t ldy, int32_t cout, const float *bias, int32_t ksplit,
                             float *workspace, int64_t workspace_bytes, double *stats_out, int32_t *stats_rows, void *stats_ws,
-                            int64_t stats_ws_bytes, void *stream) {
+                            int64_t stats_ws_bytes, void *stream, int32_t *slabs_out = nullptr) {
+  // slabs_out != NULL: a split launch LEAVES its partial slabs in `workspace` ([*slabs_out][n_out][cout], summed by the
+  // caller's next kernel -- mink_bn_small_fwd); *slabs_out = 1 means y holds the result as usual
+  if (slabs_out) *slabs_out = 1;
   if (stats_rows) *stats_rows = 0;
   MINK_REQUIRE(K >= 1 && K <= KMAX, "gather_gemm: kernel volume %d unsupported", K);
   MINK_REQUIRE(cin >= 1 && cout >= 1 && ldx >= cin && ldy >= cout && n_out >= 0 && n_in >= 0, "gather_gemm: bad shape");
@@ -2316,7 +2378,9 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
     if (w_transposed) compact_gemm_kernel<true, CMT, true><<<cgrid, 256, smem, st>>>(p);
     else compact_gemm_kernel<false, CMT, true><<<cgrid, 256, smem, st>>>(p);
     MINK_CHECK_LAUNCH();
-    if (zc > 1) {
+    if (zc > 1 && slabs_out) {
+      *slabs_out = zc;
+    } else if (zc > 1) {
       splitk_reduce_kernel<<<dim3((unsigned)cdiv(n_out * cout, 256)), 256, 0, st>>>(workspace, n_out, cout, zc, bias, y, ldy);
       MINK_CHECK_LAUNCH();
     }
@@ -2370,6 +2434,11 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
     MINK_CHECK_LAUNCH();
     *stats_rows = rows;
   }
+  if (zs > 1 && slabs_out) {
+    MINK_REQUIRE(!bias && !stats_out, "gather_gemm: slabs are left to the caller only without bias and statistics");
+    *slabs_out = zs;
+    return MINK_OK;
+  }
   if (zs > 1 && stats_split) {
     const int tpr = cout >> 2, rlanes = 256 / tpr;
     const int rows = (int)std::max<int64_t>(1, std::min<int64_t>(512, cdiv(n_out, (int64_t)rlanes * 4)));  // one four-row trip per thread
@@ -2391,6 +2460,15 @@ int mink_conv_gather_gemm(const float *x, int64_t n_in, int32_t ldx, int32_t cin
                           float *workspace, int64_t workspace_bytes, void *stream) {
   return gather_gemm_impl(x, n_in, ldx, cin, w, w_transposed, flip_k, nbr, n_out, K, row_perm, n_virtual, y, ldy, cout, bias,
                           ksplit, workspace, workspace_bytes, nullptr, nullptr, nullptr, 0, stream);
+}
+
+int mink_conv_gather_gemm_slabs(const float *x, int64_t n_in, int32_t ldx, int32_t cin, const float *w, int32_t w_transposed,
+                                int32_t flip_k, const int32_t *nbr, int64_t n_out, int32_t K, const int32_t *row_perm,
+                                int64_t n_virtual, float *y, int32_t ldy, int32_t cout, int32_t ksplit, float *workspace,
+                                int64_t workspace_bytes, int32_t *slabs_out, void *stream) {
+  MINK_REQUIRE(slabs_out, "gather_gemm_slabs: NULL slabs_out");
+  return gather_gemm_impl(x, n_in, ldx, cin, w, w_transposed, flip_k, nbr, n_out, K, row_perm, n_virtual, y, ldy, cout, nullptr,
+                          ksplit, workspace, workspace_bytes, nullptr, nullptr, nullptr, 0, stream, slabs_out);
 }
 
 int64_t mink_conv_stats_workspace_bytes(int64_t n_out, int32_t cout) {

@@ -3,11 +3,15 @@
 // TensorField->SparseTensor segment mean.  All are HBM-roofline work: 16-byte accesses per
 // lane, channels fastest so a wave reads whole feature rows, no atomics (two-stage
 // deterministic reductions through a small workspace).
+#include <algorithm>
+
 #include "common.h"
 
 namespace mink {
 
 constexpr int EB = 256;
+static bool g_bn_small = true;  // few-row layers: the one-launch batch norm (mink_bn_set_small)
+static int g_bn_fold = 32;      // finalize inside the apply pass when there are at most this many partial rows (mink_bn_set_fold; 0 = never)
 constexpr int kRedBlocks = 2048;  // workgroups of the column reductions (8 per CU: the passes are latency-bound)
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -19,6 +23,43 @@ __device__ __forceinline__ float4 ldx4(const float *p, int64_t i) {
   const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(p) + i);
   return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
                      __uint_as_float(u.y & 0xFFFF0000u));
+}
+
+// (contraction off: the same source line became a multiply + fma in one kernel and two multiplies + add in another -- the
+//  running statistics of the folded and the separate finalize must be equal bit for bit; __fmul_rn is a plain `*` in HIP)
+__device__ __forceinline__ void bn_running_update(float *running_mean, float *running_var, int c, float momentum, float m, double var, int64_t n) {
+#pragma clang fp contract(off)
+  const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+  const float keep = 1.f - momentum, ub = (float)unbiased;
+  const float a0 = keep * running_mean[c], a1 = momentum * m;
+  running_mean[c] = a0 + a1;
+  const float b0 = keep * running_var[c], b1 = momentum * ub;
+  running_var[c] = b0 + b1;
+}
+__device__ __forceinline__ double bn_variance(double s, double ss, int64_t n, double &m) {
+#pragma clang fp contract(off)
+  m = s / (double)n;
+  const double mm = m * m;
+  const double var = ss / (double)n - mm;
+  return var < 0.0 ? 0.0 : var;
+}
+
+__device__ __forceinline__ float4 bn_affine(float4 v, float4 mu, float4 is, float4 g, float4 b) {
+#pragma clang fp contract(off)  // (two kernels share this line and must round it the same way: see bn_running_update)
+  float4 o;
+  o.x = (v.x - mu.x) * is.x * g.x + b.x, o.y = (v.y - mu.y) * is.y * g.y + b.y;
+  o.z = (v.z - mu.z) * is.z * g.z + b.z, o.w = (v.w - mu.w) * is.w * g.w + b.w;
+  return o;
+}
+
+__device__ __forceinline__ float4 bn_dx(float4 g, float4 v, float4 mu, float4 is, float4 ga, float4 dg, float4 db, float inv_n) {
+#pragma clang fp contract(off)
+  float4 o;
+  o.x = ga.x * is.x * (g.x - db.x * inv_n - (v.x - mu.x) * is.x * dg.x * inv_n);
+  o.y = ga.y * is.y * (g.y - db.y * inv_n - (v.y - mu.y) * is.y * dg.y * inv_n);
+  o.z = ga.z * is.z * (g.z - db.z * inv_n - (v.z - mu.z) * is.z * dg.z * inv_n);
+  o.w = ga.w * is.w * (g.w - db.w * inv_n - (v.w - mu.w) * is.w * dg.w * inv_n);
+  return o;
 }
 
 // ---------------------------------------------------------------------- column sums
@@ -159,16 +200,11 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double *__
   int c;
   double s, ss;
   if (!finalize_sums(partial, nblk, C, c, s, ss)) return;
-  const double m = s / (double)n;
-  double var = ss / (double)n - m * m;
-  if (var < 0.0) var = 0.0;
+  double m;
+  const double var = bn_variance(s, ss, n, m);  // (no contraction: bn_apply_fold_kernel must reproduce this bit for bit)
   mean[c] = (float)m;
   invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
-    const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
+  if (running_mean) bn_running_update(running_mean, running_var, c, momentum, (float)m, var, n);
 }
 
 template <bool WIDE>
@@ -219,6 +255,227 @@ __global__ void bn_bwd_sums_to_float_kernel(const double *__restrict__ sums, con
   dgamma_mean[c] = (float)(sums[C + c] / *n_total);
 }
 
+// ------------------------------------------------------------------ few-row layers: a whole batch norm in ONE launch
+// Below ~1 k rows (the deepest stages; every stage of Mink-ResNet34 at four scenes per GPU) a batch norm is three dependent
+// launches of 5-9 us each (column partials, finalize, apply) for a few hundred KB of data: launch latency, not bytes.  Here a
+// workgroup owns a slab of 16 CHANNELS and ALL rows, so the column statistics never leave the workgroup:
+//   forward : y = sum of the convolution's split-K slabs (in slab order) -> statistics -> out = act(bn(y) [+ residual])
+//   backward: (sum g, sum g xhat) -> dgamma, dbeta -> dx, dresidual
+// 1024 threads = 256 row lanes x 4 lanes of 16 bytes: a thread owns rows rl, rl + 256, rl + 512, rl + 768 -- ONE trip, every
+// load of a pass independent (two slabs x four rows in flight, double-buffered: the pass costs ~nslab / 2 memory round trips,
+// not rows x nslab / 64 as a 256-thread form did: 40-80 us).  The second pass re-reads what the same thread wrote or read in
+// the first (L1 / L2 hits).  Sums: fp32 per thread over its <= 4 rows, double across the 256 row lanes in lane order
+// (bitwise reproducible; NOT the summation order of the three-launch form).
+constexpr int kSmallT = 1024;     // threads per workgroup
+constexpr int kSmallRows = 1024;  // largest row count taken (mink_bn_small_rows)
+
+// CH channels per workgroup (16: 4 lanes x 16 bytes per row, 256 row lanes x 4 rows; 8: 2 lanes, 512 row lanes x 2 rows --
+// twice the workgroups: a single CU takes in ~25 GB/s of slabs that other XCDs wrote, 16 workgroups were 20 us for 0.5 MB)
+template <int CH>
+struct SmallCfg {
+  static constexpr int LANES = CH / 4, RL = kSmallT / LANES, NU = kSmallRows / RL, NQ = 8 / NU, QN = 2 * CH, NP = 256 / QN;
+};
+
+template <int CH>
+__device__ __forceinline__ void small_reduce(float4 s0, float4 s1, int c4, int rl, double *s_red, double *s_part, double *tot) {
+  using K = SmallCfg<CH>;
+  // s_red [RL row lanes][2][CH] -> s_part [NP][QN] -> tot [2][CH]
+  double *d = s_red + rl * K::QN + 4 * c4;
+  d[0] = s0.x, d[1] = s0.y, d[2] = s0.z, d[3] = s0.w;
+  d[CH] = s1.x, d[CH + 1] = s1.y, d[CH + 2] = s1.z, d[CH + 3] = s1.w;
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int q = threadIdx.x % K::QN, p = threadIdx.x / K::QN;
+    constexpr int per = K::RL / K::NP;
+    double t = 0.0;
+    for (int r = 0; r < per; ++r) t += s_red[(p * per + r) * K::QN + q];
+    s_part[p * K::QN + q] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < K::QN) {
+    double t = 0.0;
+    for (int p = 0; p < K::NP; ++p) t += s_part[p * K::QN + threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+template <int CH>
+__global__ __launch_bounds__(kSmallT) void bn_small_fwd_kernel(const float *__restrict__ ws, int nslab, int64_t n, int C, float *y,
+                                                               float eps, float momentum, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, const float *__restrict__ residual,
+                                                               int relu, float *__restrict__ out, float *__restrict__ mean,
+                                                               float *__restrict__ invstd, float *running_mean, float *running_var) {
+  using K = SmallCfg<CH>;
+  constexpr int NU = K::NU, NQ = K::NQ;
+  extern __shared__ double s_dyn[];  // [RL][QN] + [NP][QN] + [QN]
+  double *s_red = s_dyn, *s_part = s_dyn + K::RL * K::QN, *s_tot = s_part + 256;
+  __shared__ __attribute__((aligned(16))) float s_mu[CH], s_is[CH];
+  const int c4 = threadIdx.x % K::LANES, rl = threadIdx.x / K::LANES;
+  const int c = blockIdx.x * CH + 4 * c4;
+  const int64_t total = n * C;
+  int64_t off[NU];
+  bool live[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int64_t r = rl + K::RL * u;
+    live[u] = r < n;
+    off[u] = (live[u] ? r : 0) * C + c;
+  }
+  float4 v[NU];
+  if (nslab == 0) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) v[u] = ld4(y + off[u]);
+  } else {
+    // NQ slabs at a time, the next group requested before the current one is added (slab order kept)
+    float4 t[2][NQ][NU];
+    auto fetch = [&](int buf, int z) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) t[buf][q][u] = ld4(ws + (int64_t)(z + q < nslab ? z + q : z) * total + off[u]);
+    };
+    auto add = [&](int buf, int z) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (z + q < nslab) {
+#pragma unroll
+          for (int u = 0; u < NU; ++u) v[u].x += t[buf][q][u].x, v[u].y += t[buf][q][u].y, v[u].z += t[buf][q][u].z, v[u].w += t[buf][q][u].w;
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < NU; ++u) v[u] = make_float4(0, 0, 0, 0);
+    fetch(0, 0);
+    for (int z = 0; z < nslab; z += 2 * NQ) {
+      if (z + NQ < nslab) fetch(1, z + NQ);
+      add(0, z);
+      if (z + 2 * NQ < nslab) fetch(0, z + 2 * NQ);
+      add(1, z + NQ);
+    }
+  }
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (live[u]) {
+      if (nslab) st4(y + off[u], v[u]);
+      s0.x += v[u].x, s0.y += v[u].y, s0.z += v[u].z, s0.w += v[u].w;
+      s1.x += v[u].x * v[u].x, s1.y += v[u].y * v[u].y, s1.z += v[u].z * v[u].z, s1.w += v[u].w * v[u].w;
+    }
+  }
+  float4 rs[NU];  // requested now: in flight across the reduction
+#pragma unroll
+  for (int u = 0; u < NU; ++u) rs[u] = residual ? ld4(residual + off[u]) : make_float4(0, 0, 0, 0);
+  small_reduce<CH>(s0, s1, c4, rl, s_red, s_part, s_tot);
+  if (threadIdx.x < CH) {
+    const int cc = blockIdx.x * CH + threadIdx.x;
+    const double m = s_tot[threadIdx.x] / (double)n;
+    double var = s_tot[CH + threadIdx.x] / (double)n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
+    s_mu[threadIdx.x] = mf, s_is[threadIdx.x] = isf;
+    mean[cc] = mf, invstd[cc] = isf;
+    if (running_mean) {
+      const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+      running_mean[cc] = (1.f - momentum) * running_mean[cc] + momentum * mf;
+      running_var[cc] = (1.f - momentum) * running_var[cc] + momentum * (float)unbiased;
+    }
+  }
+  __syncthreads();
+  const float4 mu = ld4(s_mu + 4 * c4), is = ld4(s_is + 4 * c4), g = ld4(gamma + c), b = ld4(beta + c);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (live[u]) {
+      float4 o;
+      o.x = (v[u].x - mu.x) * is.x * g.x + b.x, o.y = (v[u].y - mu.y) * is.y * g.y + b.y;
+      o.z = (v[u].z - mu.z) * is.z * g.z + b.z, o.w = (v[u].w - mu.w) * is.w * g.w + b.w;
+      o.x += rs[u].x, o.y += rs[u].y, o.z += rs[u].z, o.w += rs[u].w;
+      if (relu) o.x = fmaxf(o.x, 0.f), o.y = fmaxf(o.y, 0.f), o.z = fmaxf(o.z, 0.f), o.w = fmaxf(o.w, 0.f);
+      st4(out + off[u], o);
+    }
+  }
+}
+
+// nslab > 0: the incoming gradient is the sum of `nslab` split-K slabs of the data-gradient convolution that produced it
+// ([nslab][n][C] at `dy`); the sum is written to `dy_sum`
+template <int CH>
+__global__ __launch_bounds__(kSmallT) void bn_small_bwd_kernel(const float *__restrict__ dy, int nslab, float *dy_sum,
+                                                               const float *__restrict__ x, const float *__restrict__ yrelu, int64_t n,
+                                                               int C, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                               const float *__restrict__ gamma, float *__restrict__ dx,
+                                                               float *__restrict__ dres, float *__restrict__ dgamma,
+                                                               float *__restrict__ dbeta) {
+  using K = SmallCfg<CH>;
+  constexpr int NU = K::NU, NQ = K::NQ;
+  extern __shared__ double s_dyn[];
+  double *s_red = s_dyn, *s_part = s_dyn + K::RL * K::QN, *s_tot = s_part + 256;
+  const int c4 = threadIdx.x % K::LANES, rl = threadIdx.x / K::LANES;
+  const int c = blockIdx.x * CH + 4 * c4;
+  const int64_t total = n * C;
+  const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c);
+  int64_t off[NU];
+  bool live[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int64_t r = rl + K::RL * u;
+    live[u] = r < n;
+    off[u] = (live[u] ? r : 0) * C + c;
+  }
+  float4 g[NU], xv[NU], yv[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    g[u] = ld4(dy + off[u]);
+    xv[u] = ld4(x + off[u]);
+    yv[u] = yrelu ? ld4(yrelu + off[u]) : make_float4(1, 1, 1, 1);
+  }
+  for (int z = 1; z < nslab; z += NQ) {  // NQ slabs x NU rows in flight
+    float4 t[NQ][NU];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int u = 0; u < NU; ++u) t[q][u] = ld4(dy + (int64_t)(z + q < nslab ? z + q : z) * total + off[u]);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (z + q < nslab) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) g[u].x += t[q][u].x, g[u].y += t[q][u].y, g[u].z += t[q][u].z, g[u].w += t[q][u].w;
+      }
+  }
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (nslab && live[u]) st4(dy_sum + off[u], g[u]);
+    float4 &q = g[u];
+    q.x = yv[u].x > 0.f ? q.x : 0.f, q.y = yv[u].y > 0.f ? q.y : 0.f, q.z = yv[u].z > 0.f ? q.z : 0.f, q.w = yv[u].w > 0.f ? q.w : 0.f;
+    if (live[u]) {
+      s0.x += q.x, s0.y += q.y, s0.z += q.z, s0.w += q.w;
+      s1.x += q.x * (xv[u].x - mu.x) * is.x, s1.y += q.y * (xv[u].y - mu.y) * is.y, s1.z += q.z * (xv[u].z - mu.z) * is.z,
+          s1.w += q.w * (xv[u].w - mu.w) * is.w;
+    }
+  }
+  small_reduce<CH>(s0, s1, c4, rl, s_red, s_part, s_tot);
+  if (threadIdx.x < CH) {
+    const int cc = blockIdx.x * CH + threadIdx.x;
+    dbeta[cc] = (float)s_tot[threadIdx.x];
+    dgamma[cc] = (float)s_tot[CH + threadIdx.x];
+  }
+  const float inv_n = 1.f / (float)n;
+  const float4 db = make_float4((float)s_tot[4 * c4], (float)s_tot[4 * c4 + 1], (float)s_tot[4 * c4 + 2], (float)s_tot[4 * c4 + 3]);
+  const float4 dg = make_float4((float)s_tot[CH + 4 * c4], (float)s_tot[CH + 1 + 4 * c4], (float)s_tot[CH + 2 + 4 * c4], (float)s_tot[CH + 3 + 4 * c4]);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (live[u]) {
+      const float4 q = g[u];
+      if (dres) st4(dres + off[u], q);
+      float4 o;
+      o.x = ga.x * is.x * (q.x - db.x * inv_n - (xv[u].x - mu.x) * is.x * dg.x * inv_n);
+      o.y = ga.y * is.y * (q.y - db.y * inv_n - (xv[u].y - mu.y) * is.y * dg.y * inv_n);
+      o.z = ga.z * is.z * (q.z - db.z * inv_n - (xv[u].z - mu.z) * is.z * dg.z * inv_n);
+      o.w = ga.w * is.w * (q.w - db.w * inv_n - (xv[u].w - mu.w) * is.w * dg.w * inv_n);
+      st4(dx + off[u], o);
+    }
+  }
+}
+
 // y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] )
 __global__ __launch_bounds__(EB) void bn_apply_kernel(const float *__restrict__ x, int64_t n4, int C4,
                                                       const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -228,9 +485,7 @@ __global__ __launch_bounds__(EB) void bn_apply_kernel(const float *__restrict__ 
   for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EB) {
     const int c = (int)(i % C4) * 4;
     const float4 v = ld4(x + 4 * i), mu = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
-    float4 o;
-    o.x = (v.x - mu.x) * is.x * g.x + b.x, o.y = (v.y - mu.y) * is.y * g.y + b.y;
-    o.z = (v.z - mu.z) * is.z * g.z + b.z, o.w = (v.w - mu.w) * is.w * g.w + b.w;
+    float4 o = bn_affine(v, mu, is, g, b);
     if (residual) {
       const float4 r = ld4(residual + 4 * i);
       o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
@@ -259,12 +514,118 @@ __global__ __launch_bounds__(EB) void bn_bwd_apply_kernel(const float *__restric
     if (dres) st4(dres + 4 * i, g);
     const float4 v = ld4(x + 4 * i), mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c),
                  dg = ld4(dgamma + c), db = ld4(dbeta + c);
-    float4 o;
-    o.x = ga.x * is.x * (g.x - db.x * inv_n - (v.x - mu.x) * is.x * dg.x * inv_n);
-    o.y = ga.y * is.y * (g.y - db.y * inv_n - (v.y - mu.y) * is.y * dg.y * inv_n);
-    o.z = ga.z * is.z * (g.z - db.z * inv_n - (v.z - mu.z) * is.z * dg.z * inv_n);
-    o.w = ga.w * is.w * (g.w - db.w * inv_n - (v.w - mu.w) * is.w * dg.w * inv_n);
-    st4(dx + 4 * i, o);
+    st4(dx + 4 * i, bn_dx(g, v, mu, is, ga, dg, db, inv_n));
+  }
+}
+
+// ------------------------------------------------------------------ finalize folded into the consumer
+// mean / invstd (or dgamma / dbeta) from <= kFoldRows partial rows, computed by EVERY workgroup of the apply pass for the 64
+// channels it covers instead of by a launch of its own (5-7 us + a kernel boundary on a chain of ~10 us kernels).  The sums
+// are those of finalize_sums<false>, bit for bit: lane l of a wave there adds rows l, l + 64 in order, then the butterfly
+// over offsets 32, 16, ..., 1 leaves lane 0 with the balanced tree  s1[j] = v[j] + v[j+32], s2[j] = s1[j] + s1[j+16], ...,
+// s6 = s5[0] + s5[1].  Here a lane holds the 32 row sums v[j] of one parity (j = par, par + 2, ...) of one (quantity,
+// channel) column -- 32 independent 8-byte loads -- walks the same tree down to s5[par] and takes s5[par ^ 1] from its
+// partner: one shuffle instead of 768.  Wave w covers channels c0 + 16 w .. + 15 (32 columns x 2 parities = 64 lanes).
+constexpr int kFoldRows = 128;
+__device__ __forceinline__ void fold_sums(const double *__restrict__ partial, int nblk, int C, int c0, double *s_out /* [2][64] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, par = lane >> 5, qty = col >> 4, ch = 16 * wave + (col & 15);
+  const double *p = partial + (int64_t)qty * C + c0 + ch;
+  const int64_t rs = 2 * (int64_t)C;
+  double v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int j = par + 2 * i;
+    double a = 0.0;
+    if (j < nblk) a += p[j * rs];
+    v[i] = a;
+  }
+  if (nblk > 64) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int j = par + 2 * i + 64;
+      if (j < nblk) v[i] += p[j * rs];
+    }
+  }
+#pragma unroll
+  for (int h = 16; h >= 1; h >>= 1)
+#pragma unroll
+    for (int i = 0; i < h; ++i) v[i] = v[i] + v[i + h];
+  const double t = v[0] + __shfl_xor(v[0], 32, 64);
+  if (par == 0) s_out[qty * 64 + ch] = t;
+}
+
+// bn_stats_finalize_kernel + bn_apply_kernel in one launch; grid (row chunks, C / 64)
+__global__ __launch_bounds__(EB) void bn_apply_fold_kernel(const float *__restrict__ x, int64_t n, int C,
+                                                           const double *__restrict__ partial, int nblk, float eps, float momentum,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           const float *__restrict__ residual, int relu, float *__restrict__ y,
+                                                           float *__restrict__ mean, float *__restrict__ invstd, float *running_mean,
+                                                           float *running_var) {
+  __shared__ double s_sum[2 * 64];
+  __shared__ __attribute__((aligned(16))) float s_mu[64], s_is[64];
+  const int c0 = blockIdx.y * 64;
+  fold_sums(partial, nblk, C, c0, s_sum);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = c0 + threadIdx.x;
+    double m;
+    const double var = bn_variance(s_sum[threadIdx.x], s_sum[64 + threadIdx.x], n, m);
+    const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
+    s_mu[threadIdx.x] = mf, s_is[threadIdx.x] = isf;
+    if (blockIdx.x == 0) {
+      mean[c] = mf, invstd[c] = isf;
+      if (running_mean) bn_running_update(running_mean, running_var, c, momentum, mf, var, n);
+    }
+  }
+  __syncthreads();
+  const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = c0 + 4 * c4;
+  const float4 mu = ld4(s_mu + 4 * c4), is = ld4(s_is + 4 * c4), g = ld4(gamma + c), b = ld4(beta + c);
+  for (int64_t row = (int64_t)blockIdx.x * 16 + rl; row < n; row += (int64_t)gridDim.x * 16) {
+    const int64_t o_ = row * C + c;
+    float4 o = bn_affine(ld4(x + o_), mu, is, g, b);
+    if (residual) {
+      const float4 r = ld4(residual + o_);
+      o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
+    }
+    if (relu) o.x = fmaxf(o.x, 0.f), o.y = fmaxf(o.y, 0.f), o.z = fmaxf(o.z, 0.f), o.w = fmaxf(o.w, 0.f);
+    st4(y + o_, o);
+  }
+}
+
+// bn_bwd_finalize_kernel<false> + bn_bwd_apply_kernel in one launch; grid (row chunks, C / 64)
+__global__ __launch_bounds__(EB) void bn_bwd_apply_fold_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                               const float *__restrict__ yrelu, int64_t n, int C, float inv_n,
+                                                               const double *__restrict__ partial, int nblk,
+                                                               const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                               const float *__restrict__ gamma, float *__restrict__ dgamma,
+                                                               float *__restrict__ dbeta, float *__restrict__ dx,
+                                                               float *__restrict__ dres) {
+  __shared__ double s_sum[2 * 64];
+  __shared__ __attribute__((aligned(16))) float s_db[64], s_dg[64];
+  const int c0 = blockIdx.y * 64;
+  fold_sums(partial, nblk, C, c0, s_sum);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float db = (float)s_sum[threadIdx.x], dg = (float)s_sum[64 + threadIdx.x];
+    s_db[threadIdx.x] = db, s_dg[threadIdx.x] = dg;
+    if (blockIdx.x == 0) dbeta[c0 + threadIdx.x] = db, dgamma[c0 + threadIdx.x] = dg;
+  }
+  __syncthreads();
+  const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = c0 + 4 * c4;
+  const float4 mu = ld4(mean + c), is = ld4(invstd + c), ga = ld4(gamma + c), dg = ld4(s_dg + 4 * c4), db = ld4(s_db + 4 * c4);
+  for (int64_t row = (int64_t)blockIdx.x * 16 + rl; row < n; row += (int64_t)gridDim.x * 16) {
+    const int64_t o_ = row * C + c;
+    float4 g = ld4(dy + o_);
+    if (yrelu) {
+      const float4 yv = ld4(yrelu + o_);
+      g.x = yv.x > 0.f ? g.x : 0.f, g.y = yv.y > 0.f ? g.y : 0.f, g.z = yv.z > 0.f ? g.z : 0.f, g.w = yv.w > 0.f ? g.w : 0.f;
+    }
+    if (dres) st4(dres + o_, g);
+    const float4 v = ld4(x + o_);
+    st4(dx + o_, bn_dx(g, v, mu, is, ga, dg, db, inv_n));
   }
 }
 
@@ -626,6 +987,33 @@ int mink_bn_apply(const float *x, int64_t n, int32_t C, const float *mean, const
   return MINK_OK;
 }
 
+int mink_bn_set_fold(int32_t max_rows) {
+  const int old = g_bn_fold;
+  g_bn_fold = max_rows < 0 ? 0 : (max_rows > kFoldRows ? kFoldRows : max_rows);
+  return old;
+}
+
+int mink_bn_apply_from_partials(const float *x, int64_t n, int32_t C, const double *partial, int32_t rows, float eps, float momentum,
+                                const float *gamma, const float *beta, const float *residual, int32_t relu, float *y, float *mean,
+                                float *invstd, float *running_mean, float *running_var, void *stream) {
+  REQ_C4(C, "bn_apply_from_partials");
+  MINK_REQUIRE(partial && rows >= 1 && n >= 1 && x && gamma && beta && y && mean && invstd, "bn_apply_from_partials: bad arguments");
+  MINK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_apply_from_partials: running stats must come in pairs");
+  REQ_A16(x, "bn_apply_from_partials");
+  REQ_A16(y, "bn_apply_from_partials");
+  REQ_A16(residual, "bn_apply_from_partials");
+  if (rows <= g_bn_fold && (C & 63) == 0) {
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 64), 512 / (C / 64)));
+    bn_apply_fold_kernel<<<dim3(gx, (unsigned)(C / 64)), EB, 0, (hipStream_t)stream>>>(x, n, C, partial, rows, eps, momentum, gamma, beta, residual,
+                                                                                  relu, y, mean, invstd, running_mean, running_var);
+    MINK_CHECK_LAUNCH();
+    return MINK_OK;
+  }
+  int rc = mink_bn_stats_from_partials(partial, rows, n, C, eps, momentum, mean, invstd, running_mean, running_var, stream);
+  if (rc) return rc;
+  return mink_bn_apply(x, n, C, mean, invstd, gamma, beta, residual, relu, y, stream);
+}
+
 int mink_bn_fwd(const float *x, int64_t n, int32_t C, float eps, float momentum, const float *gamma, const float *beta,
                 const float *residual, int32_t relu, float *y, float *mean, float *invstd, float *running_mean,
                 float *running_var, void *workspace, int64_t workspace_bytes, void *stream) {
@@ -656,11 +1044,86 @@ int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int3
   int nblk = 0;
   int rc = launch_colreduce(1, dy, x, yr, n, C, mean, invstd, (double *)workspace, st, &nblk);
   if (rc) return rc;
+  if (nblk <= g_bn_fold && (C & 63) == 0) {  // the finalize runs inside the apply pass
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 64), 512 / (C / 64)));
+    bn_bwd_apply_fold_kernel<<<dim3(gx, (unsigned)(C / 64)), EB, 0, st>>>(dy, x, yr, n, C, 1.f / (float)n, (const double *)workspace, nblk,
+                                                                         mean, invstd, gamma, dgamma, dbeta, dx, dresidual);
+    MINK_CHECK_LAUNCH();
+    return MINK_OK;
+  }
   launch_bwd_finalize((const double *)workspace, nblk, C, gamma, dgamma, dbeta, st);
   MINK_CHECK_LAUNCH();
   const int64_t n4 = n * (C >> 2);
   bn_bwd_apply_kernel<<<dim3(ew_grid(n4)), EB, 0, st>>>(dy, x, yr, n4, C >> 2, 1.f / (float)n, mean, invstd, gamma,
                                                        dgamma, dbeta, dx, dresidual);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+constexpr int kSmallSmem = (1024 / 4 * 32 + 256 + 32) * (int)sizeof(double);  // RL x QN is 8192 doubles for both channel widths
+static int g_small_ch = 0;  // 0: by channel count (8 below 512 channels); 8 / 16: forced (mink_bn_set_small(8 | 16))
+static bool small_attrs() {
+  bool ok = true;
+  ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&bn_small_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSmem) == hipSuccess;
+  ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&bn_small_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSmem) == hipSuccess;
+  ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&bn_small_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSmem) == hipSuccess;
+  ok &= hipFuncSetAttribute(reinterpret_cast<const void *>(&bn_small_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallSmem) == hipSuccess;
+  return ok;
+}
+static int small_width(int C) { return g_small_ch ? g_small_ch : (C >= 1024 ? 16 : 8); }
+
+int32_t mink_bn_small_rows(void) { return g_bn_small ? kSmallRows : 0; }
+
+int mink_bn_set_small(int32_t on) {
+  const int old = g_bn_small ? (g_small_ch ? g_small_ch : 1) : 0;
+  g_bn_small = on != 0;
+  g_small_ch = (on == 8 || on == 16) ? on : 0;
+  return old;
+}
+
+int mink_bn_small_fwd(const float *slabs, int32_t nslab, int64_t n, int32_t C, float *y, float eps, float momentum,
+                      const float *gamma, const float *beta, const float *residual, int32_t relu, float *out, float *mean,
+                      float *invstd, float *running_mean, float *running_var, void *stream) {
+  MINK_REQUIRE(n >= 1 && n <= kSmallRows && C >= 16 && C % 16 == 0, "bn_small_fwd: %lld rows x %d channels not supported",
+               (long long)n, C);
+  MINK_REQUIRE(y && gamma && beta && out && mean && invstd && nslab >= 0 && (nslab == 0 || slabs), "bn_small_fwd: bad arguments");
+  MINK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_small_fwd: running stats must come in pairs");
+  REQ_A16(y, "bn_small_fwd");
+  REQ_A16(out, "bn_small_fwd");
+  REQ_A16(slabs, "bn_small_fwd");
+  REQ_A16(residual, "bn_small_fwd");
+  static const bool attr_ok = small_attrs();
+  MINK_REQUIRE(attr_ok, "bn_small: %d bytes of LDS per workgroup refused", kSmallSmem);
+  if (small_width(C) == 16)
+    bn_small_fwd_kernel<16><<<dim3((unsigned)(C / 16)), kSmallT, kSmallSmem, (hipStream_t)stream>>>(
+        slabs, nslab, n, C, y, eps, momentum, gamma, beta, residual, relu, out, mean, invstd, running_mean, running_var);
+  else
+    bn_small_fwd_kernel<8><<<dim3((unsigned)(C / 8)), kSmallT, kSmallSmem, (hipStream_t)stream>>>(
+        slabs, nslab, n, C, y, eps, momentum, gamma, beta, residual, relu, out, mean, invstd, running_mean, running_var);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_bn_small_bwd(const float *dy, int32_t nslab, float *dy_sum, const float *x, const float *y, int64_t n, int32_t C,
+                      const float *mean, const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual,
+                      float *dgamma, float *dbeta, void *stream) {
+  MINK_REQUIRE(n >= 1 && n <= kSmallRows && C >= 16 && C % 16 == 0, "bn_small_bwd: %lld rows x %d channels not supported",
+               (long long)n, C);
+  MINK_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && nslab >= 0 && (nslab == 0 || dy_sum), "bn_small_bwd: bad arguments");
+  MINK_REQUIRE(!relu || y, "bn_small_bwd: fused ReLU needs the forward output");
+  REQ_A16(dy, "bn_small_bwd");
+  REQ_A16(x, "bn_small_bwd");
+  REQ_A16(dx, "bn_small_bwd");
+  REQ_A16(dy_sum, "bn_small_bwd");
+  REQ_A16(dresidual, "bn_small_bwd");
+  static const bool attr_ok = small_attrs();
+  MINK_REQUIRE(attr_ok, "bn_small: %d bytes of LDS per workgroup refused", kSmallSmem);
+  if (small_width(C) == 16)
+    bn_small_bwd_kernel<16><<<dim3((unsigned)(C / 16)), kSmallT, kSmallSmem, (hipStream_t)stream>>>(
+        dy, nslab, dy_sum, x, relu ? y : nullptr, n, C, mean, invstd, gamma, dx, dresidual, dgamma, dbeta);
+  else
+    bn_small_bwd_kernel<8><<<dim3((unsigned)(C / 8)), kSmallT, kSmallSmem, (hipStream_t)stream>>>(
+        dy, nslab, dy_sum, x, relu ? y : nullptr, n, C, mean, invstd, gamma, dx, dresidual, dgamma, dbeta);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

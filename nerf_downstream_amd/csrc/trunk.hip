@@ -54,9 +54,18 @@ MinkStageHook g_stage_hook = nullptr;  // test / timeline instrumentation betwee
     if (rc_) return rc_; \
   } while (0)
 
-// y = conv(x) and the batch statistics of y (from the convolution's own epilogue when the launch shape allows)
+struct ConvOut {
+  float *slabs = nullptr;
+  int32_t nslab = 0;           // > 1: `slabs` holds that many partial sums of y (few-row layers)
+  bool small = false;
+  const double *partial = nullptr;  // column (sum, sum of squares) partials of y, `rows` of them (0: mean / invstd are final)
+  int32_t rows = 0;
+};
+
+// y = conv(x) and the column partials of y for the batch norm that follows (from the convolution's own epilogue or split-K
+// reduce when the launch shape allows: co.rows > 0, finalized by the norm's apply pass; else mean / invstd are computed here)
 int conv_stats(const MinkConvLayer &c, const MinkNormLayer &nm, const float *x, int64_t n_in, int64_t n_out, float *y, void *ws_base,
-               int64_t ws_bytes, hipStream_t st) {
+               int64_t ws_bytes, hipStream_t st, ConvOut &co) {
   Scratch ws(ws_base, ws_bytes);
   const int ksplit = mink_conv_plan(n_out, c.K, c.cin, c.cout, 0);
   const int64_t slab_bytes = ksplit > 1 ? 4ll * ksplit * n_out * c.cout : 0, stats_bytes = mink_conv_stats_workspace_bytes(n_out, c.cout);
@@ -68,14 +77,42 @@ int conv_stats(const MinkConvLayer &c, const MinkNormLayer &nm, const float *x, 
   int32_t rows = 0;
   TRY(mink_conv_gather_gemm_stats(x, n_in, c.cin, c.cin, c.w, c.nbr, n_out, c.K, y, c.cout, c.cout, nullptr, ksplit, slabs, slab_bytes,
                                   partial, &rows, stats_ws, stats_bytes, st));
+  co.partial = partial, co.rows = rows;
+  if (rows > 0) return MINK_OK;
   const float mom = nm.running_mean ? nm.momentum : 0.f;
-  if (rows > 0)
-    return mink_bn_stats_from_partials(partial, rows, n_out, c.cout, nm.eps, mom, nm.mean, nm.invstd, nm.running_mean,
-                                       nm.running_var, st);
   const int64_t bn_bytes = mink_bn_workspace_bytes(n_out, c.cout);
   void *bn_ws = ws.take(bn_bytes);
   MINK_REQUIRE(bn_ws, "block: scratch too small for batch-norm statistics");
   return mink_bn_stats(y, n_out, c.cout, nm.eps, mom, nm.mean, nm.invstd, nm.running_mean, nm.running_var, bn_ws, bn_bytes, st);
+}
+
+// Few-row layers (mink_bn_small_rows): the convolution leaves its split-K slabs and ONE launch sums them, takes the
+// statistics and applies norm + residual + ReLU -- two launches per convolution + norm instead of four.
+bool small_layer(int64_t n_out, int cout) { return n_out <= mink_bn_small_rows() && cout % 16 == 0; }
+
+// the convolution of a conv + norm pair (and, on the general path, the statistics and their finalize)
+int conv_for_norm(const MinkConvLayer &c, const MinkNormLayer &nm, const float *x, int64_t n_in, int64_t n_out, float *y, void *ws_base,
+                  int64_t ws_bytes, hipStream_t st, ConvOut &co) {
+  co.small = small_layer(n_out, c.cout);
+  if (!co.small) return conv_stats(c, nm, x, n_in, n_out, y, ws_base, ws_bytes, st, co);
+  Scratch ws(ws_base, ws_bytes);
+  const int ksplit = mink_conv_plan(n_out, c.K, c.cin, c.cout, 0);
+  const int64_t slab_bytes = ksplit > 1 ? 4ll * ksplit * n_out * c.cout : 0;
+  co.slabs = ksplit > 1 ? (float *)ws.take(slab_bytes) : nullptr;
+  MINK_REQUIRE(ksplit == 1 || co.slabs, "block: scratch too small for a %lld x %d convolution", (long long)n_out, c.cout);
+  return mink_conv_gather_gemm_slabs(x, n_in, c.cin, c.cin, c.w, 0, 0, c.nbr, n_out, c.K, nullptr, 0, y, c.cout, c.cout, ksplit, co.slabs,
+                                     slab_bytes, &co.nslab, st);
+}
+
+// out = act(norm(y) [+ residual]) behind conv_for_norm
+int norm_act(const MinkNormLayer &nm, int64_t n_out, int C, float *y, const float *residual, int relu, float *out, const ConvOut &co,
+             hipStream_t st) {
+  if (!co.small && co.rows > 0)  // (the statistics' finalize runs inside the apply pass when the partial rows are few)
+    return mink_bn_apply_from_partials(y, n_out, C, co.partial, co.rows, nm.eps, nm.running_mean ? nm.momentum : 0.f, nm.gamma, nm.beta, residual,
+                                       relu, out, nm.mean, nm.invstd, nm.running_mean, nm.running_var, st);
+  if (!co.small) return mink_bn_apply(y, n_out, C, nm.mean, nm.invstd, nm.gamma, nm.beta, residual, relu, out, st);
+  return mink_bn_small_fwd(co.slabs, co.nslab > 1 ? co.nslab : 0, n_out, C, y, nm.eps, nm.running_mean ? nm.momentum : 0.f, nm.gamma, nm.beta,
+                           residual, relu, out, nm.mean, nm.invstd, nm.running_mean, nm.running_var, st);
 }
 
 struct Lane {  // a stream and what is left of its scratch buffer
@@ -87,8 +124,10 @@ struct Lane {  // a stream and what is left of its scratch buffer
 
 // gy (complete on data.st) -> dW on weight.st, dX (optional) on data.st
 // (ev_slot < 0: the caller has already ordered weight.st after gy)
+// gx_slabs (stride-1 convolutions only): leave the data gradient as split-K slabs for the caller's next kernel
+// (mink_bn_small_bwd sums them); gx_slabs->nslab <= 1 on return means gx is complete as usual
 int conv_backward(const MinkConvLayer &c, const float *x, int64_t n_in, int64_t n_out, const float *gy, float *gx, Lane data,
-                  Lane weight, int ev_slot) {
+                  Lane weight, int ev_slot, ConvOut *gx_slabs = nullptr) {
   if (ev_slot >= 0) TRY(order_after(weight.st, data.st, ev_slot));
   {
     Scratch ws(weight.ws, weight.bytes);
@@ -104,6 +143,11 @@ int conv_backward(const MinkConvLayer &c, const float *x, int64_t n_in, int64_t 
     const int64_t slab_bytes = ksplit > 1 ? 4ll * ksplit * n_out * c.cin : 0;
     float *slabs = ksplit > 1 ? (float *)ws.take(slab_bytes) : nullptr;
     MINK_REQUIRE(ksplit == 1 || slabs, "block: data-gradient scratch too small");
+    if (gx_slabs) {
+      gx_slabs->slabs = slabs;
+      return mink_conv_gather_gemm_slabs(gy, n_out, c.cout, c.cout, c.w, 1, 1, c.nbr, n_out, c.K, nullptr, 0, gx, c.cin, c.cin, ksplit,
+                                         slabs, slab_bytes, &gx_slabs->nslab, data.st);
+    }
     return mink_conv_gather_gemm(gy, n_out, c.cout, c.cout, c.w, 1, 1, c.nbr, n_out, c.K, nullptr, 0, gx, c.cin, c.cin, nullptr,
                                  ksplit, slabs, slab_bytes, data.st);
   }
@@ -199,7 +243,11 @@ int mink_stem_forward(const MinkStem *s, const MinkExec *ex) {
     return mink_bn_relu_pool_fwd_b16(s->y, c.cout, s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta, s->nbr_pool, s->n_pool, 8,
                                      s->out, st);
   }
-  TRY(conv_stats(s->conv, s->norm, s->x, s->n, s->n, s->y, ex->ws_compute, ex->ws_bytes, st));
+  ConvOut co;
+  TRY(conv_stats(s->conv, s->norm, s->x, s->n, s->n, s->y, ex->ws_compute, ex->ws_bytes, st, co));
+  if (co.rows > 0)
+    TRY(mink_bn_stats_from_partials(co.partial, co.rows, s->n, s->conv.cout, s->norm.eps, s->norm.running_mean ? s->norm.momentum : 0.f,
+                                    s->norm.mean, s->norm.invstd, s->norm.running_mean, s->norm.running_var, st));
   return mink_bn_relu_pool_fwd(s->y, s->conv.cout, s->norm.mean, s->norm.invstd, s->norm.gamma, s->norm.beta, s->nbr_pool,
                                s->n_pool, 8, s->out, st);
 }
@@ -250,15 +298,17 @@ int mink_block_forward(const MinkBasicBlock *b, const MinkExec *ex) {
     TRY(check_norm(b->normd, "block_forward downsample norm", false));
     MINK_REQUIRE(b->yd && b->sd && b->down.cout == C && b->down.cin == b->conv1.cin, "block_forward: bad downsample path");
     TRY(order_after(br, st, 0));  // x is ready
-    TRY(conv_stats(b->down, b->normd, b->x, b->n_in, b->n_out, b->yd, br == st ? ex->ws_compute : ex->ws_branch, ex->ws_bytes, br));
-    TRY(mink_bn_apply(b->yd, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, b->normd.beta, nullptr, 0, b->sd, br));
+    ConvOut cd;
+    TRY(conv_for_norm(b->down, b->normd, b->x, b->n_in, b->n_out, b->yd, br == st ? ex->ws_compute : ex->ws_branch, ex->ws_bytes, br, cd));
+    TRY(norm_act(b->normd, b->n_out, C, b->yd, nullptr, 0, b->sd, cd, br));
     shortcut = b->sd;
   }
-  TRY(conv_stats(b->conv1, b->norm1, b->x, b->n_in, b->n_out, b->y1, ex->ws_compute, ex->ws_bytes, st));
-  TRY(mink_bn_apply(b->y1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, b->norm1.beta, nullptr, 1, b->h1, st));
-  TRY(conv_stats(b->conv2, b->norm2, b->h1, b->n_out, b->n_out, b->y2, ex->ws_compute, ex->ws_bytes, st));
+  ConvOut c1, c2;
+  TRY(conv_for_norm(b->conv1, b->norm1, b->x, b->n_in, b->n_out, b->y1, ex->ws_compute, ex->ws_bytes, st, c1));
+  TRY(norm_act(b->norm1, b->n_out, C, b->y1, nullptr, 1, b->h1, c1, st));
+  TRY(conv_for_norm(b->conv2, b->norm2, b->h1, b->n_out, b->n_out, b->y2, ex->ws_compute, ex->ws_bytes, st, c2));
   if (down) TRY(order_after(st, br, 1));
-  return mink_bn_apply(b->y2, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, b->norm2.beta, shortcut, 1, b->out, st);
+  return norm_act(b->norm2, b->n_out, C, b->y2, shortcut, 1, b->out, c2, st);
 }
 
 int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
@@ -283,9 +333,14 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
   const int64_t bn_bytes = mink_bn_workspace_bytes(b->n_out, C);
   MINK_REQUIRE(ex->ws_compute && ex->ws_bytes > 2 * bn_bytes + 256, "block_backward: scratch too small");
   const bool want_gx = b->g_x != nullptr;
+  const bool small = small_layer(b->n_out, C);
   // out = relu(norm2(y2) + shortcut)
-  TRY(mink_bn_bwd(b->g_out, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, 1, g_y2, g_res,
-                  b->norm2.dgamma, b->norm2.dbeta, compute.ws, bn_bytes, st));
+  if (small)
+    TRY(mink_bn_small_bwd(b->g_out, 0, nullptr, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, 1, g_y2, g_res,
+                          b->norm2.dgamma, b->norm2.dbeta, st));
+  else
+    TRY(mink_bn_bwd(b->g_out, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, 1, g_y2, g_res,
+                    b->norm2.dgamma, b->norm2.dbeta, compute.ws, bn_bytes, st));
   // ONE event on the compute stream hands g_y2 / g_res to both auxiliary streams (every event record or wait on the
   // compute stream is a barrier packet in the chain of small dependent kernels)
   const bool aux = wst != st || (down && br != st);
@@ -300,8 +355,12 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
     if (br != st) MINK_HIP(hipStreamWaitEvent(br, g_ev[2], 0));
     // (on one stream the branch shares the compute scratch: its batch-norm partials sit behind the main chain's)
     const Lane bl = br == st ? branch.after(bn_bytes) : branch;
-    TRY(mink_bn_bwd(g_res, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
-                    b->normd.dgamma, b->normd.dbeta, bl.ws, bn_bytes, br));
+    if (small)
+      TRY(mink_bn_small_bwd(g_res, 0, nullptr, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
+                            b->normd.dgamma, b->normd.dbeta, br));
+    else
+      TRY(mink_bn_bwd(g_res, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
+                      b->normd.dgamma, b->normd.dbeta, bl.ws, bn_bytes, br));
     const Lane rest_b = bl.after(bn_bytes);
     if (want_gx) {
       // The shortcut convolution (kernel volume 1, stride 2) reaches only the input voxels that sit on an output
@@ -314,9 +373,17 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
     TRY(conv_backward(b->down, b->x, b->n_in, b->n_out, g_yd, nullptr, rest_b, weight, br == wst ? -1 : 3));
   }
   const Lane rest = compute.after(2 * bn_bytes);
-  TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, -1));
-  TRY(mink_bn_bwd(g_h1, b->y1, b->h1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr,
-                  b->norm1.dgamma, b->norm1.dbeta, compute.ws, bn_bytes, st));
+  if (small) {  // conv2's data gradient stays in its split-K slabs: norm1's one-launch backward sums them on the way in
+    ConvOut gs;
+    TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, -1, &gs));
+    const bool sl = gs.nslab > 1;
+    TRY(mink_bn_small_bwd(sl ? gs.slabs : g_h1, sl ? gs.nslab : 0, sl ? g_h1 : nullptr, b->y1, b->h1, b->n_out, C, b->norm1.mean,
+                          b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr, b->norm1.dgamma, b->norm1.dbeta, st));
+  } else {
+    TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, -1));
+    TRY(mink_bn_bwd(g_h1, b->y1, b->h1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr,
+                    b->norm1.dgamma, b->norm1.dbeta, compute.ws, bn_bytes, st));
+  }
   TRY(conv_backward(b->conv1, b->x, b->n_in, b->n_out, g_y1, want_gx ? (down ? b->g_x : g_xa) : nullptr, rest, weight, 5));
   if (!want_gx) return MINK_OK;
   if (!down) return mink_eltwise(g_xa, g_res, ni, 2, b->g_x, st);

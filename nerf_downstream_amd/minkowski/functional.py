@@ -298,6 +298,18 @@ def _side_stream(device):
     return s
 
 
+def set_bn_small(on=True):
+    """Few-row layers of the native trunk: the one-launch batch norm + split-K sum (mink_bn_small_fwd / _bwd; csrc/
+    elementwise.hip).  Off: the trunk sequences exactly the kernels of the module-by-module path (the bitwise tests)."""
+    return bool(lib().mink_bn_set_small(1 if on else 0))
+
+
+def set_bn_fold(max_rows=32):
+    """Batch-norm finalize inside the apply pass (mink_bn_apply_from_partials, mink_bn_bwd) when the producer left at most
+    `max_rows` partial rows (0: never; at most 128).  Returns the previous limit."""
+    return int(lib().mink_bn_set_fold(int(max_rows)))
+
+
 def set_wgrad_overlap(on=True):
     global _OVERLAP_WGRAD
     old, _OVERLAP_WGRAD = _OVERLAP_WGRAD, bool(on)
@@ -643,6 +655,17 @@ class BatchNormFunction(torch.autograd.Function):
                     x.data_ptr(), n, C, eps, momentum if running_mean is not None else 0.0, gamma.data_ptr(), beta.data_ptr(),
                     _ptr(residual), int(relu), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
                     _ptr(running_var), ws.data_ptr(), ws.numel(), _stream(),
+                )
+            )
+        elif training and partial is not None:
+            # statistics partials from the producing convolution: finalize + apply, one launch when the partial rows are few
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            invstd = torch.empty(C, dtype=torch.float32, device=dev)
+            check(
+                L.mink_bn_apply_from_partials(
+                    x.data_ptr(), n, C, partial.data_ptr(), partial.shape[0], eps, momentum if running_mean is not None else 0.0,
+                    gamma.data_ptr(), beta.data_ptr(), _ptr(residual), int(relu), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                    _ptr(running_mean), _ptr(running_var), _stream(),
                 )
             )
         else:

@@ -9,10 +9,14 @@ import sys
 d, steps = sys.argv[1], int(sys.argv[2])
 f = (glob.glob(f"{d}/*/*kernel_trace.csv") + glob.glob(f"{d}/*kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
-ends = [int(r["End_Timestamp"]) for r in rows if "wgrad_stream" in r["Kernel_Name"]]
-if ends and steps == 0:  # bench.py trace: count the training steps and drop the forward-only phase after them
-    steps = len(ends)
-    rows = [r for r in rows if int(r["Start_Timestamp"]) <= max(ends)]
+marks = sorted(int(r["Start_Timestamp"]) for r in rows if "wgrad_stream" in r["Kernel_Name"])
+if marks and steps == 0:
+    # bench.py trace: the steady-state window scripts/stream_busy.py uses -- the last (up to) 8 training steps, delimited by the
+    # stem weight-gradient kernel (the last kernel of every backward pass); warm-up steps (event timing on, map plans still being
+    # recorded: ~55 more launches per step) and the forward-only phase after the timed region are left out
+    steps = min(8, len(marks) - 1)
+    t0, t1 = marks[-1 - steps], marks[-1]
+    rows = [r for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
 agg = collections.defaultdict(list)
 for r in rows:
     name = r["Kernel_Name"].split("(")[0][:46]

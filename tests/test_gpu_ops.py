@@ -123,6 +123,112 @@ def test_batch_norm(C, relu, res):
     assert torch.allclose(ye.cpu(), ref(x), atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("n,C,nslab,relu,res", [(1, 16, 0, True, False), (63, 64, 3, True, True), (512, 512, 14, True, False),
+                                                (1024, 128, 1, False, True), (777, 256, 5, True, True), (300, 48, 0, False, False)])
+def test_one_launch_batch_norm_of_few_row_layers(n, C, nslab, relu, res):
+    """mink_bn_small_fwd / _bwd (the native trunk's layers below 1,024 rows: split-K slab sum + statistics + norm + residual +
+    ReLU in one launch; backward likewise) against torch.nn.BatchNorm1d in float64 on the same values -- ragged row counts,
+    one row (variance 0), channel counts that are not multiples of 64, slabs and no slabs."""
+    from nerf_downstream_amd._lib import check, lib
+
+    L = lib()
+    assert L.mink_bn_small_rows() == 1024
+    torch.manual_seed(n + C)
+    dev = torch.device("cuda", 0)
+    slabs = (torch.randn(max(nslab, 1), n, C) * 1.5 + 0.2).to(dev)
+    y = slabs[0].clone() if nslab == 0 else torch.empty(n, C, device=dev)
+    gamma, beta = torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) - 0.5
+    r = torch.randn(n, C, device=dev) if res else None
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    out, mean, invstd = torch.empty(n, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    check(L.mink_bn_small_fwd(slabs.data_ptr() if nslab else None, nslab, n, C, y.data_ptr(), 1e-5, 0.1, gamma.data_ptr(), beta.data_ptr(),
+                              r.data_ptr() if res else None, int(relu), out.data_ptr(), mean.data_ptr(), invstd.data_ptr(), rm.data_ptr(),
+                              rv.data_ptr(), st))
+    y64 = (slabs[:max(nslab, 1)].double().sum(0) if nslab else slabs[0].double()).cpu().requires_grad_(True)
+    assert torch.allclose(y.cpu().double(), y64.detach(), atol=1e-5, rtol=1e-6)
+    ref = torch.nn.BatchNorm1d(C).double()
+    with torch.no_grad():
+        ref.weight.copy_(gamma.cpu().double()), ref.bias.copy_(beta.cpu().double())
+    if n == 1:  # torch refuses one row in training mode; the kernels follow the formula (variance 0)
+        z = (y64 - y64.mean(0)) / torch.sqrt(y64.var(0, unbiased=False) + 1e-5) * ref.weight + ref.bias
+    else:
+        z = ref(y64)
+    rc = r.cpu().double().requires_grad_(True) if res else None
+    if res:
+        z = z + rc
+    if relu:
+        z = torch.relu(z)
+    assert torch.allclose(out.cpu().double(), z.detach(), atol=2e-5, rtol=1e-5)
+    assert torch.allclose(mean.cpu().double(), y64.detach().mean(0), atol=1e-5)
+    if n > 1:
+        assert torch.allclose(rm.cpu().double(), ref.running_mean, atol=1e-6) and torch.allclose(rv.cpu().double(), ref.running_var, atol=1e-5)
+    # backward: the incoming gradient as `nslab` slabs too
+    gsl = torch.randn(max(nslab, 1), n, C, device=dev)
+    g_sum = torch.empty(n, C, device=dev)
+    dx, dres = torch.empty(n, C, device=dev), (torch.empty(n, C, device=dev) if res else None)
+    dgamma, dbeta = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    check(L.mink_bn_small_bwd(gsl.data_ptr(), nslab, g_sum.data_ptr() if nslab else None, y.data_ptr(), out.data_ptr(), n, C, mean.data_ptr(),
+                              invstd.data_ptr(), gamma.data_ptr(), int(relu), dx.data_ptr(), dres.data_ptr() if res else None,
+                              dgamma.data_ptr(), dbeta.data_ptr(), st))
+    g64 = gsl[:max(nslab, 1)].double().sum(0).cpu() if nslab else gsl[0].double().cpu()
+    if nslab:
+        assert torch.allclose(g_sum.cpu().double(), g64, atol=1e-5)
+    z.backward(g64)
+    scale = float(y64.grad.abs().max()) + 1e-12
+    assert float((dx.cpu().double() - y64.grad).abs().max()) < 2e-4 * max(scale, 1.0)
+    if n > 1:
+        assert torch.allclose(dgamma.cpu().double(), ref.weight.grad, atol=2e-3, rtol=1e-4)
+    assert torch.allclose(dbeta.cpu().double(), ref.bias.grad, atol=2e-3, rtol=1e-4)
+    if res:
+        assert torch.allclose(dres.cpu().double(), rc.grad, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,C,rows", [(2128, 256, 67), (8432, 128, 128), (512, 512, 16), (37056, 64, 128), (100, 64, 1), (3000, 192, 100)])
+def test_batch_norm_finalize_inside_the_apply_pass_is_bitwise(n, C, rows):
+    """mink_bn_apply_from_partials / mink_bn_bwd with the finalize folded into the apply pass (one launch less each, <= 128
+    partial rows) against the separate launches (mink_bn_set_fold(0)): outputs, statistics, running statistics and parameter
+    gradients equal BIT FOR BIT -- every workgroup re-derives the sums in the finalize kernel's own order."""
+    from nerf_downstream_amd._lib import check, lib
+
+    L = lib()
+    torch.manual_seed(rows + C)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    x = (torch.randn(n, C) * 1.3 + 0.4).to(dev)
+    part = torch.zeros(rows, 2, C, dtype=torch.float64, device=dev)
+    for r in range(rows):  # genuine partials of x over interleaved rows
+        xs = x[r::rows].double()
+        part[r, 0], part[r, 1] = xs.sum(0), (xs * xs).sum(0)
+    gamma, beta = torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) - 0.5
+    res = torch.randn(n, C, device=dev)
+    outs = {}
+    for fold in (0, 128):  # (0: separate launches; 128: folded up to 128 partial rows, the most fold_sums takes)
+        old = L.mink_bn_set_fold(fold)
+        try:
+            y, mean, invstd = torch.empty(n, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            check(L.mink_bn_apply_from_partials(x.data_ptr(), n, C, part.data_ptr(), rows, 1e-5, 0.1, gamma.data_ptr(), beta.data_ptr(), res.data_ptr(),
+                                                1, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), st))
+            gy = torch.randn(n, C, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+            dx, dres = torch.empty(n, C, device=dev), torch.empty(n, C, device=dev)
+            dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+            ws = torch.empty(L.mink_bn_workspace_bytes(n, C), dtype=torch.uint8, device=dev)
+            check(L.mink_bn_bwd(gy.data_ptr(), x.data_ptr(), y.data_ptr(), n, C, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), 1,
+                                dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st))
+            torch.cuda.synchronize()
+            outs[fold] = (y, mean, invstd, rm, rv, dx, dres, dg, db)
+        finally:
+            L.mink_bn_set_fold(old)
+    for k, (a, b) in enumerate(zip(outs[0], outs[128])):
+        assert torch.equal(a, b), k
+    ref = torch.nn.BatchNorm1d(C).double()
+    with torch.no_grad():
+        ref.weight.copy_(gamma.cpu().double()), ref.bias.copy_(beta.cpu().double())
+    z = torch.relu(ref(x.cpu().double()) + res.cpu().double())
+    assert torch.allclose(outs[128][0].cpu().double(), z, atol=2e-5, rtol=1e-5)
+
+
 def test_relu_add_pool_globalavg(oracle_maps):
     ME, OME, tf, otf = _pair([8, 9, 10], 24, 8, negative=True)
     x, ox = tf.sparse(), otf.sparse()

@@ -185,10 +185,11 @@ def test_native_trunk_is_bitwise_the_module_path(oracle_maps, name, cin, seeds):
     batch = {"coordinates": coords.cuda(), "features": feats.cuda()}
     labels = (torch.arange(len(seeds)) * 7 + 1).cuda() % 51
 
-    def run(native, overlap):
+    def run(native, overlap, small=False):
         hip, _ = _models(name, cin, 51)
         hip._native_trunk = native
         old = Fn.set_wgrad_overlap(overlap)
+        old_small = Fn.set_bn_small(small)  # (off: the trunk sequences exactly the module path's kernels)
         try:
             outs = []
             for _ in range(2):  # second pass: the map plan of the first is replayed ahead (prepared manager -> forked shortcut)
@@ -200,6 +201,7 @@ def test_native_trunk_is_bitwise_the_module_path(oracle_maps, name, cin, seeds):
             torch.cuda.synchronize()
         finally:
             Fn.set_wgrad_overlap(old)
+            Fn.set_bn_small(old_small)
         return outs, {k: p.grad.clone() for k, p in hip.named_parameters()}, {k: b.clone() for k, b in hip.named_buffers()}, used
 
     ref_out, ref_g, ref_b, used = run(False, False)
@@ -212,6 +214,20 @@ def test_native_trunk_is_bitwise_the_module_path(oracle_maps, name, cin, seeds):
             assert torch.equal(g[k], ref_g[k]), (overlap, k)
         for k in ref_b:
             assert torch.equal(b[k], ref_b[k]), (overlap, k)
+    # the trunk as it runs by default: below 1,024 rows a layer's batch norm is ONE launch that also sums the convolution's
+    # split-K slabs (mink_bn_small_fwd / _bwd) -- another summation order, so equal to rounding, not bit for bit; and the
+    # same with and without the stream overlaps, bit for bit
+    outs_s, g_s, b_s, plan = run(True, True, small=True)
+    outs_1, g_1, b_1, _ = run(True, False, small=True)
+    assert plan
+    assert all(torch.equal(a, c) for a, c in zip(outs_s, outs_1)) and all(torch.equal(g_s[k], g_1[k]) for k in g_s)
+    scale = float(ref_out[-1].abs().max())
+    assert float((outs_s[-1] - ref_out[-1]).abs().max()) < 2e-5 * max(scale, 1.0), float((outs_s[-1] - ref_out[-1]).abs().max())
+    for k in ref_g:
+        err = float((g_s[k] - ref_g[k]).norm() / ref_g[k].norm().clamp_min(1e-20))
+        assert err < 2e-4, (k, err)  # (a ReLU input at zero to rounding may take the other branch: test_gpu_parity_full.py)
+    for k in ref_b:
+        assert torch.allclose(b_s[k].float(), ref_b[k].float(), rtol=1e-4, atol=1e-6), k
 
 
 def test_native_trunk_follows_replaced_parameters(oracle_maps):
