@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const unsigned w_ = a < 4 ? kl0 : a < 8 ? kl1 : kl2;
       return (int)((w_ >> (8 * (a & 3))) & 255u);
     };
-    const int n_items = na * ncc;
+    const int n_items = (p.stagger & 4) ? 0 : na * ncc;  // (bit 2, timing only: prologue and epilogue alone)
 
     int g_ka = 0, g_cc = 0;  // iterator of the global-load stage
     // every call issues the same NA + (W_T ? 2 : 8) loads, whatever the item: the vmcnt distances of the ring are static
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const int c0 = (cbeg + g_cc) * BK;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const float *src = xcol + (int64_t)s_src[j * CM + a_r + 32 * i] * p.ldx + c0;
+        const float *src = xcol + (int64_t)((p.stagger & 16) ? 0 : s_src[j * CM + a_r + 32 * i]) * p.ldx + c0;  // (bit 16, timing only: every gather reads row 0)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ga[slot][i]) : "v"(src));
       }
     };
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const int kw = p.flip_k ? K - 1 - k : k;
       const int c0 = (cbeg + g_cc) * BK;
       if constexpr (!W_T) {
-        const int so = 4 * ((kw * p.cin + c0) * p.cout + n0);
+        const int so = (p.stagger & 8) ? 0 : 4 * ((kw * p.cin + c0) * p.cout + n0);  // (bit 3, timing only: one weight block for every item)
         if constexpr (PERM) {  // (the compiler does not hold the item's offset in a scalar register there: it goes into the lane offset)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -1124,12 +1124,13 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       // 16x16x4 MFMAs of one chain is filled by the other three waves of the SIMD.
       float4 u[NBLK][2];
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) u[b][0] = xr(b, 0), u[b][1] = xr(b, 1);
+      for (int b = 0; b < NBLK; ++b) u[b][0] = xr((p.stagger & 128) ? 0 : b, 0), u[b][1] = xr((p.stagger & 128) ? 0 : b, 1);  // (bit 7, timing only: one block's operands)
 #pragma unroll
       for (int b = 0; b < NBLK; ++b)
-        if (b < nb) mfma8(acc[b], u[b][0], u[b][1]);  // uniform
+        if (b < nb && !(p.stagger & 32)) mfma8(acc[b], u[b][0], u[b][1]);  // uniform (bit 5, timing only: no matrix work)
       if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
         cc = 0, ++ka;
+        if (!(p.stagger & 64)) {  // (bit 6, timing only: no scatter)
         auto scatter = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
           constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
           int lr[hi - lo];
@@ -1153,6 +1154,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
         if constexpr (NBLK > 4) {
           if (nb > 4) scatter(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
           if (nb > 6) scatter(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+        }
         }
       }
       gload_w(slot);

@@ -356,7 +356,7 @@ if which == "wmid":  # mid-layer weight gradient (tiled kernel): full, without t
             res.append((ab, timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, c, c)), reps) * 1e3))
         lib().mink_conv_set_stagger(0)
         print(f"l@{ts}.c2 wgrad rows={nbr.shape[0]} {c}->{c}: " + "  ".join(f"ablate {a}: {t:.1f} us" for a, t in res))
-if which == "cab":  # compact kernel with (0) and without (16) its steady-state global loads: how much of an item is waiting for memory
+if which == "cab":  # compact kernel: full / every gather reads row 0 (16) / no matrix work (32) / both (48): what an item's time is made of
     from nerf_downstream_amd._lib import lib
     keys = {1: k1}
     for ts in (2, 4, 8, 16, 32):
@@ -368,8 +368,8 @@ if which == "cab":  # compact kernel with (0) and without (16) its steady-state 
         xin = torch.randn(nbr.shape[0], c, device=dev)
         w = torch.randn(27, c, c, device=dev) * 0.05
         res = []
-        for ab in (0, 16, 0, 16):
+        for ab in (0, 16, 32, 48, 0, 32 + 64, 32 + 128, 32 + 64 + 128, 8, 8 + 16, 8 + 16 + 32, 4):
             lib().mink_conv_set_stagger(ab)
             res.append(timeit(lambda: Fn.gather_gemm(xin, w, nbr, c), reps) * 1e3)
         lib().mink_conv_set_stagger(0)
-        print(f"l@{ts}.c2 fwd rows={nbr.shape[0]} {c}->{c}: full {res[0]:.1f} / {res[2]:.1f} us, without steady-state loads {res[1]:.1f} / {res[3]:.1f} us")
+        print(f"l@{ts}.c2 fwd rows={nbr.shape[0]} {c}->{c}: full {res[0]:.1f} / {res[4]:.1f} us, gathers from row 0 {res[1]:.1f}, no MFMA {res[2]:.1f}, neither {res[3]:.1f}; no MFMA + no scatter {res[5]:.1f}, + one block of LDS operands {res[6]:.1f}, + both {res[7]:.1f}; one weight block {res[8]:.1f}, + gathers from row 0 {res[9]:.1f}, + no MFMA {res[10]:.1f}; NO ITEMS (prologue + epilogue + split-K reduce) {res[11]:.1f}")
