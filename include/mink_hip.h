@@ -558,6 +558,14 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex);
  * made the B=16 step 5 % SLOWER -- DESIGN.md Appendix A).  mink_bn_set_fold(max_rows) sets the limit (0: never) and returns
  * the previous one. */
 int mink_bn_set_fold(int32_t max_rows);
+/* mink_bn_bwd whose incoming gradient is still the `nslab` split-K slabs ([nslab][n][C] at dy_slabs) of the data-gradient
+ * convolution that produced it (mink_conv_gather_gemm_slabs): the column-reduction pass sums them in slab order -- what
+ * splitk_reduce would have written, bit for bit --, adds `addend` behind them (optional [n][C]: the gradient of a residual branch,
+ * what mink_eltwise(.., 2, ..) would have added) and stores the sum to dy_sum on the way.  One or two launches and passes over
+ * the gradient less per convolution backward.  C <= 1024. */
+int mink_bn_bwd_slabs(const float *dy_slabs, int32_t nslab, const float *addend, float *dy_sum, const float *x, const float *y, int64_t n, int32_t C,
+                      const float *mean, const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual,
+                      float *dgamma, float *dbeta, void *workspace, int64_t workspace_bytes, void *stream);
 int mink_bn_apply_from_partials(const float *x, int64_t n, int32_t C, const double *partial, int32_t rows, float eps, float momentum,
                                 const float *gamma, const float *beta, const float *residual, int32_t relu, float *y, float *mean,
                                 float *invstd, float *running_mean, float *running_var, void *stream);
@@ -571,7 +579,8 @@ int mink_bn_apply_from_partials(const float *x, int64_t n, int32_t C, const doub
  *   mink_bn_small_fwd            y = sum of `nslab` slabs (nslab == 0: y as given) -> batch statistics (mean, invstd, running
  *                                statistics as mink_bn_stats) -> out = [relu](bn(y) [+ residual])
  *   mink_bn_small_bwd            mink_bn_bwd in one launch; nslab > 0: the incoming gradient is the sum of `nslab` slabs at
- *                                `dy` ([nslab][n][C]), written to dy_sum
+ *                                `dy` ([nslab][n][C]) plus `addend` ([n][C], optional: a residual branch's gradient),
+ *                                written to dy_sum
  * C must be a multiple of 16.  Results are deterministic; the summation order differs from the three-launch form (last-bit
  * differences), which is why the module-by-module path, the yardstick of the bitwise tests, never takes these. */
 int32_t mink_bn_small_rows(void);
@@ -583,7 +592,7 @@ int mink_conv_gather_gemm_slabs(const float *x, int64_t n_in, int32_t ldx, int32
 int mink_bn_small_fwd(const float *slabs, int32_t nslab, int64_t n, int32_t C, float *y, float eps, float momentum,
                       const float *gamma, const float *beta, const float *residual, int32_t relu, float *out, float *mean,
                       float *invstd, float *running_mean, float *running_var, void *stream);
-int mink_bn_small_bwd(const float *dy, int32_t nslab, float *dy_sum, const float *x, const float *y, int64_t n, int32_t C,
+int mink_bn_small_bwd(const float *dy, int32_t nslab, const float *addend, float *dy_sum, const float *x, const float *y, int64_t n, int32_t C,
                       const float *mean, const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual,
                       float *dgamma, float *dbeta, void *stream);
 

@@ -178,6 +178,7 @@ SIGNATURES = {
     "mink_block_forward": (ctypes.c_int, [_p, _p]),
     "mink_block_backward": (ctypes.c_int, [_p, _p]),
     "mink_bn_set_fold": (ctypes.c_int, [_i32]),
+    "mink_bn_bwd_slabs": (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _i64, _p]),
     "mink_bn_apply_from_partials": (ctypes.c_int, [_p, _i64, _i32, _p, _i32, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
     "mink_bn_small_rows": (_i32, []),
     "mink_bn_set_small": (ctypes.c_int, [_i32]),
@@ -186,7 +187,7 @@ SIGNATURES = {
         [_p, _i64, _i32, _i32, _p, _i32, _i32, _p, _i64, _i32, _p, _i64, _p, _i32, _i32, _i32, _p, _i64, _p, _p],
     ),
     "mink_bn_small_fwd": (ctypes.c_int, [_p, _i32, _i64, _i32, _p, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
-    "mink_bn_small_bwd": (ctypes.c_int, [_p, _i32, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    "mink_bn_small_bwd": (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
     "mink_set_stage_hook": (ctypes.c_int, [_p]),
     "mink_event_create": (ctypes.c_int, [_p]),
     "mink_event_destroy": (ctypes.c_int, [_p]),

@@ -822,8 +822,11 @@ constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * LDA + CK
 // an offset range but ALL offsets -- the rulebook holds the live ones (CKP at a time: a tile that is not class-pure
 // just takes more rounds) -- and a split launch cuts the CHANNEL chunks instead (every slice sees every live offset:
 // balanced whatever the class is).  p.kper is then the number of 32-channel chunks per slice.
-template <bool W_T, int CM, bool PERM = false>
+// ABL: the timing-only switches of scripts/kbench.py cab (p.stagger bits 2-7) are compiled in -- forward kernel only; the
+// production instantiations carry none of their branches
+template <bool W_T, int CM, bool PERM = false, bool ABL = false>
 __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(GemmParams p) {
+  const int abl = ABL ? p.stagger : 0;
   constexpr int NBLK = CM / 16, NH = CM / 64, NA = CM / 32;
   constexpr int NU = PERM ? 7 : 3;  // offsets of the slice a wave looks at (cs, cs + 4, ...)
   extern __shared__ __attribute__((aligned(16))) unsigned char c_smem[];
@@ -994,7 +997,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const unsigned w_ = a < 4 ? kl0 : a < 8 ? kl1 : kl2;
       return (int)((w_ >> (8 * (a & 3))) & 255u);
     };
-    const int n_items = (p.stagger & 4) ? 0 : na * ncc;  // (bit 2, timing only: prologue and epilogue alone)
+    const int n_items = (abl & 4) ? 0 : na * ncc;  // (bit 2, timing only: prologue and epilogue alone)
 
     int g_ka = 0, g_cc = 0;  // iterator of the global-load stage
     // every call issues the same NA + (W_T ? 2 : 8) loads, whatever the item: the vmcnt distances of the ring are static
@@ -1008,7 +1011,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const int c0 = (cbeg + g_cc) * BK;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const float *src = xcol + (int64_t)((p.stagger & 16) ? 0 : s_src[j * CM + a_r + 32 * i]) * p.ldx + c0;  // (bit 16, timing only: every gather reads row 0)
+        const float *src = xcol + (int64_t)((abl & 16) ? 0 : s_src[j * CM + a_r + 32 * i]) * p.ldx + c0;  // (bit 16, timing only: every gather reads row 0)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ga[slot][i]) : "v"(src));
       }
     };
@@ -1019,7 +1022,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const int kw = p.flip_k ? K - 1 - k : k;
       const int c0 = (cbeg + g_cc) * BK;
       if constexpr (!W_T) {
-        const int so = (p.stagger & 8) ? 0 : 4 * ((kw * p.cin + c0) * p.cout + n0);  // (bit 3, timing only: one weight block for every item)
+        const int so = (abl & 8) ? 0 : 4 * ((kw * p.cin + c0) * p.cout + n0);  // (bit 3, timing only: one weight block for every item)
         if constexpr (PERM) {  // (the compiler does not hold the item's offset in a scalar register there: it goes into the lane offset)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -1124,13 +1127,13 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       // 16x16x4 MFMAs of one chain is filled by the other three waves of the SIMD.
       float4 u[NBLK][2];
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) u[b][0] = xr((p.stagger & 128) ? 0 : b, 0), u[b][1] = xr((p.stagger & 128) ? 0 : b, 1);  // (bit 7, timing only: one block's operands)
+      for (int b = 0; b < NBLK; ++b) u[b][0] = xr((abl & 128) ? 0 : b, 0), u[b][1] = xr((abl & 128) ? 0 : b, 1);  // (bit 7, timing only: one block's operands)
 #pragma unroll
       for (int b = 0; b < NBLK; ++b)
-        if (b < nb && !(p.stagger & 32)) mfma8(acc[b], u[b][0], u[b][1]);  // uniform (bit 5, timing only: no matrix work)
+        if (b < nb && !(abl & 32)) mfma8(acc[b], u[b][0], u[b][1]);  // uniform (bit 5, timing only: no matrix work)
       if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
         cc = 0, ++ka;
-        if (!(p.stagger & 64)) {  // (bit 6, timing only: no scatter)
+        if (!(abl & 64)) {  // (bit 6, timing only: no scatter)
         auto scatter = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
           constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
           int lr[hi - lo];
@@ -2407,7 +2410,12 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
     tiles_x = cgrid.x;
     compact_swizzle(p, cgrid, cin, cout, K);
     if (w_transposed) compact_gemm_kernel<true, CMT><<<cgrid, 256, smem, st>>>(p);
-    else compact_gemm_kernel<false, CMT><<<cgrid, 256, smem, st>>>(p);
+    else if (g_stagger & 0xFC) {  // timing-only switches (kbench cab): the instantiation that carries them
+      static const bool abl_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<false, CMT, false, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
+      MINK_REQUIRE(abl_ok, "gather_gemm: %d bytes of LDS per workgroup refused", smem);
+      compact_gemm_kernel<false, CMT, false, true><<<cgrid, 256, smem, st>>>(p);
+    } else compact_gemm_kernel<false, CMT><<<cgrid, 256, smem, st>>>(p);
   } else {
     const bool stage = row_perm != nullptr;
     if (vec) {

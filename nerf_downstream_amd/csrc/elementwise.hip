@@ -62,6 +62,15 @@ __device__ __forceinline__ float4 bn_dx(float4 g, float4 v, float4 mu, float4 is
   return o;
 }
 
+// one row's contribution to (sum g, sum g xhat) of the batch-norm backward; shared (and contraction-free) because the slab-summing
+// form below must accumulate exactly what colreduce_kernel<1> accumulates
+__device__ __forceinline__ void bn_bwd_accumulate(float4 g, float4 x, float4 mu, float4 is, float4 &s0, float4 &s1) {
+#pragma clang fp contract(off)
+  s0.x += g.x, s0.y += g.y, s0.z += g.z, s0.w += g.w;
+  s1.x += g.x * (x.x - mu.x) * is.x, s1.y += g.y * (x.y - mu.y) * is.y, s1.z += g.z * (x.z - mu.z) * is.z,
+      s1.w += g.w * (x.w - mu.w) * is.w;
+}
+
 // ---------------------------------------------------------------------- column sums
 // Generic two-quantity column reduction over rows: each thread owns 4 channels (one float4
 // column) and strides over rows; partial[blk][2][C] in double.
@@ -140,9 +149,7 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
           g.x = y.x > 0.f ? g.x : 0.f, g.y = y.y > 0.f ? g.y : 0.f, g.z = y.z > 0.f ? g.z : 0.f,
           g.w = y.w > 0.f ? g.w : 0.f;
         }
-        s0.x += g.x, s0.y += g.y, s0.z += g.z, s0.w += g.w;
-        s1.x += g.x * (x.x - mu.x) * is.x, s1.y += g.y * (x.y - mu.y) * is.y, s1.z += g.z * (x.z - mu.z) * is.z,
-            s1.w += g.w * (x.w - mu.w) * is.w;
+        bn_bwd_accumulate(g, x, mu, is, s0, s1);
       }
     }
     double *d = s_red + ((int64_t)rl * 2) * C + 4 * c4;
@@ -154,6 +161,61 @@ __global__ __launch_bounds__(EB) void colreduce_kernel(const float *__restrict__
     double s = 0.0;
     for (int r = 0; r < rlanes; ++r) s += s_red[(int64_t)r * 2 * C + e];
     partial[(int64_t)blockIdx.x * 2 * LD + (e < C ? e : LD + e - C)] = s;
+  }
+}
+
+// colreduce_kernel<1> whose gradient operand is still in the split-K slabs of the data-gradient convolution that produced it:
+// g = slab 0 + slab 1 + ... (slab order: the sum splitk_reduce_kernel would have written), stored to `g_sum` on the way -- the
+// reduce launch and one pass over the gradient disappear from the chain (8 per ResNet14 step, 28 per ResNet34 step); `addend`
+// (optional): the gradient of the residual branch, added behind the slabs -- the identity blocks' add launch goes too.  Same thread
+// -> row mapping and the same accumulation as colreduce_kernel<1>: bit-identical statistics.  C <= 1024.
+__global__ __launch_bounds__(EB) void colreduce_slabs_kernel(const float *__restrict__ slabs, int nslab, const float *__restrict__ addend,
+                                                             float *__restrict__ g_sum, const float *__restrict__ b, const float *__restrict__ yrelu, int64_t n, int C,
+                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                             double *__restrict__ partial) {
+  extern __shared__ double s_red[];
+  const int tpr = C >> 2, rlanes = EB / tpr;
+  const int c4 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const int64_t total = n * C;
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
+  if (rl < rlanes) {
+    const float4 mu = ld4(mean + 4 * c4), is = ld4(invstd + 4 * c4);
+    for (int64_t row = (int64_t)blockIdx.x * rlanes + rl; row < n; row += (int64_t)gridDim.x * rlanes) {
+      const int64_t off = row * C + 4 * c4;
+      const float4 x = ld4(b + off);
+      float4 y = make_float4(1, 1, 1, 1);
+      if (yrelu) y = ld4(yrelu + off);
+      float4 g = ld4(slabs + off);
+      int z = 1;
+      for (; z + 3 < nslab; z += 4) {  // four slabs in flight, added in slab order
+        const float4 t0 = ld4(slabs + (int64_t)z * total + off), t1 = ld4(slabs + (int64_t)(z + 1) * total + off),
+                     t2 = ld4(slabs + (int64_t)(z + 2) * total + off), t3 = ld4(slabs + (int64_t)(z + 3) * total + off);
+        g.x += t0.x, g.y += t0.y, g.z += t0.z, g.w += t0.w;
+        g.x += t1.x, g.y += t1.y, g.z += t1.z, g.w += t1.w;
+        g.x += t2.x, g.y += t2.y, g.z += t2.z, g.w += t2.w;
+        g.x += t3.x, g.y += t3.y, g.z += t3.z, g.w += t3.w;
+      }
+      for (; z < nslab; ++z) {
+        const float4 t = ld4(slabs + (int64_t)z * total + off);
+        g.x += t.x, g.y += t.y, g.z += t.z, g.w += t.w;
+      }
+      if (addend) {  // (the residual branch's gradient: what the add launch behind the reduce would have added)
+        const float4 t = ld4(addend + off);
+        g.x += t.x, g.y += t.y, g.z += t.z, g.w += t.w;
+      }
+      st4(g_sum + off, g);
+      g.x = y.x > 0.f ? g.x : 0.f, g.y = y.y > 0.f ? g.y : 0.f, g.z = y.z > 0.f ? g.z : 0.f, g.w = y.w > 0.f ? g.w : 0.f;
+      bn_bwd_accumulate(g, x, mu, is, s0, s1);
+    }
+    double *d = s_red + ((int64_t)rl * 2) * C + 4 * c4;
+    d[0] = s0.x, d[1] = s0.y, d[2] = s0.z, d[3] = s0.w;
+    d[C + 0] = s1.x, d[C + 1] = s1.y, d[C + 2] = s1.z, d[C + 3] = s1.w;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * C; e += EB) {
+    double t = 0.0;
+    for (int r = 0; r < rlanes; ++r) t += s_red[(int64_t)r * 2 * C + e];
+    partial[(int64_t)blockIdx.x * 2 * C + e] = t;
   }
 }
 
@@ -398,8 +460,8 @@ __global__ __launch_bounds__(kSmallT) void bn_small_fwd_kernel(const float *__re
 // nslab > 0: the incoming gradient is the sum of `nslab` split-K slabs of the data-gradient convolution that produced it
 // ([nslab][n][C] at `dy`); the sum is written to `dy_sum`
 template <int CH>
-__global__ __launch_bounds__(kSmallT) void bn_small_bwd_kernel(const float *__restrict__ dy, int nslab, float *dy_sum,
-                                                               const float *__restrict__ x, const float *__restrict__ yrelu, int64_t n,
+__global__ __launch_bounds__(kSmallT) void bn_small_bwd_kernel(const float *__restrict__ dy, int nslab, const float *__restrict__ addend,
+                                                               float *dy_sum, const float *__restrict__ x, const float *__restrict__ yrelu, int64_t n,
                                                                int C, const float *__restrict__ mean, const float *__restrict__ invstd,
                                                                const float *__restrict__ gamma, float *__restrict__ dx,
                                                                float *__restrict__ dres, float *__restrict__ dgamma,
@@ -439,6 +501,13 @@ __global__ __launch_bounds__(kSmallT) void bn_small_bwd_kernel(const float *__re
 #pragma unroll
         for (int u = 0; u < NU; ++u) g[u].x += t[q][u].x, g[u].y += t[q][u].y, g[u].z += t[q][u].z, g[u].w += t[q][u].w;
       }
+  }
+  if (addend) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const float4 t = ld4(addend + off[u]);
+      g[u].x += t.x, g[u].y += t.y, g[u].z += t.z, g[u].w += t.w;
+    }
   }
   float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
 #pragma unroll
@@ -1104,12 +1173,14 @@ int mink_bn_small_fwd(const float *slabs, int32_t nslab, int64_t n, int32_t C, f
   return MINK_OK;
 }
 
-int mink_bn_small_bwd(const float *dy, int32_t nslab, float *dy_sum, const float *x, const float *y, int64_t n, int32_t C,
+int mink_bn_small_bwd(const float *dy, int32_t nslab, const float *addend, float *dy_sum, const float *x, const float *y, int64_t n, int32_t C,
                       const float *mean, const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual,
                       float *dgamma, float *dbeta, void *stream) {
   MINK_REQUIRE(n >= 1 && n <= kSmallRows && C >= 16 && C % 16 == 0, "bn_small_bwd: %lld rows x %d channels not supported",
                (long long)n, C);
-  MINK_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && nslab >= 0 && (nslab == 0 || dy_sum), "bn_small_bwd: bad arguments");
+  MINK_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && nslab >= 0 && (nslab == 0 || dy_sum) && (!addend || nslab > 0),
+               "bn_small_bwd: bad arguments");
+  REQ_A16(addend, "bn_small_bwd");
   MINK_REQUIRE(!relu || y, "bn_small_bwd: fused ReLU needs the forward output");
   REQ_A16(dy, "bn_small_bwd");
   REQ_A16(x, "bn_small_bwd");
@@ -1120,10 +1191,49 @@ int mink_bn_small_bwd(const float *dy, int32_t nslab, float *dy_sum, const float
   MINK_REQUIRE(attr_ok, "bn_small: %d bytes of LDS per workgroup refused", kSmallSmem);
   if (small_width(C) == 16)
     bn_small_bwd_kernel<16><<<dim3((unsigned)(C / 16)), kSmallT, kSmallSmem, (hipStream_t)stream>>>(
-        dy, nslab, dy_sum, x, relu ? y : nullptr, n, C, mean, invstd, gamma, dx, dresidual, dgamma, dbeta);
+        dy, nslab, addend, dy_sum, x, relu ? y : nullptr, n, C, mean, invstd, gamma, dx, dresidual, dgamma, dbeta);
   else
     bn_small_bwd_kernel<8><<<dim3((unsigned)(C / 8)), kSmallT, kSmallSmem, (hipStream_t)stream>>>(
-        dy, nslab, dy_sum, x, relu ? y : nullptr, n, C, mean, invstd, gamma, dx, dresidual, dgamma, dbeta);
+        dy, nslab, addend, dy_sum, x, relu ? y : nullptr, n, C, mean, invstd, gamma, dx, dresidual, dgamma, dbeta);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
+}
+
+int mink_bn_bwd_slabs(const float *dy_slabs, int32_t nslab, const float *addend, float *dy_sum, const float *x, const float *y, int64_t n, int32_t C,
+                      const float *mean, const float *invstd, const float *gamma, int32_t relu, float *dx, float *dresidual,
+                      float *dgamma, float *dbeta, void *workspace, int64_t workspace_bytes, void *stream) {
+  REQ_C4(C, "bn_bwd_slabs");
+  MINK_REQUIRE(workspace_bytes >= mink_bn_workspace_bytes(n, C), "bn_bwd_slabs: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+               (long long)(mink_bn_workspace_bytes(n, C)));
+  MINK_REQUIRE(n >= 1 && nslab >= 1 && C <= 4 * EB && dy_slabs && dy_sum && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace,
+               "bn_bwd_slabs: bad arguments");
+  MINK_REQUIRE(!relu || y, "bn_bwd_slabs: fused ReLU needs the forward output");
+  REQ_A16(dy_slabs, "bn_bwd_slabs");
+  REQ_A16(dy_sum, "bn_bwd_slabs");
+  REQ_A16(x, "bn_bwd_slabs");
+  REQ_A16(dx, "bn_bwd_slabs");
+  hipStream_t st = (hipStream_t)stream;
+  const float *yr = relu ? y : nullptr;
+  // the launch shape of launch_colreduce (one slab of channels: C <= 1024), so that the statistics are those of mink_bn_bwd
+  const int tpr = C >> 2, rlanes = EB / tpr;
+  int64_t nblk = cdiv(n, (int64_t)rlanes * 8);
+  if (nblk > kRedBlocks) nblk = kRedBlocks;
+  if (nblk < 1) nblk = 1;
+  REQ_A16(addend, "bn_bwd_slabs");
+  colreduce_slabs_kernel<<<dim3((unsigned)nblk), EB, (size_t)rlanes * 2 * C * sizeof(double), st>>>(dy_slabs, nslab, addend, dy_sum, x, yr, n, C,
+                                                                                                  mean, invstd, (double *)workspace);
+  MINK_CHECK_LAUNCH();
+  if ((int)nblk <= g_bn_fold && (C & 63) == 0) {
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 64), 512 / (C / 64)));
+    bn_bwd_apply_fold_kernel<<<dim3(gx, (unsigned)(C / 64)), EB, 0, st>>>(dy_sum, x, yr, n, C, 1.f / (float)n, (const double *)workspace, (int)nblk,
+                                                                         mean, invstd, gamma, dgamma, dbeta, dx, dresidual);
+    MINK_CHECK_LAUNCH();
+    return MINK_OK;
+  }
+  launch_bwd_finalize((const double *)workspace, (int)nblk, C, gamma, dgamma, dbeta, st);
+  MINK_CHECK_LAUNCH();
+  const int64_t n4 = n * (C >> 2);
+  bn_bwd_apply_kernel<<<dim3(ew_grid(n4)), EB, 0, st>>>(dy_sum, x, yr, n4, C >> 2, 1.f / (float)n, mean, invstd, gamma, dgamma, dbeta, dx, dresidual);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }

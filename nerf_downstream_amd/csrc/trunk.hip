@@ -88,15 +88,19 @@ int conv_stats(const MinkConvLayer &c, const MinkNormLayer &nm, const float *x, 
 
 // Few-row layers (mink_bn_small_rows): the convolution leaves its split-K slabs and ONE launch sums them, takes the
 // statistics and applies norm + residual + ReLU -- two launches per convolution + norm instead of four.
-bool small_layer(int64_t n_out, int cout) { return n_out <= mink_bn_small_rows() && cout % 16 == 0; }
+// ... where that one launch is faster than the three it replaces: its time grows with rows x slabs (a workgroup owns 8 channels
+// and ALL rows; measured 7 us at 128 x 2, 13 us at 128 x 14 and 532 x 5, 22 us at 512 x 14 against ~22 us for the three launches)
+bool small_layer(int64_t n_out, int cout, int nslab = 1) {
+  return n_out <= mink_bn_small_rows() && cout % 16 == 0 && n_out * (nslab > 1 ? nslab : 1) <= 3000;
+}
 
 // the convolution of a conv + norm pair (and, on the general path, the statistics and their finalize)
 int conv_for_norm(const MinkConvLayer &c, const MinkNormLayer &nm, const float *x, int64_t n_in, int64_t n_out, float *y, void *ws_base,
                   int64_t ws_bytes, hipStream_t st, ConvOut &co) {
-  co.small = small_layer(n_out, c.cout);
+  const int ksplit = mink_conv_plan(n_out, c.K, c.cin, c.cout, 0);
+  co.small = small_layer(n_out, c.cout, ksplit);
   if (!co.small) return conv_stats(c, nm, x, n_in, n_out, y, ws_base, ws_bytes, st, co);
   Scratch ws(ws_base, ws_bytes);
-  const int ksplit = mink_conv_plan(n_out, c.K, c.cin, c.cout, 0);
   const int64_t slab_bytes = ksplit > 1 ? 4ll * ksplit * n_out * c.cout : 0;
   co.slabs = ksplit > 1 ? (float *)ws.take(slab_bytes) : nullptr;
   MINK_REQUIRE(ksplit == 1 || co.slabs, "block: scratch too small for a %lld x %d convolution", (long long)n_out, c.cout);
@@ -311,7 +315,22 @@ int mink_block_forward(const MinkBasicBlock *b, const MinkExec *ex) {
   return norm_act(b->norm2, b->n_out, C, b->y2, shortcut, 1, b->out, c2, st);
 }
 
-int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
+}  // extern "C"
+
+namespace {
+// A block's input gradient that has not been summed yet: g = slab 0 + ... + slab nslab-1 + addend, to be written to `sum` by
+// whoever consumes it -- the batch-norm backward of the block BEFORE (mink_bn_bwd_slabs / mink_bn_small_bwd), which reads the
+// gradient anyway.  An identity block then ends with its conv1 data gradient's kernel: no reduce launch, no add launch.
+struct PendingGrad {
+  const float *slabs = nullptr;
+  int32_t nslab = 0;
+  const float *addend = nullptr;
+};
+
+// in : this block's g_out arrives as `in` (nslab > 1) and is written to b->g_out by the first kernel here
+// out: an identity block may leave its input gradient pending (out->nslab > 1; the caller's next block consumes it)
+int block_backward_impl(const MinkBasicBlock *b, const MinkExec *ex, const PendingGrad *in, PendingGrad *out) {
+  if (out) *out = PendingGrad{};
   MINK_REQUIRE(b && ex, "block_backward: NULL descriptor");
   TRY(check_conv(b->conv1, "block_backward conv1", true));
   TRY(check_conv(b->conv2, "block_backward conv2", true));
@@ -335,9 +354,17 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
   const bool want_gx = b->g_x != nullptr;
   const bool small = small_layer(b->n_out, C);
   // out = relu(norm2(y2) + shortcut)
-  if (small)
-    TRY(mink_bn_small_bwd(b->g_out, 0, nullptr, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, 1, g_y2, g_res,
-                          b->norm2.dgamma, b->norm2.dbeta, st));
+  const bool pend = in && in->nslab > 1;  // g_out = the pending slabs + addend of the block behind, summed here into b->g_out
+  float *g_out_w = const_cast<float *>(b->g_out);
+  if (pend && small_layer(b->n_out, C, in->nslab))
+    TRY(mink_bn_small_bwd(in->slabs, in->nslab, in->addend, g_out_w, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd,
+                          b->norm2.gamma, 1, g_y2, g_res, b->norm2.dgamma, b->norm2.dbeta, st));
+  else if (pend)
+    TRY(mink_bn_bwd_slabs(in->slabs, in->nslab, in->addend, g_out_w, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma,
+                          1, g_y2, g_res, b->norm2.dgamma, b->norm2.dbeta, compute.ws, bn_bytes, st));
+  else if (small)
+    TRY(mink_bn_small_bwd(b->g_out, 0, nullptr, nullptr, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, 1, g_y2,
+                          g_res, b->norm2.dgamma, b->norm2.dbeta, st));
   else
     TRY(mink_bn_bwd(b->g_out, b->y2, b->out, b->n_out, C, b->norm2.mean, b->norm2.invstd, b->norm2.gamma, 1, g_y2, g_res,
                     b->norm2.dgamma, b->norm2.dbeta, compute.ws, bn_bytes, st));
@@ -356,7 +383,7 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
     // (on one stream the branch shares the compute scratch: its batch-norm partials sit behind the main chain's)
     const Lane bl = br == st ? branch.after(bn_bytes) : branch;
     if (small)
-      TRY(mink_bn_small_bwd(g_res, 0, nullptr, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
+      TRY(mink_bn_small_bwd(g_res, 0, nullptr, nullptr, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
                             b->normd.dgamma, b->normd.dbeta, br));
     else
       TRY(mink_bn_bwd(g_res, b->yd, nullptr, b->n_out, C, b->normd.mean, b->normd.invstd, b->normd.gamma, 0, g_yd, nullptr,
@@ -373,23 +400,44 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) {
     TRY(conv_backward(b->down, b->x, b->n_in, b->n_out, g_yd, nullptr, rest_b, weight, br == wst ? -1 : 3));
   }
   const Lane rest = compute.after(2 * bn_bytes);
-  if (small) {  // conv2's data gradient stays in its split-K slabs: norm1's one-launch backward sums them on the way in
+  {  // conv2's data gradient stays in its split-K slabs: norm1's backward sums them on the way in (no reduce launch)
     ConvOut gs;
-    TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, -1, &gs));
+    TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, -1, C <= 1024 ? &gs : nullptr));
     const bool sl = gs.nslab > 1;
-    TRY(mink_bn_small_bwd(sl ? gs.slabs : g_h1, sl ? gs.nslab : 0, sl ? g_h1 : nullptr, b->y1, b->h1, b->n_out, C, b->norm1.mean,
-                          b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr, b->norm1.dgamma, b->norm1.dbeta, st));
-  } else {
-    TRY(conv_backward(b->conv2, b->h1, b->n_out, b->n_out, g_y2, g_h1, rest, weight, -1));
-    TRY(mink_bn_bwd(g_h1, b->y1, b->h1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr,
-                    b->norm1.dgamma, b->norm1.dbeta, compute.ws, bn_bytes, st));
+    if (small_layer(b->n_out, C, gs.nslab))
+      TRY(mink_bn_small_bwd(sl ? gs.slabs : g_h1, sl ? gs.nslab : 0, nullptr, sl ? g_h1 : nullptr, b->y1, b->h1, b->n_out, C, b->norm1.mean,
+                            b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr, b->norm1.dgamma, b->norm1.dbeta, st));
+    else if (sl && C <= 1024)
+      TRY(mink_bn_bwd_slabs(gs.slabs, gs.nslab, nullptr, g_h1, b->y1, b->h1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, 1, g_y1,
+                            nullptr, b->norm1.dgamma, b->norm1.dbeta, compute.ws, bn_bytes, st));
+    else {
+      TRY(mink_bn_bwd(g_h1, b->y1, b->h1, b->n_out, C, b->norm1.mean, b->norm1.invstd, b->norm1.gamma, 1, g_y1, nullptr,
+                      b->norm1.dgamma, b->norm1.dbeta, compute.ws, bn_bytes, st));
+    }
   }
-  TRY(conv_backward(b->conv1, b->x, b->n_in, b->n_out, g_y1, want_gx ? (down ? b->g_x : g_xa) : nullptr, rest, weight, 5));
+  // an identity block may hand its input gradient on UNSUMMED: conv1's data-gradient slabs + g_res (the caller's next block sums
+  // them inside its own batch-norm backward; needs the same channel count there: the block before an identity block has it)
+  ConvOut g1;
+  const bool defer = out && want_gx && !down && b->conv1.stride == 1 && cin <= 1024;
+  TRY(conv_backward(b->conv1, b->x, b->n_in, b->n_out, g_y1, want_gx ? (down ? b->g_x : g_xa) : nullptr, rest, weight, 5,
+                    defer ? &g1 : nullptr));
   if (!want_gx) return MINK_OK;
-  if (!down) return mink_eltwise(g_xa, g_res, ni, 2, b->g_x, st);
+  if (!down) {
+    if (defer && g1.nslab > 1) {
+      out->slabs = g1.slabs, out->nslab = g1.nslab, out->addend = g_res;
+      return MINK_OK;
+    }
+    return mink_eltwise(g_xa, g_res, ni, 2, b->g_x, st);
+  }
   if (br != st) MINK_HIP(hipStreamWaitEvent(st, g_ev[6], 0));
   return mink_rows_scatter_add(g_sc, b->down.nbr, b->n_out, cin, b->g_x, st);
 }
+
+}  // namespace
+
+extern "C" {
+
+int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex) { return block_backward_impl(b, ex, nullptr, nullptr); }
 
 }  // extern "C"
 
@@ -539,6 +587,7 @@ int mink_net_backward(MinkNet *net, const MinkLevelMaps *levels, int32_t n_level
   hipStream_t st = (hipStream_t)ex->compute, wst = (hipStream_t)ex->wgrad;
   const float *g = g_out;
   int64_t goff = 0;
+  PendingGrad pending;
   for (int i = net->n_blocks - 1; i >= 0; --i) {
     const BlockShape &sh = shapes[i];
     MinkBasicBlock &b = net->blocks[i];
@@ -546,7 +595,11 @@ int mink_net_backward(MinkNet *net, const MinkLevelMaps *levels, int32_t n_level
     TRY(bind_block(b, sh, levels, arena + offs[i], x));
     b.g_out = g, b.g_tmp = grad_arena + goff, b.g_x = grad_arena + goff + sh.gtmp;
     if (g_stage_hook) g_stage_hook(i, 1);
-    TRY(mink_block_backward(&b, ex));
+    // (an identity block leaves its input gradient to the block before it, which is on the same level with the same width)
+    const bool may_defer = i > 0 && shapes[i - 1].level_out == sh.level_out && net->blocks[i - 1].conv1.cout == b.conv1.cin;
+    PendingGrad next;
+    TRY(block_backward_impl(&b, ex, &pending, may_defer ? &next : nullptr));
+    pending = next;
     if (done_events && done_events[i]) {
       // everything this block wrote into parameter-gradient buffers is complete once this event fires: the weight
       // gradients run on `wgrad`, the batch-norm gradients on `compute` / `branch`

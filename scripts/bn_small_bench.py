@@ -28,7 +28,7 @@ for n, C, nslab in [(532, 256, 14), (128, 512, 14), (532, 256, 5), (1000, 128, 7
                     check(L.mink_bn_small_fwd(slabs.data_ptr(), nslab, n, C, y.data_ptr(), 1e-5, 0.1, gamma.data_ptr(), beta.data_ptr(), None, 1,
                                               out.data_ptr(), mean.data_ptr(), invstd.data_ptr(), None, None, st))
                 else:
-                    check(L.mink_bn_small_bwd(slabs.data_ptr(), nslab, dx.data_ptr(), y.data_ptr(), out.data_ptr(), n, C, mean.data_ptr(),
+                    check(L.mink_bn_small_bwd(slabs.data_ptr(), nslab, None, dx.data_ptr(), y.data_ptr(), out.data_ptr(), n, C, mean.data_ptr(),
                                               invstd.data_ptr(), gamma.data_ptr(), 1, dx.data_ptr(), None, dg.data_ptr(), db.data_ptr(), st))
                 b.record()
                 torch.cuda.synchronize()

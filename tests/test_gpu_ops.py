@@ -168,7 +168,7 @@ def test_one_launch_batch_norm_of_few_row_layers(n, C, nslab, relu, res):
     g_sum = torch.empty(n, C, device=dev)
     dx, dres = torch.empty(n, C, device=dev), (torch.empty(n, C, device=dev) if res else None)
     dgamma, dbeta = torch.empty(C, device=dev), torch.empty(C, device=dev)
-    check(L.mink_bn_small_bwd(gsl.data_ptr(), nslab, g_sum.data_ptr() if nslab else None, y.data_ptr(), out.data_ptr(), n, C, mean.data_ptr(),
+    check(L.mink_bn_small_bwd(gsl.data_ptr(), nslab, None, g_sum.data_ptr() if nslab else None, y.data_ptr(), out.data_ptr(), n, C, mean.data_ptr(),
                               invstd.data_ptr(), gamma.data_ptr(), int(relu), dx.data_ptr(), dres.data_ptr() if res else None,
                               dgamma.data_ptr(), dbeta.data_ptr(), st))
     g64 = gsl[:max(nslab, 1)].double().sum(0).cpu() if nslab else gsl[0].double().cpu()
