@@ -550,13 +550,15 @@ int mink_block_backward(const MinkBasicBlock *b, const MinkExec *ex);
 
 /* ------------------------------------------------------------------ batch-norm finalize inside the apply pass
  * mink_bn_apply_from_partials = mink_bn_stats_from_partials + mink_bn_apply (the reference's MinkowskiBatchNorm forward,
- * co3d_3d/src/models/mink/modules/common.py:22-24) -- as ONE launch when `rows` is at most the fold limit (default 32, at most
- * 128) and C is a multiple of 64: every workgroup of the apply pass sums the partial rows of its 64 channels itself, in the
+ * co3d_3d/src/models/mink/modules/common.py:22-24) -- as ONE launch when `rows` is at most the fold limit (mink_bn_set_fold; at
+ * most 128; DEFAULT 0 = never: see below), re-reading the partials in every workgroup of the pass costs at most ~8 MB in total,
+ * and C is a multiple of 64: every workgroup of the apply pass sums the partial rows of its 64 channels itself, in the
  * order of the finalize kernel (results are bit-identical to the two-call sequence; mean / invstd / running statistics are
  * written by the first row chunk).  mink_bn_bwd folds its finalize into its apply pass under the same conditions.  Every
- * workgroup re-reads rows x 1 KB of partials: worth a launch only where the rows are few (measured: folding at up to 128 rows
- * made the B=16 step 5 % SLOWER -- DESIGN.md Appendix A).  mink_bn_set_fold(max_rows) sets the limit (0: never) and returns
- * the previous one. */
+ * workgroup re-reads rows x 1 KB of partials and starts its pass behind that: measured SLOWER than the separate finalize launch
+ * in every configuration (B=16: +5 % folding every layer, +-0 with the bytes rule; ResNet34 at B=4: +2.5 % with the bytes rule
+ * -- DESIGN.md Appendix A), so it is off by default and kept as a tested, bit-identical option.  mink_bn_set_fold(max_rows) sets the limit (0: never; 1000 + r: r rows
+ * without the total-bytes rule, for tests) and returns the previous one. */
 int mink_bn_set_fold(int32_t max_rows);
 /* mink_bn_bwd whose incoming gradient is still the `nslab` split-K slabs ([nslab][n][C] at dy_slabs) of the data-gradient
  * convolution that produced it (mink_conv_gather_gemm_slabs): the column-reduction pass sums them in slab order -- what

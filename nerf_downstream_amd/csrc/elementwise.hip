@@ -11,7 +11,8 @@ namespace mink {
 
 constexpr int EB = 256;
 static bool g_bn_small = true;  // few-row layers: the one-launch batch norm (mink_bn_set_small)
-static int g_bn_fold = 32;      // finalize inside the apply pass when there are at most this many partial rows (mink_bn_set_fold; 0 = never)
+static bool g_bn_fold_force = false;
+static int g_bn_fold = 0;       // finalize inside the apply pass when there are at most this many partial rows AND re-reading them is cheap (fold_ok; mink_bn_set_fold).  0 = never, the default: measured slower in every configuration
 constexpr int kRedBlocks = 2048;  // workgroups of the column reductions (8 per CU: the passes are latency-bound)
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -1056,8 +1057,19 @@ int mink_bn_apply(const float *x, int64_t n, int32_t C, const float *mean, const
   return MINK_OK;
 }
 
+// Fold the finalize into the apply pass?  Every workgroup of that pass re-reads rows x 1 KB of partials (64 channels x 2 x 8
+// bytes): fine for the short passes of the deep layers, ruinous at layer 1 of a large batch (579 workgroups x 128 KB = 74 MB of
+// L2 reads for a 19 MB pass: the step got 5 % slower).  So: few rows AND at most ~8 MB of partial re-reads in total.
+static bool fold_ok(int rows, int64_t n, int C, unsigned &gx) {
+  if (rows > g_bn_fold || (C & 63) != 0) return false;
+  gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 64), 512 / (C / 64)));
+  return g_bn_fold_force || (int64_t)rows * gx * (C / 64) <= 8192;
+}
+
 int mink_bn_set_fold(int32_t max_rows) {
-  const int old = g_bn_fold;
+  const int old = g_bn_fold + (g_bn_fold_force ? 1000 : 0);
+  g_bn_fold_force = max_rows >= 1000;  // (1000 + r: up to r rows WITHOUT the total-bytes rule -- the bitwise tests of the folded kernels)
+  if (g_bn_fold_force) max_rows -= 1000;
   g_bn_fold = max_rows < 0 ? 0 : (max_rows > kFoldRows ? kFoldRows : max_rows);
   return old;
 }
@@ -1071,8 +1083,8 @@ int mink_bn_apply_from_partials(const float *x, int64_t n, int32_t C, const doub
   REQ_A16(x, "bn_apply_from_partials");
   REQ_A16(y, "bn_apply_from_partials");
   REQ_A16(residual, "bn_apply_from_partials");
-  if (rows <= g_bn_fold && (C & 63) == 0) {
-    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 64), 512 / (C / 64)));
+  unsigned gx = 0;
+  if (fold_ok(rows, n, C, gx)) {
     bn_apply_fold_kernel<<<dim3(gx, (unsigned)(C / 64)), EB, 0, (hipStream_t)stream>>>(x, n, C, partial, rows, eps, momentum, gamma, beta, residual,
                                                                                   relu, y, mean, invstd, running_mean, running_var);
     MINK_CHECK_LAUNCH();
@@ -1113,8 +1125,8 @@ int mink_bn_bwd(const float *dy, const float *x, const float *y, int64_t n, int3
   int nblk = 0;
   int rc = launch_colreduce(1, dy, x, yr, n, C, mean, invstd, (double *)workspace, st, &nblk);
   if (rc) return rc;
-  if (nblk <= g_bn_fold && (C & 63) == 0) {  // the finalize runs inside the apply pass
-    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 64), 512 / (C / 64)));
+  unsigned gx = 0;
+  if (fold_ok(nblk, n, C, gx)) {  // the finalize runs inside the apply pass
     bn_bwd_apply_fold_kernel<<<dim3(gx, (unsigned)(C / 64)), EB, 0, st>>>(dy, x, yr, n, C, 1.f / (float)n, (const double *)workspace, nblk,
                                                                          mean, invstd, gamma, dgamma, dbeta, dx, dresidual);
     MINK_CHECK_LAUNCH();
@@ -1223,8 +1235,8 @@ int mink_bn_bwd_slabs(const float *dy_slabs, int32_t nslab, const float *addend,
   colreduce_slabs_kernel<<<dim3((unsigned)nblk), EB, (size_t)rlanes * 2 * C * sizeof(double), st>>>(dy_slabs, nslab, addend, dy_sum, x, yr, n, C,
                                                                                                   mean, invstd, (double *)workspace);
   MINK_CHECK_LAUNCH();
-  if ((int)nblk <= g_bn_fold && (C & 63) == 0) {
-    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 64), 512 / (C / 64)));
+  unsigned gx = 0;
+  if (fold_ok((int)nblk, n, C, gx)) {
     bn_bwd_apply_fold_kernel<<<dim3(gx, (unsigned)(C / 64)), EB, 0, st>>>(dy_sum, x, yr, n, C, 1.f / (float)n, (const double *)workspace, (int)nblk,
                                                                          mean, invstd, gamma, dgamma, dbeta, dx, dresidual);
     MINK_CHECK_LAUNCH();

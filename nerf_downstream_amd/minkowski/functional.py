@@ -304,7 +304,7 @@ def set_bn_small(on=True):
     return bool(lib().mink_bn_set_small(1 if on else 0))
 
 
-def set_bn_fold(max_rows=32):
+def set_bn_fold(max_rows=0):
     """Batch-norm finalize inside the apply pass (mink_bn_apply_from_partials, mink_bn_bwd) when the producer left at most
     `max_rows` partial rows (0: never; at most 128).  Returns the previous limit."""
     return int(lib().mink_bn_set_fold(int(max_rows)))

@@ -203,7 +203,7 @@ def test_batch_norm_finalize_inside_the_apply_pass_is_bitwise(n, C, rows):
     gamma, beta = torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) - 0.5
     res = torch.randn(n, C, device=dev)
     outs = {}
-    for fold in (0, 128):  # (0: separate launches; 128: folded up to 128 partial rows, the most fold_sums takes)
+    for fold in (0, 1128):  # (0: separate launches; 1000 + 128: folded up to 128 partial rows whatever the re-read volume)
         old = L.mink_bn_set_fold(fold)
         try:
             y, mean, invstd = torch.empty(n, C, device=dev), torch.empty(C, device=dev), torch.empty(C, device=dev)
@@ -220,13 +220,13 @@ def test_batch_norm_finalize_inside_the_apply_pass_is_bitwise(n, C, rows):
             outs[fold] = (y, mean, invstd, rm, rv, dx, dres, dg, db)
         finally:
             L.mink_bn_set_fold(old)
-    for k, (a, b) in enumerate(zip(outs[0], outs[128])):
+    for k, (a, b) in enumerate(zip(outs[0], outs[1128])):
         assert torch.equal(a, b), k
     ref = torch.nn.BatchNorm1d(C).double()
     with torch.no_grad():
         ref.weight.copy_(gamma.cpu().double()), ref.bias.copy_(beta.cpu().double())
     z = torch.relu(ref(x.cpu().double()) + res.cpu().double())
-    assert torch.allclose(outs[128][0].cpu().double(), z, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(outs[1128][0].cpu().double(), z, atol=2e-5, rtol=1e-5)
 
 
 def test_relu_add_pool_globalavg(oracle_maps):
