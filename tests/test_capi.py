@@ -102,3 +102,39 @@ def test_trunk_branch_policy():
     assert Fn.set_conv_storage("bf16") == "fp32" and Fn.set_conv_storage("fp32") == "bf16"
     with pytest.raises(ValueError):
         Fn.set_conv_storage("fp16")
+
+
+def test_net_sizes_follow_the_documented_arena_layout():
+    """mink_net_sizes (host arithmetic only: no GPU): the activation arena of mink_net_forward is, per block and 256-byte
+    aligned, [y1 | h1 | y2 | out | (yd | sd)] of n_out x C floats + six C-vectors of statistics; the gradient arena the block's
+    mink_block_grad_scratch_floats + its input gradient -- the layout include/mink_hip.h documents and
+    nerf_downstream_amd/minkowski/trunk.py::_Saved walks."""
+    import ctypes
+
+    from nerf_downstream_amd._lib import BasicBlock, LevelMaps, Net, lib
+
+    L = lib()
+    blocks = (BasicBlock * 3)()
+    spec = [(64, 64, 2, True), (64, 64, 1, False), (64, 128, 2, True)]  # cin, C, stride, shortcut convolution
+    for b, (cin, C, stride, down) in zip(blocks, spec):
+        b.conv1.K, b.conv1.cin, b.conv1.cout, b.conv1.stride = 27, cin, C, stride
+        b.conv2.K, b.conv2.cin, b.conv2.cout, b.conv2.stride = 27, C, C, 1
+        if down:
+            b.down.w, b.down.K, b.down.cin, b.down.cout, b.down.stride = 1, 1, cin, C, 2  # (any non-NULL pointer: never dereferenced here)
+    net = Net()
+    net.blocks, net.n_blocks, net.with_stem = ctypes.cast(blocks, ctypes.POINTER(BasicBlock)), 3, 1
+    levels = (LevelMaps * 3)()
+    rows = [10840, 2316, 527]
+    for lv, n in zip(levels, rows):
+        lv.n = n
+    a, g, w = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    assert L.mink_net_sizes(ctypes.byref(net), levels, 3, ctypes.byref(a), ctypes.byref(g), ctypes.byref(w)) == 0
+    up = lambda v: -(-v // 64) * 64  # noqa: E731
+    shapes = [(rows[0], rows[1], 64, 64, True), (rows[1], rows[1], 64, 64, False), (rows[1], rows[2], 64, 128, True)]
+    want_a = sum(up((6 if d else 4) * no * C) + up(6 * C) for _, no, _, C, d in shapes)
+    want_g = sum(up(L.mink_block_grad_scratch_floats(ni, no, cin, C, int(d))) + up(ni * cin) for ni, no, cin, C, d in shapes)
+    assert a.value == want_a and g.value == want_g
+    assert w.value == max(L.mink_block_workspace_bytes(ni, no, cin, C) for ni, no, cin, C, _ in shapes)
+    # a block that strides past the last level given is refused
+    assert L.mink_net_sizes(ctypes.byref(net), levels, 2, ctypes.byref(a), ctypes.byref(g), ctypes.byref(w)) != 0
+    assert b"level" in L.mink_last_error()
