@@ -824,11 +824,16 @@ constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * LDA + CK
 // balanced whatever the class is).  p.kper is then the number of 32-channel chunks per slice.
 // ABL: the timing-only switches of scripts/kbench.py cab (p.stagger bits 2-7) are compiled in -- forward kernel only; the
 // production instantiations carry none of their branches
-template <bool W_T, int CM, bool PERM = false, bool ABL = false>
-__global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(GemmParams p) {
+// NWV: waves per workgroup (4: a wave owns ONE 16-column strip; 2: a wave owns TWO strips -- the per-item instruction stream is
+// then paid once per 48 MFMAs instead of once per 24 and a block's LDS operands feed both strips; bit-identical results, and
+// measured 8-14 % SLOWER on every layer (two waves per SIMD hide each other's latencies worse than four: DESIGN.md Appendix A),
+// so only NWV = 4 is instantiated).
+template <bool W_T, int CM, bool PERM = false, bool ABL = false, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_gemm_kernel(GemmParams p) {
   const int abl = ABL ? p.stagger : 0;
-  constexpr int NBLK = CM / 16, NH = CM / 64, NA = CM / 32;
-  constexpr int NU = PERM ? 7 : 3;  // offsets of the slice a wave looks at (cs, cs + 4, ...)
+  constexpr int T = 64 * NWV, SPW = 4 / NWV;  // threads, column strips per wave
+  constexpr int NBLK = CM / 16, NH = CM / 64, NA = CM / (T / 8);
+  constexpr int NU = ((PERM ? 27 : CKP) + NWV - 1) / NWV;  // offsets of the slice a wave looks at (cs, cs + NWV, ...)
   extern __shared__ __attribute__((aligned(16))) unsigned char c_smem[];
   float *sC = reinterpret_cast<float *>(c_smem);             // [CM + 1][CLDC]; row CM takes the padding lanes
   float *sA = sC + (CM + 1) * CLDC;                          // [2][CM][LDA] compacted gathered rows
@@ -863,7 +868,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
 
   // ---- prologue: table entries of the slice (a wave takes offsets cs, cs + 4, ...; they are requested together,
   // straight from global memory: one round trip), C = 0
-  static_assert(CKP <= 12, "three offsets per wave");
+  static_assert(CKP <= 12 && (NWV == 4 || NWV == 2) && CM == 64, "the rulebook's slots and the wave layout");
   int orow[NH];
 #pragma unroll
   for (int hh = 0; hh < NH; ++hh) {
@@ -874,16 +879,16 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
   int tv[NU][NH];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int jj = cs + 4 * u;
+    const int jj = cs + NWV * u;
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh)
       tv[u][hh] = (jj < nk && orow[hh] >= 0) ? p.nbr[(int64_t)orow[hh] * K + kbeg + jj] : -1;
   }
-  for (int e = tid; e < (CM + 1) * CLDC / 4; e += 256) reinterpret_cast<float4 *>(sC)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = tid; e < (CM + 1) * CLDC / 4; e += T) reinterpret_cast<float4 *>(sC)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (PERM) {  // rows per offset first: the live offsets get the rulebook's slots in ascending order
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int jj = cs + 4 * u;
+      const int jj = cs + NWV * u;
       int cnt = 0;
 #pragma unroll
       for (int hh = 0; hh < NH; ++hh) cnt += __popcll(__ballot(tv[u][hh] >= 0));
@@ -905,16 +910,20 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
     const unsigned long long wa = (unsigned long long)p.w;
     rw.x = (int)(unsigned)wa, rw.y = (int)((wa >> 32) & 0xFFFFu), rw.z = (int)(4u * (unsigned)K * (unsigned)p.cin * (unsigned)p.cout), rw.w = 0x00020000;
   }
-  int wv[W_T ? 2 : 8];
-  if (!W_T) {
+  int wv[SPW][W_T ? 2 : 8];  // (strip q of this wave: columns 16 (SPW cs + q) + n)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) wv[e] = 4 * ((16 * (e >> 2) + 4 * kq + (e & 3)) * p.cout + 16 * cs + n);
-  } else {
+  for (int q = 0; q < SPW; ++q) {
+    if (!W_T) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) wv[h] = 4 * ((16 * cs + n) * p.cin + 16 * h + 4 * kq);
+      for (int e = 0; e < 8; ++e) wv[q][e] = 4 * ((16 * (e >> 2) + 4 * kq + (e & 3)) * p.cout + 16 * (SPW * cs + q) + n);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wv[q][h] = 4 * ((16 * (SPW * cs + q) + n) * p.cin + 16 * h + 4 * kq);
+    }
   }
-  // ---- staging of the gathered rows: rows a_r + 32 i, float4 column a_cc
+  // ---- staging of the gathered rows: rows a_r + (T / 8) i, float4 column a_cc
   const int a_cc = tid & 7, a_r = tid >> 3;
+  constexpr int ARP = T / 8;  // rows per staging pass
   const float *xcol = p.x + 4 * a_cc;
   // The ring's global loads are issued through inline asm and waited for with hand-counted s_waitcnt: every step issues the
   // same NA + NW loads in the same order, so "the rows of item it + 1 have arrived" is vmcnt(NA + 2 NW) and "the weights of
@@ -924,22 +933,24 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
   // the matrix pipe idle -- that, not the MFMAs, was the kernel's item time (pipe busy 0.40).  The compiler does not see
   // these loads: their registers must not be copied between the load and its wait (they are only ever named as asm operands
   // and MFMA / LDS-store sources behind the wait), and everything is drained before the ring's registers die.
-  constexpr int NW = W_T ? 2 : 8;  // weight loads per item
+  constexpr int NW = SPW * (W_T ? 2 : 8);  // weight loads per item
   constexpr bool DBG_WAIT0 = false;
   f32x4 ga[CD][NA];  // (a native vector: copies of the HIP uint4 struct become memcpy calls that keep the ring in scratch)
-  float gw[CD][W_T ? 1 : 8];
-  f32x4 gwt[CD][W_T ? 2 : 1];  // W_T: the fragment as the two 16-byte loads deliver it (component e & 3 of load e >> 2)
-  f32x4 acc[NBLK];
+  float gw[CD][SPW][W_T ? 1 : 8];
+  f32x4 gwt[CD][SPW][W_T ? 2 : 1];  // W_T: the fragment as the two 16-byte loads deliver it (component e & 3 of load e >> 2)
+  f32x4 acc[SPW][NBLK];
 #pragma unroll
-  for (int i = 0; i < NBLK; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float *myC = sC + 16 * cs + 4 * kq;
+  for (int q = 0; q < SPW; ++q)
+#pragma unroll
+    for (int i = 0; i < NBLK; ++i) acc[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float *myC = sC + 16 * SPW * cs + 4 * kq;  // (strip q: + 16 q)
 
   // PERM: the live offsets CKP at a time (a class-pure tile has at most eight: one round)
   for (int round0 = 0; round0 < n_live; round0 += CKP) {
     // ---- rulebook of the round: wave64 ballot + prefix rank per offset
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int jj = cs + 4 * u;
+      const int jj = cs + NWV * u;
       const int slot = PERM ? __popc(amask & ((1u << jj) - 1u)) - round0 : jj;
       const bool mine = PERM ? (jj < nk && ((amask >> jj) & 1u) && slot >= 0 && slot < CKP) : jj < nk;
       if (mine) {  // uniform
@@ -1011,7 +1022,7 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       const int c0 = (cbeg + g_cc) * BK;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const float *src = xcol + (int64_t)((abl & 16) ? 0 : s_src[j * CM + a_r + 32 * i]) * p.ldx + c0;  // (bit 16, timing only: every gather reads row 0)
+        const float *src = xcol + (int64_t)((abl & 16) ? 0 : s_src[j * CM + a_r + ARP * i]) * p.ldx + c0;  // (bit 16, timing only: every gather reads row 0)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ga[slot][i]) : "v"(src));
       }
     };
@@ -1025,54 +1036,69 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
         const int so = (abl & 8) ? 0 : 4 * ((kw * p.cin + c0) * p.cout + n0);  // (bit 3, timing only: one weight block for every item)
         if constexpr (PERM) {  // (the compiler does not hold the item's offset in a scalar register there: it goes into the lane offset)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int vo = wv[e] + so;
-            asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(gw[slot][e]) : "v"(vo), "s"(rw));
-          }
+          for (int q = 0; q < SPW; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int vo = wv[q][e] + so;
+              asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(gw[slot][q][e]) : "v"(vo), "s"(rw));
+            }
         } else {
           const int sso = __builtin_amdgcn_readfirstlane(so);  // (uniform; an SGPR operand)
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(gw[slot][e]) : "v"(wv[e]), "s"(rw), "s"(sso));
+          for (int q = 0; q < SPW; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(gw[slot][q][e]) : "v"(wv[q][e]), "s"(rw), "s"(sso));
         }
       } else {
         const int so = 4 * ((kw * p.cout + n0) * p.cin + c0);  // (added to the lane offset: see above)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int vo = wv[h] + so;
-          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(gwt[slot][h]) : "v"(vo), "s"(rw));
-        }
+        for (int q = 0; q < SPW; ++q)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int vo = wv[q][h] + so;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(gwt[slot][q][h]) : "v"(vo), "s"(rw));
+          }
       }
       if (g_ka < na && ++g_cc == ncc) g_cc = 0, ++g_ka;
     };
     auto sts = [&](int slot, int buf) __attribute__((always_inline)) {
       float *a = sA + buf * CM * LDA;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&a[(a_r + 32 * i) * LDA + 4 * a_cc]) = ga[slot][i];
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&a[(a_r + ARP * i) * LDA + 4 * a_cc]) = ga[slot][i];
     };
 
-    static_assert(NA == 2, "the hand-counted waits name two row loads per item");
-    // "+v": the asm is the definition point of the registers for everything that follows (nothing that reads them may be
-    // scheduled above the wait)
+    // The wait itself names no register; the empty asm statements behind it are the definition points of the ring's registers
+    // for everything that follows (volatile asm statements keep their order, so nothing that reads a register can be
+    // scheduled above its wait).
+    auto tie_rows = [&](int sl) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ga[sl][i]));
+    };
+    auto tie_weights = [&](int sl) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < SPW; ++q) {
+        if constexpr (W_T) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(gwt[sl][q][h]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(gw[sl][q][e]));
+        }
+      }
+    };
+    static_assert(3 * NA + 2 * NW <= 63 && 2 * NA + 3 * NW <= 63, "vmcnt is six bits");
     auto wait_rows = [&](int sl) __attribute__((always_inline)) {  // the gathered rows of ring slot sl have arrived
-      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ga[sl][0]), "+v"(ga[sl][1]) : "n"(DBG_WAIT0 ? 0 : NA + 2 * NW));
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DBG_WAIT0 ? 0 : NA + 2 * NW));
+      tie_rows(sl);
     };
     auto wait_weights = [&](int sl) __attribute__((always_inline)) {  // the weight fragment of ring slot sl has arrived
-      if constexpr (W_T)
-        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(gwt[sl][0]), "+v"(gwt[sl][1]) : "n"(DBG_WAIT0 ? 0 : 3 * NA + 2 * NW));
-      else
-        asm volatile("s_waitcnt vmcnt(%8)"
-                     : "+v"(gw[sl][0]), "+v"(gw[sl][1]), "+v"(gw[sl][2]), "+v"(gw[sl][3]), "+v"(gw[sl][4]), "+v"(gw[sl][5]), "+v"(gw[sl][6]),
-                       "+v"(gw[sl][7])
-                     : "n"(DBG_WAIT0 ? 0 : 3 * NA + 2 * NW));
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DBG_WAIT0 ? 0 : 3 * NA + 2 * NW));
+      tie_weights(sl);
     };
     auto drain = [&](int sl) __attribute__((always_inline)) {  // nothing of ring slot sl is in flight any more
-      if constexpr (W_T)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ga[sl][0]), "+v"(ga[sl][1]), "+v"(gwt[sl][0]), "+v"(gwt[sl][1]));
-      else
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(ga[sl][0]), "+v"(ga[sl][1]), "+v"(gw[sl][0]), "+v"(gw[sl][1]), "+v"(gw[sl][2]), "+v"(gw[sl][3]), "+v"(gw[sl][4]),
-                       "+v"(gw[sl][5]), "+v"(gw[sl][6]), "+v"(gw[sl][7]));
+      asm volatile("s_waitcnt vmcnt(0)");
+      tie_rows(sl), tie_weights(sl);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -1084,7 +1110,8 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     if (n_items > 0) {  // uniform
       gload_a(0), gload_w(0), gload_a(1), gload_w(1), gload_a(2), gload_w(2);
-      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ga[0][0]), "+v"(ga[0][1]) : "n"(2 * NA + 3 * NW));
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NA + 3 * NW));
+      tie_rows(0);
       sts(0, 0);
     }
     MINK_LDS_BARRIER();
@@ -1102,12 +1129,13 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       // it has this step's MFMAs to arrive
       gload_a(slot);
       wait_weights(slot);
-      auto wf = [&](auto e_c) __attribute__((always_inline)) -> float {
-        constexpr int e = decltype(e_c)::value;
-        if constexpr (W_T) return gwt[slot][e >> 2][e & 3];
-        else return gw[slot][e];
-      };
-      auto mfma8 = [&](f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
+      auto mfma8 = [&](auto q_c, f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_c)::value;  // strip of this wave
+        auto wf = [&](auto e_c) __attribute__((always_inline)) -> float {
+          constexpr int e = decltype(e_c)::value;
+          if constexpr (W_T) return gwt[slot][q][e >> 2][e & 3];
+          else return gw[slot][q][e];
+        };
         using std::integral_constant;
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 0>{}), u0.x, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 1>{}), u0.y, c, 0, 0, 0);
@@ -1130,24 +1158,30 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
       for (int b = 0; b < NBLK; ++b) u[b][0] = xr((abl & 128) ? 0 : b, 0), u[b][1] = xr((abl & 128) ? 0 : b, 1);  // (bit 7, timing only: one block's operands)
 #pragma unroll
       for (int b = 0; b < NBLK; ++b)
-        if (b < nb && !(abl & 32)) mfma8(acc[b], u[b][0], u[b][1]);  // uniform (bit 5, timing only: no matrix work)
+        if (b < nb && !(abl & 32)) {  // uniform (bit 5, timing only: no matrix work)
+          mfma8(std::integral_constant<int, 0>{}, acc[0][b], u[b][0], u[b][1]);
+          if constexpr (SPW > 1) mfma8(std::integral_constant<int, 1>{}, acc[SPW - 1][b], u[b][0], u[b][1]);
+        }
       if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
         cc = 0, ++ka;
         if (!(abl & 64)) {  // (bit 6, timing only: no scatter)
         auto scatter = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
           constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
           int lr[hi - lo];
-          float4 c[hi - lo];
 #pragma unroll
           for (int b = lo; b < hi; ++b) lr[b - lo] = b < nb ? (int)s_lrow[j * CM + b * 16 + n] : CM;
 #pragma unroll
-          for (int b = lo; b < hi; ++b) c[b - lo] = *reinterpret_cast<const float4 *>(myC + lr[b - lo] * CLDC);
+          for (int q = 0; q < SPW; ++q) {
+            float4 c[hi - lo];
 #pragma unroll
-          for (int b = lo; b < hi; ++b) {
-            float4 &v = c[b - lo];
-            v.x += acc[b][0], v.y += acc[b][1], v.z += acc[b][2], v.w += acc[b][3];
-            *reinterpret_cast<float4 *>(myC + lr[b - lo] * CLDC) = v;
-            acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int b = lo; b < hi; ++b) c[b - lo] = *reinterpret_cast<const float4 *>(myC + 16 * q + lr[b - lo] * CLDC);
+#pragma unroll
+            for (int b = lo; b < hi; ++b) {
+              float4 &v = c[b - lo];
+              v.x += acc[q][b][0], v.y += acc[q][b][1], v.z += acc[q][b][2], v.w += acc[q][b][3];
+              *reinterpret_cast<float4 *>(myC + 16 * q + lr[b - lo] * CLDC) = v;
+              acc[q][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
           }
         };
         // (each accumulator is named in ONE place: two call sites that differ only in the block index get tail-merged
@@ -1180,9 +1214,10 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
   if (direct && p.bias) bias = *reinterpret_cast<const float4 *>(p.bias + n0 + 4 * c4);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  constexpr int RG = T / 16;  // row groups of the epilogue (16 lanes of 16 bytes per row)
 #pragma unroll
-  for (int jr = 0; jr < NBLK; ++jr) {
-    const int r = rg + 16 * jr;
+  for (int jr = 0; jr < CM / RG; ++jr) {
+    const int r = rg + RG * jr;
     const int64_t row = PERM ? (int64_t)s_orow[r] : (r < rows_here ? o0 + r : -1);
     if (row >= 0) {
       const float4 u = *reinterpret_cast<const float4 *>(&sC[r * CLDC + 4 * c4]);
@@ -1193,14 +1228,14 @@ __global__ __launch_bounds__(256, CM == 64 ? 4 : 2) void compact_gemm_kernel(Gem
     }
   }
   if (!PERM && p.stats && direct) {  // uniform
-    float *red = sA;  // [16 row groups][2][64]; the tiles are dead (last barrier)
+    float *red = sA;  // [RG row groups][2][64]; the tiles are dead (last barrier)
     *reinterpret_cast<float4 *>(&red[(rg * 2 + 0) * BN + 4 * c4]) = s;
     *reinterpret_cast<float4 *>(&red[(rg * 2 + 1) * BN + 4 * c4]) = q;
     __syncthreads();
     if (tid < 2 * BN) {
       const int which = tid >> 6, c = tid & 63;
       float t = 0.f;
-      for (int g = 0; g < 16; ++g) t += red[(g * 2 + which) * BN + c];
+      for (int g = 0; g < RG; ++g) t += red[(g * 2 + which) * BN + c];
       p.stats[((int64_t)bx * 2 + which) * p.cout + n0 + c] = t;
     }
   }
