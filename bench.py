@@ -317,11 +317,18 @@ def main():
     torch.manual_seed(777)  # same initial weights on every rank (reference: pl.seed_everything)
     model = get_model(args.model, args.in_channel, args.num_classes).to(dev)
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=dev.type == "cuda")
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=200000)
     # one flat gradient buffer the backward kernels write into; with N > 1 ranks its buckets are all-reduced (overlapped
     # with backward), with one rank that is all it is -- the step is the same program at every N
     reducer = BucketedGradAllReduce(model, bucket_bytes=int(os.environ.get("BENCH_BUCKET_BYTES", 8 << 20)), force=force_reducer)
+    # SGD with momentum and weight decay (configs/co3d_cls.gin) as one kernel over the flat buffers (parallel.FlatSGD;
+    # BENCH_TORCH_SGD=1: torch's fused multi-tensor SGD, the same update)
+    if dev.type == "cuda" and os.environ.get("BENCH_TORCH_SGD", "0") == "0":
+        from nerf_downstream_amd.parallel import FlatSGD
+
+        opt = FlatSGD(reducer, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    else:
+        opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=dev.type == "cuda")
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=200000)
 
     batches = make_batches(2, args.batch, rank, args.num_classes, args.grid, args.in_channel)
     batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]

@@ -470,6 +470,14 @@ int mink_augment_scenes(const void *coords, int32_t coords_are_int32, const floa
                         const uint32_t *streams, uint64_t seed, const int32_t *raw_cols, float *out_coords,
                         float *out_feats, int64_t ldo, int32_t *n_kept, void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------ optimizer step over flat buffers
+ * torch.optim.SGD's update with momentum and weight decay (the reference's optimizer: co3d_3d/src/modules/optim.py:12-14,
+ * co3d_3d/configs/co3d_cls.gin) for parameters w, gradients g and momentum buffers m that each live in ONE flat fp32 buffer of
+ * the same layout (n floats, a multiple of 4; padding elements are zero and stay zero):
+ *   g' = g + weight_decay w;  m = momentum m + g';  w = w - lr m        (dampening 0, no Nesterov; a zero m = torch's first step)
+ * zero_grad != 0 clears g behind the update (the next step's zero_grad memset).  One pass over 6 n floats. */
+int mink_sgd_step(float *w, float *g, float *m, int64_t n, float lr, float momentum, float weight_decay, int32_t zero_grad, void *stream);
+
 /* ------------------------------------------------------------------ whole residual blocks
  * One call = the complete launch sequence of one stage of the reference network, so the host pays one FFI call per
  * block instead of one per kernel (a Mink-ResNet14 step is ~300 launches; issued one by one from a Python autograd

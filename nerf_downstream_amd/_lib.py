@@ -158,6 +158,7 @@ SIGNATURES = {
     "mink_bn_relu_pool_fwd": (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
     "mink_bn_relu_pool_bwd": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "mink_eltwise": (ctypes.c_int, [_p, _p, _i64, _i32, _p, _p]),
+    "mink_sgd_step": (ctypes.c_int, [_p, _p, _p, _i64, _f32, _f32, _f32, _i32, _p]),
     "mink_activation": (ctypes.c_int, [_p, _p, _p, _i32, _i64, _i32, _f32, _p, _p]),
     "mink_block_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
     "mink_block_grad_scratch_floats": (_i64, [_i64, _i64, _i32, _i32, _i32]),

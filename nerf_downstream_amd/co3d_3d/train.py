@@ -216,9 +216,14 @@ def train(
         raise ValueError(f"train.training_module = {training_module!r}; available: {sorted(TRAINING_MODULES)}")
     module = TRAINING_MODULES[training_module](model)
     optimizer = get_optimizer(optimizer_name, model.parameters(), lr=lr, weight_decay=weight_decay)
-    scheduler = get_scheduler(scheduler_name, optimizer, warmup_steps)
     # flat gradient buffer written by the backward kernels (HIP backend); all-reduced in buckets when world > 1
     reducer = BucketedGradAllReduce(model) if (world > 1 or (device.type == "cuda" and ME is None)) else None
+    if reducer is not None and reducer.flat.is_cuda and optimizer_name == "SGD" and os.environ.get("MINK_TORCH_SGD", "0") == "0":
+        # the same update as torch.optim.SGD, as one kernel over the flat parameter / gradient / momentum buffers
+        from nerf_downstream_amd.parallel import FlatSGD
+
+        optimizer = FlatSGD.like(optimizer, reducer)
+    scheduler = get_scheduler(scheduler_name, optimizer, warmup_steps)
     csv_logger = CSVLogger(save_path, run_name, resume=resume_training) if rank == 0 and "csv" in loggers else None
     for name in loggers:
         if name != "csv" and rank == 0:

@@ -699,6 +699,25 @@ __global__ __launch_bounds__(EB) void bn_bwd_apply_fold_kernel(const float *__re
   }
 }
 
+// ------------------------------------------------------------------ SGD with momentum over flat buffers
+// torch.optim.SGD's update (the reference's optimizer: co3d_3d/src/modules/optim.py:12-14, configs/co3d_cls.gin) for parameters,
+// gradients and momentum buffers that each live in ONE flat fp32 buffer of the same layout (parallel.BucketedGradAllReduce):
+//   g' = g + wd w;  m = mu m + g'  (a zero buffer makes the first step m = g', as torch's clone does);  w = w - lr m
+// one pass instead of torch's multi-tensor chunks (ResNet34: 5 launches, 314 us for 85 MB of parameters), and the gradient
+// buffer is cleared on the way out (the memset of the next step's zero_grad).
+__global__ __launch_bounds__(EB) void sgd_flat_kernel(float *__restrict__ w, float *__restrict__ g, float *__restrict__ m, int64_t n4,
+                                                      float lr, float mu, float wd, int zero_grad) {
+#pragma clang fp contract(off)  // (the products and sums of torch's own kernel, one rounding each)
+  for (int64_t i = (int64_t)blockIdx.x * EB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EB) {
+    float4 wv = ld4(w + 4 * i), gv = ld4(g + 4 * i), mv = ld4(m + 4 * i);
+    gv.x += wd * wv.x, gv.y += wd * wv.y, gv.z += wd * wv.z, gv.w += wd * wv.w;
+    mv.x = mu * mv.x + gv.x, mv.y = mu * mv.y + gv.y, mv.z = mu * mv.z + gv.z, mv.w = mu * mv.w + gv.w;
+    wv.x -= lr * mv.x, wv.y -= lr * mv.y, wv.z -= lr * mv.z, wv.w -= lr * mv.w;
+    st4(w + 4 * i, wv), st4(m + 4 * i, mv);
+    if (zero_grad) st4(g + 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+}
+
 // mode 0: y = max(a,0); mode 1: y = b>0 ? a : 0; mode 2: y = a + b
 __global__ __launch_bounds__(EB) void eltwise_kernel(const float *__restrict__ a, const float *__restrict__ b,
                                                      int64_t count, int mode, float *__restrict__ y) {
@@ -1379,6 +1398,19 @@ int mink_bn_relu_pool_bwd_b16(const float *dy_pool, const void *xb, int64_t n, i
                               void *workspace, int64_t workspace_bytes, void *stream) {
   return bn_relu_pool_bwd_impl(dy_pool, (const float *)xb, true, n, C, mean, invstd, gamma, beta, in2out, nullptr, dgamma, dbeta, workspace,
                                workspace_bytes, stream);
+}
+
+int mink_sgd_step(float *w, float *g, float *m, int64_t n, float lr, float momentum, float weight_decay, int32_t zero_grad, void *stream) {
+  MINK_REQUIRE(w && g && m && n >= 0 && (n & 3) == 0, "sgd_step: bad arguments (n = %lld must be a multiple of 4)", (long long)n);
+  REQ_A16(w, "sgd_step");
+  REQ_A16(g, "sgd_step");
+  REQ_A16(m, "sgd_step");
+  if (n == 0) return MINK_OK;
+  const int64_t n4 = n >> 2;
+  sgd_flat_kernel<<<dim3((unsigned)std::min<int64_t>(cdiv(n4, EB), 8192)), EB, 0, (hipStream_t)stream>>>(w, g, m, n4, lr, momentum, weight_decay,
+                                                                                                   zero_grad);
+  MINK_CHECK_LAUNCH();
+  return MINK_OK;
 }
 
 int mink_eltwise(const float *a, const float *b, int64_t count, int32_t mode, float *y, void *stream) {

@@ -2,6 +2,7 @@
 order and recipe: loss trajectory and top-1 on the fixed synthetic split must agree
 (north_star: "top-1 on a fixed synthetic split matching reference +-0.1%"), and 2-rank data
 parallelism on the card (gloo transport, both ranks on cuda:0) must match the rank average."""
+import copy
 import os
 import socket
 import sys
@@ -353,6 +354,76 @@ def test_train_on_co3d_format_compact_equals_decoded(tmp_path, monkeypatch):
         hist[compact] = [h["train/loss"] for h in res["history"] if "train/loss" in h]
         assert [h for h in res["history"] if "val/acc1" in h]
     assert len(hist[True]) == 6 and hist[True] == hist[False]
+
+
+def test_flat_sgd_is_torch_sgd(tmp_path):
+    """parallel.FlatSGD (one kernel over the flat parameter / gradient / momentum buffers, mink_sgd_step) against
+    torch.optim.SGD(fused) on the same model, batches and cosine schedule: five training steps, parameters equal to rounding
+    (the same products and sums, one rounding each; torch's kernel may contract), momentum buffers too; optimizer checkpoints
+    are interchangeable both ways (registration-order param_groups); the gradient buffer is cleared by the step."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import batch_scenes
+
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from nerf_downstream_amd.parallel import BucketedGradAllReduce, FlatSGD
+
+    dev = torch.device("cuda", 0)
+    coords, feats = batch_scenes([81, 82, 83], grid=32, cin=28)
+    batch = {"coordinates": coords.to(dev), "features": feats.to(dev)}
+    labels = torch.tensor([1, 4, 2], device=dev)
+
+    def run(flat, steps, resume=None):
+        torch.manual_seed(21)
+        m = get_model("ResNet14", 28, 5).to(dev)
+        red = BucketedGradAllReduce(m)
+        opt = FlatSGD(red, lr=0.05, momentum=0.9, weight_decay=1e-3) if flat else \
+            torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-3, fused=True)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10)
+        if resume is not None:
+            m.load_state_dict(resume["model"]), opt.load_state_dict(copy.deepcopy(resume["opt"])), sched.load_state_dict(resume["sched"])
+        for _ in range(steps):
+            red.zero_grad()
+            F.cross_entropy(m(m.process_input(batch)), labels).backward()
+            red.finish()
+            opt.step()
+            sched.step()
+        torch.cuda.synchronize()
+        if flat:
+            assert red.cleared and float(red.flat.abs().max()) == 0.0  # cleared behind the update: zero_grad() skips its memset
+            assert all(p.data_ptr() >= opt.flat_w.data_ptr() for p in m.parameters())
+        w = torch.cat([p.detach().flatten() for p in m.parameters()])
+        mom = torch.cat([opt.state[p]["momentum_buffer"].flatten() for p in m.parameters()])
+        ck = {"model": {k: v.clone() for k, v in m.state_dict().items()}, "opt": copy.deepcopy(opt.state_dict()),
+              "sched": sched.state_dict()}  # (deep copy: load_state_dict does not clone, a resumed torch SGD would step the checkpoint itself)
+        return w, mom, ck
+
+    # (trajectories of this network amplify rounding differences -- tests/test_gpu_parity_full.py -- so steps are compared ONE at
+    #  a time from a common state: the first step from the initial weights, the second and third from a checkpoint)
+    def close(a, b, rel):
+        return float((a - b).abs().max()) <= rel * float(b.abs().max()) + 1e-7
+
+    w_t, m_t, ck_t = run(False, 1)
+    w_f, m_f, ck_f = run(True, 1)
+    assert close(w_f, w_t, 1e-6) and close(m_f, m_t, 1e-6), (float((w_f - w_t).abs().max()), float((m_f - m_t).abs().max()))
+    # the next step (momentum now non-zero, learning rate moved by the schedule) from the OTHER optimizer's checkpoint
+    w_t2, m_t2, _ = run(False, 1, resume=ck_t)
+    w_f2, m_f2, _ = run(True, 1, resume=ck_t)   # torch's checkpoint into FlatSGD
+    w_t3, m_t3, _ = run(False, 1, resume=ck_f)  # FlatSGD's checkpoint into torch
+    assert close(w_f2, w_t2, 1e-6) and close(m_f2, m_t2, 1e-5)
+    # (the two checkpoints differ by the first step's rounding, which one forward/backward of this network amplifies ~100x)
+    assert close(w_t3, w_t2, 5e-3) and close(m_t3, m_t2, 5e-2), (float((w_t3 - w_t2).abs().max()), float((m_t3 - m_t2).abs().max()))
+    # and it trains: five steps stay within the band in which two correct trainers of this network drift apart
+    w_t5, _, _ = run(False, 5)
+    w_f5, _, _ = run(True, 5)
+    assert float((w_f5 - w_t5).abs().max()) < 0.2 and float((w_f5 - w_t).abs().max()) > 1e-3
+    # a parameter that leaves the flat buffer is refused, not silently skipped
+    torch.manual_seed(21)
+    m = get_model("ResNet14", 28, 5).to(dev)
+    red = BucketedGradAllReduce(m)
+    opt = FlatSGD(red, lr=0.05, momentum=0.9)
+    m.final.bias.data = m.final.bias.data.clone()
+    with pytest.raises(RuntimeError, match="no longer lives in the flat buffers"):
+        opt.step()
 
 
 def test_segmentation_and_augmented_training_runs(tmp_path):
