@@ -47,3 +47,29 @@ for i in range(48, 58): step(i)
 torch.cuda.synchronize()
 pr.disable()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22); print(s.getvalue()[:4500])
+
+# (c) the library calls themselves: every mink_* entry point wrapped with a host timer (both the main thread and autograd's)
+from nerf_downstream_amd._lib import lib
+L = lib()
+acc = collections.defaultdict(lambda: [0, 0.0])
+def wrap(name, fn):
+    def timed(*a):
+        t = time.perf_counter()
+        r = fn(*a)
+        e = acc[name]; e[0] += 1; e[1] += time.perf_counter() - t
+        return r
+    return timed
+from nerf_downstream_amd import _lib as _lm
+for name in _lm.SIGNATURES:
+    setattr(L, name, wrap(name, getattr(L, name)))
+for i in range(60, 68): step(i)
+torch.cuda.synchronize(); acc.clear()
+t0 = time.perf_counter()
+for i in range(68, 68 + N): step(i)
+th = time.perf_counter() - t0
+torch.cuda.synchronize()
+print(f"host {th / N * 1e3:.3f} ms/step with the timers; library calls per step:")
+tot = 0.0
+for name, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:14]:
+    print(f"  {name:40s} {c / N:6.1f} calls  {t / N * 1e6:8.1f} us"); tot += t
+print(f"  all library calls: {sum(t for _, t in acc.values()) / N * 1e6:.0f} us/step")
