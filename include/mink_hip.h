@@ -710,7 +710,7 @@ int mink_stream_destroy(void *stream);
 /* ------------------------------------------------------------------ kernel timing (measurement only)
  * bench.py reports the roofline of the dominant convolution kernel from HIP events recorded on the stream each
  * kernel is launched on.  mode 0: off; 1: every convolution launch; 2: only launches matching (kind, K, cin, cout).
- * kind: 0 forward, 1 data gradient, 2 weight gradient.  mink_conv_timing_fetch synchronises the recorded events,
+ * kind: 0 forward, 1 data gradient, 2 weight gradient, -1 (mode 2) any of them -- the passes of one layer.  mink_conv_timing_fetch synchronises the recorded events,
  * writes up to `max` entries and clears the list; returns the number written (or the number pending if out == NULL). */
 typedef struct {
   int32_t kind, K, cin, cout;

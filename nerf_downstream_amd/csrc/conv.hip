@@ -2178,7 +2178,7 @@ struct ScopedTimer {  // records an event pair around the launches of one convol
   hipStream_t st;
   ScopedTimer(int kind, int64_t n_in, int64_t n_out, int K, int cin, int cout, const int32_t *nbr, hipStream_t stream) : st(stream) {
     if (g_time_mode == 0) return;
-    if (g_time_mode == 2 && !(kind == g_time_kind && K == g_time_K && cin == g_time_cin && cout == g_time_cout)) return;
+    if (g_time_mode == 2 && !((g_time_kind < 0 || kind == g_time_kind) && K == g_time_K && cin == g_time_cin && cout == g_time_cout)) return;
     std::lock_guard<std::mutex> lk(g_time_mu);
     for (hipEvent_t *ev : {&t.a, &t.b}) {
       if (!g_event_pool.empty()) {

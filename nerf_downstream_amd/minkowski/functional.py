@@ -110,8 +110,9 @@ def _parse_tag(tag):
     return _KINDS.index(kind), int(n_out), int(K), int(cin), int(cout)
 
 
-def enable_kernel_timing(on=True, only=None):
-    """`only`: a tag "kind[n_out x K:cin->cout]" -- every launch of that kind / K / cin / cout is timed."""
+def enable_kernel_timing(on=True, only=None, any_kind=False):
+    """`only`: a tag "kind[n_out x K:cin->cout]" -- every launch of that kind / K / cin / cout is timed (`any_kind`: of that
+    K / cin / cout, whatever the kind -- forward, data gradient and weight gradient of one layer)."""
     global _TIMING_MODE, _TIMING_ONLY
     L = lib()
     n = L.mink_conv_timing_fetch(None, 0)
@@ -129,7 +130,7 @@ def enable_kernel_timing(on=True, only=None):
     else:
         kind, _, K, cin, cout = _parse_tag(only)
         _TIMING_MODE, _TIMING_ONLY = 2, only
-        L.mink_conv_timing(2, kind, K, cin, cout)
+        L.mink_conv_timing(2, -1 if any_kind else kind, K, cin, cout)
 
 
 def note_table(*tables):
