@@ -320,10 +320,12 @@ def main():
         # (hipExtStreamCreateWithCUMask has no non-blocking flag) synchronises implicitly with the default stream
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
-    if dev.type == "cuda" and float(os.environ.get("BENCH_RESERVE_GB", "0")) > 0:
-        # one large cached block for the caching allocator to carve from: the two alternating batches differ in size, and the
-        # allocator otherwise grows by hipMalloc (3-13 ms each) for tens of steps
-        torch.empty(int(float(os.environ["BENCH_RESERVE_GB"]) * 2 ** 30), dtype=torch.uint8, device=dev)
+    if dev.type == "cuda":
+        # one large segment for the caching allocator to carve from (nerf_downstream_amd/memory.py; MINK_RESERVE_GB=0: off): the two
+        # alternating batches differ in size, and the pool otherwise grows by hipMalloc (up to 13 ms a call) inside timed steps
+        from nerf_downstream_amd.memory import reserve
+
+        reserve(dev)
     torch.manual_seed(777)  # same initial weights on every rank (reference: pl.seed_everything)
     model = get_model(args.model, args.in_channel, args.num_classes).to(dev)
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}

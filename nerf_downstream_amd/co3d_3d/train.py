@@ -196,6 +196,10 @@ def train(
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on hosts without the legacy path)
         dist.init_process_group("nccl" if device.type == "cuda" else "gloo")
     os.makedirs(save_path, exist_ok=True)
+    if device.type == "cuda":
+        from nerf_downstream_amd.memory import reserve
+
+        reserve(device)  # one segment for the caching allocator to split, instead of hipMalloc calls in the middle of steps
 
     torch.manual_seed(seed)  # identical initial weights on every rank (reference: pl.seed_everything)
     if model is None:

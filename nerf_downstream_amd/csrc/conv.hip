@@ -2319,6 +2319,9 @@ static int compact_plan(int64_t n_rows, int K, int cout) {
   for (int kper = CKP; kper >= 1; --kper) {
     const int zs = (int)cdiv(K, kper);
     if (zs > 14 || tiles * zs > wg_cap || (zs > 1 && zs > slab_cap)) break;
+    // (seven slabs that already fill a resident round are not worth doubling: layer 1 at four scenes, 144 tiles -- 7 slabs 33-35 us,
+    //  14 slabs 37-39, scripts/ksplit_sweep.py fp32 30 4; the reduce reads twice the slabs for the same round count per CU)
+    if (zs > 7 && best == 7 && tiles * 7 >= 1000) break;
     best = zs;
   }
   return best;

@@ -1,0 +1,34 @@
+"""Device-memory plumbing: one large segment for torch's caching allocator to carve from.
+
+A training step allocates its activations, gradient scratch and the next batch's maps from torch's caching allocator.  The
+batches differ in size (the reference's CO3D scenes have 30-90 k voxels each), so for tens of steps the allocator keeps
+meeting a request no cached block fits and goes to `hipMalloc` -- 0.1 ms for a small block, 3-13 ms for one of a few hundred
+megabytes, paid in the middle of a step (measured: ResNet34 at four scenes, one 13 ms call every ten steps while the pool was
+still growing; a bench.py run of twenty steps that catches one reads 4.2-4.6 ms per step instead of 3.7).  An MI355X has 288 GB:
+take one segment up front and hand it to the pool; every later request of >= 1 MB is a split of it.
+"""
+import os
+
+import torch
+
+_RESERVED = {}
+
+
+def reserve(device, gigabytes=None):
+    """Make torch's caching allocator own ONE free segment of `gigabytes` on `device` (default: $MINK_RESERVE_GB, else 24 GB,
+    never more than a quarter of the memory that is free; 0 = do nothing).  Idempotent per device; returns the bytes reserved."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return 0
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _RESERVED:
+        return _RESERVED[idx]
+    if gigabytes is None:
+        gigabytes = float(os.environ.get("MINK_RESERVE_GB", "24"))
+    free, _ = torch.cuda.mem_get_info(idx)
+    nbytes = int(min(gigabytes * 2 ** 30, free // 4)) // (2 << 20) * (2 << 20)
+    if nbytes > 0:
+        block = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+        del block  # (back to the allocator's pool of free LARGE blocks: split on demand, never returned to the driver)
+    _RESERVED[idx] = nbytes
+    return nbytes

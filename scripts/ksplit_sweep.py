@@ -1,5 +1,5 @@
 """Split-K factor sweep of the mid-layer forward / data-gradient convolutions in one math mode (run on the GPU box).
-usage: python scripts/ksplit_sweep.py [fp32|bf16] [reps]"""
+usage: python scripts/ksplit_sweep.py [fp32|bf16] [reps] [scenes per batch = 16]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
@@ -11,7 +11,8 @@ from nerf_downstream_amd.minkowski import functional as Fn
 math = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda", 0)
-b = make_batches(1, 16, 0, 51, 128, 28)[0]
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+b = make_batches(1, B, 0, 51, 128, 28)[0]
 x0 = ME.TensorField(coordinates=b["coordinates"].to(dev), features=b["features"].to(dev)).sparse()
 m = x0.coordinate_manager
 ME.set_conv_math(math)
@@ -39,7 +40,7 @@ def layer(name, ts_in, ts_out, cin, cout):
         plan = lib().mink_conv_plan(n_out if kind == "fwd" else (perm.numel() if perm is not None else n_out), 27,
                                     cin if kind == "fwd" else cout, cout if kind == "fwd" else cin, int(kind == "dgrad" and perm is not None))
         res = []
-        for ks in (1, 2, 3, 4, 5, 7, 9, 14):
+        for ks in (1, 2, 3, 4, 5, 7, 9, 14, 27):
             Fn._FORCE_KSPLIT = ks
             try:
                 if kind == "fwd":

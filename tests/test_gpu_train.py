@@ -511,3 +511,24 @@ def test_scannet_plenoxel_segmentation_on_gpu(tmp_path):
         assert any("val/mIoU" in h for h in res["history"])
     assert len(losses["hip"]) == 6 and abs(losses["hip"][0] - losses["cpu"][0]) < 1e-3, (losses["hip"][:2], losses["cpu"][:2])
     assert np.allclose(losses["hip"][:3], losses["cpu"][:3], atol=2e-2)
+
+
+@pytest.mark.gpu
+def test_reserved_segment_serves_later_allocations():
+    """memory.reserve(): one segment handed to torch's caching allocator up front; allocations of a training step are then splits of it
+    (no growth of the reserved total), and a second call is a no-op."""
+    from nerf_downstream_amd import memory
+
+    dev = torch.device("cuda", 0)
+    memory._RESERVED.clear()
+    torch.cuda.empty_cache()
+    got = memory.reserve(dev, gigabytes=1.0)
+    assert got == 1 << 30 and memory.reserve(dev, gigabytes=8.0) == got
+    before = torch.cuda.memory_reserved(dev)
+    assert before >= got
+    blocks = [torch.empty(s << 20, dtype=torch.uint8, device=dev) for s in (3, 40, 200, 17, 256)]
+    assert torch.cuda.memory_reserved(dev) == before  # carved out of the segment: no new hipMalloc
+    del blocks
+    assert memory.reserve(torch.device("cpu")) == 0
+    memory._RESERVED.clear()
+    torch.cuda.empty_cache()
