@@ -443,12 +443,14 @@ __device__ __forceinline__ void kernel_map_blk_body(const unsigned long long *__
 // (cell + 1) per axis -- so the thread probes eight block entries and answers all 27 look-ups from their masks with
 // bit tests and popcounts: ~20 instructions per neighbour instead of ~300 for one probe chain each.  Results are
 // staged in LDS and written as one contiguous run per workgroup.
+struct __attribute__((packed, aligned(4))) Row27 {
+  int v[27];
+};
 template <bool HAS_T>
 __device__ __forceinline__ void kernel_map_blk27_body(const unsigned long long *__restrict__ table, const int *__restrict__ base,
                                                       const int *__restrict__ rowids, uint64_t mask, int ts,
                                                       const int *__restrict__ out_coords, int64_t n_out, int *__restrict__ nbr,
                                                       int *nbr_t) {
-  __shared__ int s_out[kBlock * 27];
   const int64_t o0 = (int64_t)blockIdx.x * kBlock;
   const int64_t o = o0 + threadIdx.x;
   const bool live = o < n_out;
@@ -481,6 +483,7 @@ __device__ __forceinline__ void kernel_map_blk27_body(const unsigned long long *
   }
   // the centre cell of an axis shares block A unless it sits on the low face of its block (then it is in B)
   const bool cB[3] = {(u[0] & 3) == 0, (u[1] & 3) == 0, (u[2] & 3) == 0};
+  int out[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     const int d[3] = {k % 3 - 1, (k / 3) % 3 - 1, k / 9 - 1};
@@ -506,14 +509,18 @@ __device__ __forceinline__ void kernel_map_blk27_body(const unsigned long long *
     const int local = ((u[0] + d[0]) & 3) | (((u[1] + d[1]) & 3) << 2) | (((u[2] + d[2]) & 3) << 4);
     int v = -1;
     if ((m >> local) & 1ull) v = rowids[bs + __popcll(m & ((1ull << local) - 1ull))];
-    if (!live) v = -1;
-    s_out[threadIdx.x * 27 + k] = v;
-    if (HAS_T && v >= 0) nbr_t[(int64_t)v * 27 + k] = (int)o;
+    out[k] = v;
+    if (HAS_T && live && v >= 0) nbr_t[(int64_t)v * 27 + k] = (int)o;
   }
-  __syncthreads();
-  const int64_t rows = n_out - o0 < kBlock ? n_out - o0 : kBlock;
-  const int total = (int)rows * 27;
-  for (int e = threadIdx.x; e < total; e += kBlock) nbr[o0 * 27 + e] = s_out[e];
+  // the row's 27 entries (108 contiguous bytes, 4-byte aligned) leave as six 16-byte stores and one of 12: no LDS staging --
+  // the 27.6 KB per workgroup it took kept up to 138 KB of a CU's LDS away from the convolution kernels this one runs beside
+  if (live) {
+    Row27 *dst = reinterpret_cast<Row27 *>(nbr + o * 27);
+    Row27 r;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) r.v[k] = out[k];
+    *dst = r;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void kernel_map_blk_kernel(const unsigned long long *__restrict__ table,
