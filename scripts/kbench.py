@@ -373,3 +373,24 @@ if which == "cab":  # compact kernel: full / every gather reads row 0 (16) / no 
             res.append(timeit(lambda: Fn.gather_gemm(xin, w, nbr, c), reps) * 1e3)
         lib().mink_conv_set_stagger(0)
         print(f"l@{ts}.c2 fwd rows={nbr.shape[0]} {c}->{c}: full {res[0]:.1f} / {res[4]:.1f} us, gathers from row 0 {res[1]:.1f}, no MFMA {res[2]:.1f}, neither {res[3]:.1f}; no MFMA + no scatter {res[5]:.1f}, + one block of LDS operands {res[6]:.1f}, + both {res[7]:.1f}; one weight block {res[8]:.1f}, + gathers from row 0 {res[9]:.1f}, + no MFMA {res[10]:.1f}; NO ITEMS (prologue + epilogue + split-K reduce) {res[11]:.1f}")
+
+if which == "cabp":  # the class-permuted data gradient of the stride-2 convolutions: full / no matrix work / no items at all
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    for ts in (2, 4, 8, 16):
+        cin, cout = chans[ts], chans[2 * ts]
+        nbr, nbr_t = m.kernel_table(keys[ts], keys[2 * ts], 3, 1, transposed=True)
+        perm = m.class_perm(keys[ts])
+        gy = torch.randn(nbr.shape[0], cout, device=dev)
+        w = torch.randn(27, cin, cout, device=dev) * 0.05
+        res = []
+        for ab in (0, 32, 32 + 64, 16, 8 + 16, 4, 0):
+            lib().mink_conv_set_stagger(ab)
+            res.append(timeit(lambda: Fn.gather_gemm(gy, w, nbr_t, cin, w_transposed=True, row_perm=perm), reps) * 1e3)
+        lib().mink_conv_set_stagger(0)
+        pairs = int((nbr >= 0).sum())
+        print(f"l@{2 * ts}.c1 dgrad rows={nbr_t.shape[0]} (perm {perm.numel()}) {cout}->{cin}, {pairs} pairs = {2e-9 * pairs * cin * cout:.2f} GFLOP: full {res[0]:.1f} / {res[6]:.1f} us, "
+              f"no MFMA {res[1]:.1f}, + no scatter {res[2]:.1f}; gathers from row 0 {res[3]:.1f}, + one weight block {res[4]:.1f}; NO ITEMS {res[5]:.1f}")
