@@ -69,7 +69,7 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(240)
 def test_bucketed_allreduce_world2(tmp_path, oracle_maps):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
@@ -124,7 +124,7 @@ def _imbalance_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(150)
 def test_collectives_are_issued_in_one_order_under_imbalance(tmp_path, oracle_maps):
     """The deadlock hazard of data parallelism with deferred launches is a rank-dependent ISSUE ORDER of the bucket
     all-reduces (RCCL matches collectives by order).  Two ranks with very different batches (2 scenes vs 12) that report
@@ -161,7 +161,7 @@ def test_flat_buffer_layout_single_process():
     assert float(red.flat.abs().sum()) == 0.0
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(150)
 def test_bench_self_launches_one_rank_per_gpu():
     """`python bench.py --gpus 2` with no launcher environment starts its own ranks under torch.distributed.run (as
     a child process -- the parent never touches the GPU) and relays rank 0's JSON line.  --dry-run: rendezvous and one
