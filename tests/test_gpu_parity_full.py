@@ -77,7 +77,7 @@ def _baseline_batch(batch=16, grid=128, cin=28):
 
 
 @pytest.mark.long
-@pytest.mark.timeout(45)
+@pytest.mark.timeout(30)
 def test_baseline_batch_forward_and_maps_match_oracle(oracle_maps):
     """BASELINE config #2's own batch (B=16, 128^3, ~825 k voxels x 28 features)."""
     from nerf_downstream_amd import minkowski as ME
@@ -204,7 +204,7 @@ def _check_every_map(oracle_maps, field, coords, plan_ops):
 
 
 @pytest.mark.long
-@pytest.mark.timeout(60)
+@pytest.mark.timeout(45)
 @pytest.mark.parametrize("name,batch,math", [("ResNet14", 16, "fp32"), ("ResNet34", 4, "fp32"), ("ResNet14", 16, "bf16"),
                                              ("ResNet14", 16, "bf16s")])
 def test_baseline_batch_backward_and_every_map_match_oracle(oracle_maps, name, batch, math):
@@ -336,7 +336,7 @@ TOP1_FIXTURE = os.path.join(ROOT, "tests", "golden", "top1_oracle_v1.npz")
 
 
 @pytest.mark.long
-@pytest.mark.timeout(60)
+@pytest.mark.timeout(40)
 def test_fixed_split_top1_matches_oracle(oracle_maps):
     """north_star: "top-1 on a fixed synthetic split matching reference +-0.1 %".  SURVEY 8d's split (512 training / 128
     validation scenes, 51 classes, 300 steps, same seeds; tests/top1_recipe.py) on a task that does NOT saturate: the class
@@ -416,7 +416,7 @@ HIP_SEEDS = tuple(range(24))
 
 
 @pytest.mark.long
-@pytest.mark.timeout(60)
+@pytest.mark.timeout(45)
 def test_fixed_split_top1_statistics():
     """north_star: "top-1 on a fixed synthetic split matching reference +-0.1 %" as the statistical statement it can only
     be (fp32 training of this network is chaotic: test_reference_training_does_not_reproduce_itself).
@@ -464,7 +464,7 @@ def test_fixed_split_top1_statistics():
 
 
 @pytest.mark.long
-@pytest.mark.timeout(120)
+@pytest.mark.timeout(100)
 def test_reference_training_does_not_reproduce_itself(oracle_maps, monkeypatch):
     """Why the fixed-split criterion above is not "identical trajectories": the CPU oracle alone, run with two thread
     counts (only its summation order changes), leaves its own trajectory within a dozen steps of the same recipe."""

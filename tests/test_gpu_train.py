@@ -221,7 +221,7 @@ def _dp_worker(rank, world, port, out):
 
 
 @pytest.mark.long
-@pytest.mark.timeout(90)
+@pytest.mark.timeout(60)
 def test_data_parallel_two_ranks_on_card(tmp_path):
     mp.spawn(_dp_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
@@ -270,7 +270,7 @@ def _syncbn_worker(rank, world, port, out):
 
 
 @pytest.mark.long
-@pytest.mark.timeout(90)
+@pytest.mark.timeout(60)
 def test_sync_batch_norm_two_ranks(tmp_path):
     """MinkowskiSyncBatchNorm over 2 ranks == BatchNorm1d over the concatenated rows."""
     mp.spawn(_syncbn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
@@ -292,7 +292,7 @@ def test_sync_batch_norm_two_ranks(tmp_path):
 
 
 @pytest.mark.long
-@pytest.mark.timeout(90)
+@pytest.mark.timeout(60)
 def test_train_cli_with_dataloader_workers(tmp_path):
     """The CLI entry point end to end on the GPU: gin files, DataLoader worker processes running
     collate_mink (CPU-only, forked after HIP is initialised in the parent), checkpoints."""
@@ -332,6 +332,8 @@ def _write_co3d_scenes(root, n_scenes=16):
         (root / "filelist" / f"{phase}.txt").write_text("\n".join(lines) + "\n")
 
 
+@pytest.mark.long
+@pytest.mark.timeout(150)
 def test_train_on_co3d_format_compact_equals_decoded(tmp_path, monkeypatch):
     """train() on a tiny tree in the reference's on-disk format, DataLoader workers included: the
     compact path (GPU-side decode) and the ordinary path (CPU decode) give the same loss history."""
@@ -426,6 +428,8 @@ def test_flat_sgd_is_torch_sgd(tmp_path):
         opt.step()
 
 
+@pytest.mark.long
+@pytest.mark.timeout(100)
 def test_segmentation_and_augmented_training_runs(tmp_path):
     """train() end to end on the GPU for the two widened rows: (a) SegmentationTraining + Res16UNet on per-voxel
     labels (two-phase prepare replays the plan with the transposed tables and parity-class orders of the decoder),
@@ -463,7 +467,7 @@ def test_segmentation_and_augmented_training_runs(tmp_path):
 
 
 @pytest.mark.long
-@pytest.mark.timeout(90)
+@pytest.mark.timeout(60)
 def test_bench_two_ranks_self_launched(tmp_path):
     """`python bench.py --gpus 2` as the driver would type it (no launcher): bench.py starts its own two ranks under
     torch.distributed.run and rank 0's JSON line comes back.  Rehearsal transport: gloo, both ranks on this one card
