@@ -34,8 +34,10 @@ elif int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BENCH_FORCE_R
     # Data parallelism: one rank drives the compute, map-preparation and weight-gradient streams plus the two streams of
     # the RCCL process group.  HIP multiplexes streams over GPU_MAX_HW_QUEUES (default 4) hardware queues and two busy
     # streams on one queue serialise (measured with a one-rank group: 5.5 ms/step against 4.85 with a queue for each).
-    # The HIP runtime reads it when it is loaded -- before `import torch`.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # The HIP runtime reads it when it is loaded -- before `import torch`.  SEVEN, not eight: with the bucket-launch stream of
+    # round 4 a rank has five busy streams, and at eight hardware queues the step falls off a cliff (one-rank RCCL group,
+    # ResNet14 B=16: 4 queues 4.27 ms, 5: 4.11, 6: 3.95, 7: 3.81, 8: 5.7-6.0; ResNet34 B=4: 7: 4.3-4.6, 8: 12.6).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "7")
     # (this pool's host driver only supports dmabuf IPC: without it RCCL fails in hipIpcGetMemHandle; already exported on the
     #  boxes -- kept here for an environment that lost it)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -331,7 +333,7 @@ def main():
     state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     # one flat gradient buffer the backward kernels write into; with N > 1 ranks its buckets are all-reduced (overlapped
     # with backward), with one rank that is all it is -- the step is the same program at every N
-    reducer = BucketedGradAllReduce(model, bucket_bytes=int(os.environ.get("BENCH_BUCKET_BYTES", 8 << 20)), force=force_reducer)
+    reducer = BucketedGradAllReduce(model, bucket_bytes=int(os.environ.get("BENCH_BUCKET_BYTES", 32 << 20)), force=force_reducer)
     # SGD with momentum and weight decay (configs/co3d_cls.gin) as one kernel over the flat buffers (parallel.FlatSGD;
     # BENCH_TORCH_SGD=1: torch's fused multi-tensor SGD, the same update)
     if dev.type == "cuda" and os.environ.get("BENCH_TORCH_SGD", "0") == "0":

@@ -475,6 +475,9 @@ def _sink_views(*params):
     sink = _GRAD_SINK
     if sink is None:
         return None
+    bulk = getattr(sink, "views_for", None)
+    if bulk is not None:
+        return bulk(params)
     views = []
     for p in params:
         v = sink.view_for(p)

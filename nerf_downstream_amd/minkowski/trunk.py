@@ -473,11 +473,15 @@ class TrunkFunction(torch.autograd.Function):
         if collect:
             # every block's gradients are queued: report them in backward order, each with the event behind which they are
             # complete, so that a bucket's all-reduce waits for exactly its own blocks and overlaps the rest of backward
+            many = getattr(sink, "ready_many", None)
             for si in range(len(plan.stages) - 1, -1, -1):
                 st = plan.stages[si]
                 sink.stage_event = evp[si]
-                for i in range(st.pidx, st.pidx + st.np):
-                    sink.ready(params[i])
+                if many is not None:
+                    many(params[st.pidx : st.pidx + st.np])
+                else:
+                    for i in range(st.pidx, st.pidx + st.np):
+                        sink.ready(params[i])
             sink.stage_event = None
             sink.flush()  # everything complete so far goes out beside the stem's weight gradient (0.9 ms)
             for i in range(3):

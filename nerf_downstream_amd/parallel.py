@@ -7,9 +7,11 @@ per-rank BatchNorm statistics, mean of gradients across ranks once per step.  He
 * all parameter gradients live in ONE flat fp32 buffer (`.grad` tensors are views), laid out
   in REVERSE registration order so the buffer fills front-to-back as backward proceeds
   (layer4 -- 74 % of the bytes -- first);
-* the buffer is cut into buckets of >= 8 MiB (one parameter tensor is never split: layer4's two
-  3^3 kernels are 28 MB and 14 MB messages on their own, ready first); the LAST bucket, which
-  cannot overlap with anything, holds only the stem convolution + its batch norm (0.2 MB);
+* the buffer is cut into buckets of >= 32 MiB (one parameter tensor is never split; Mink-ResNet34's 81 MB are 4 messages of
+  >= 32 MB and the stem's, ResNet14's 11 MB one and the stem's: few, large collectives are what xGMI's point-to-point links
+  want, and every collective costs the host ~50 us of a step that is host-bound under data parallelism -- 15 buckets of >= 8 MiB
+  were 0.77 ms per ResNet34 step); the LAST bucket, which cannot overlap with anything, holds only the stem convolution +
+  its batch norm (0.2 MB);
 * a post-accumulate-grad hook counts ready parameters per bucket and launches the bucket's
   `all_reduce(async_op=True)` once it is complete -- RCCL runs it on its own HIP stream, overlapped
   with the remaining backward kernels.  On the GPU (gradient-sink mode) a complete bucket is not
@@ -26,7 +28,7 @@ import torch.distributed as dist
 
 
 class BucketedGradAllReduce:
-    def __init__(self, module, bucket_bytes=8 << 20, process_group=None, force=False):
+    def __init__(self, module, bucket_bytes=32 << 20, process_group=None, force=False):
         """`force`: run the whole machinery (hooks, gradient sink, collectives) in a one-rank group too -- for measuring
         its overhead on a single GPU (bench.py BENCH_FORCE_REDUCER=1).
 
@@ -143,6 +145,40 @@ class BucketedGradAllReduce:
         self._written.add(k)
         return g
 
+    def views_for(self, params):
+        """`view_for` over a list, all or nothing, in one call (the native trunk claims ~40 / ~110 slices per step: the per-call
+        overhead of doing so one at a time was 0.1 ms of a host-bound ResNet34 step)."""
+        if not self._active:
+            return None
+        views, written, out = self._views, self._written, []
+        for p in params:
+            k = id(p)
+            g = views.get(k)
+            if g is None or k in written or p.grad is not g:
+                return None
+            out.append(g)
+        written.update(id(p) for p in params)
+        return out
+
+    def ready_many(self, params):
+        """`ready` for every parameter of a block (they share `stage_event`)."""
+        if not self._collect:
+            return
+        counted, bucket_of, ready, buckets = self._counted, self._bucket_of, self._ready, self.buckets
+        done = False
+        for p in params:
+            k = id(p)
+            if k in counted:
+                continue
+            counted.add(k)
+            b = bucket_of[k]
+            ready[b] += 1
+            if ready[b] == buckets[b][2]:
+                self._bucket_event[b] = self.stage_event
+                done = True
+        if done and not self.defer:
+            self._drain()
+
     def gradients(self):
         """The parameter gradients in buffer order (reverse registration order) without the alignment padding."""
         return torch.cat([p.grad.flatten() for p in self._params])
@@ -214,10 +250,30 @@ class BucketedGradAllReduce:
         inside a stage the two complete neighbouring buckets in opposite orders.  The flat buffer is laid out in reverse
         registration order, so ascending bucket order is (nearly) completion order anyway: a bucket waits for its
         predecessor for a few kernels at most."""
+        first = self._next
         while self._next < len(self.buckets) and self._ready[self._next] == self.buckets[self._next][2]:
-            if not self._launched[self._next]:
-                self._launch(self._next)
             self._next += 1
+        todo = [b for b in range(first, self._next) if not self._launched[b]]
+        if len(todo) > 1 and self.flat.is_cuda and all(self._bucket_event[b] is not None for b in todo):
+            # the one-call backward reports every block after the whole pass is queued: several buckets go out at once, from
+            # the launch stream, each behind its own event -- one stream switch for all of them
+            from ._lib import check, lib
+
+            if self._launch_stream is None:
+                self._launch_stream = torch.cuda.Stream(device=self.flat.device)
+            wait, ls = lib().mink_stream_wait_event, self._launch_stream.cuda_stream
+            with torch.cuda.stream(self._launch_stream):
+                for b in todo:
+                    s, e, _ = self.buckets[b]
+                    self._launched[b] = True
+                    self.launch_log.append((b, s, e))
+                    check(wait(ls, self._bucket_event[b]))
+                    self._work.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
+            if len(self.launch_log) > 4096:
+                del self.launch_log[:2048]
+            return
+        for b in todo:
+            self._launch(b)
 
     def flush(self):
         """Launch the collectives of the buckets completed so far.  With `defer` (gradient-sink mode) a complete
@@ -258,8 +314,13 @@ class BucketedGradAllReduce:
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
-        for w in self._work:
-            w.wait()
+        if self._avg and self._work:
+            # RCCL runs the collectives of one communicator on ONE stream in issue order: the current stream waiting for the last
+            # of them has waited for all (each wait() is ~25 us of host time; gloo completes on the CPU and needs every one)
+            self._work[-1].wait()
+        else:
+            for w in self._work:
+                w.wait()
         self._work.clear()
         if not self._avg:
             self.flat.mul_(1.0 / self.world)

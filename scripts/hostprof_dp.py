@@ -28,11 +28,12 @@ wrap(dist, "all_reduce", "dist.all_reduce")
 wrap(torch.cuda.Stream, "wait_stream", "Stream.wait_stream")
 
 torch.manual_seed(0)
-model = get_model("ResNet14", 28, 51).to(dev)
+MODEL, BATCH = os.environ.get("MODEL", "ResNet14"), int(os.environ.get("BATCH", "16"))
+model = get_model(MODEL, 28, 51).to(dev)
 opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=True)
 use = os.environ.get("DP", "1") == "1"
 reducer = BucketedGradAllReduce(model, force=True) if use else None
-batches = make_batches(2, 16, 0, 51, 128, 28)
+batches = make_batches(2, BATCH, 0, 51, 128, 28)
 batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
 state = {"tf": model.process_input(batches[0])}
 W = collections.defaultdict(float)
