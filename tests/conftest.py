@@ -40,7 +40,7 @@ def pytest_collection_modifyitems(config, items):
     long_.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), 0))
     items[:] = short + long_
     # every test has a timeout: the marked ones their own (the long tests; with -x only ONE test can ever run into its limit, and the
-    # largest mark -- 150 s -- plus the ~3 minutes of the whole suite stays far inside the driver's 900 s),
+    # largest mark -- 120 s -- plus the ~3 minutes of the whole suite stays far inside the driver's 900 s),
     # everything else 60 s (they take 0.01-5 s)
     for it in items:
         if it.get_closest_marker("timeout") is None:

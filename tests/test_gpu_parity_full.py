@@ -464,7 +464,7 @@ def test_fixed_split_top1_statistics():
 
 
 @pytest.mark.long
-@pytest.mark.timeout(100)
+@pytest.mark.timeout(90)
 def test_reference_training_does_not_reproduce_itself(oracle_maps, monkeypatch):
     """Why the fixed-split criterion above is not "identical trajectories": the CPU oracle alone, run with two thread
     counts (only its summation order changes), leaves its own trajectory within a dozen steps of the same recipe."""

@@ -333,7 +333,7 @@ def _write_co3d_scenes(root, n_scenes=16):
 
 
 @pytest.mark.long
-@pytest.mark.timeout(150)
+@pytest.mark.timeout(120)
 def test_train_on_co3d_format_compact_equals_decoded(tmp_path, monkeypatch):
     """train() on a tiny tree in the reference's on-disk format, DataLoader workers included: the
     compact path (GPU-side decode) and the ordinary path (CPU decode) give the same loss history."""
@@ -429,7 +429,7 @@ def test_flat_sgd_is_torch_sgd(tmp_path):
 
 
 @pytest.mark.long
-@pytest.mark.timeout(100)
+@pytest.mark.timeout(80)
 def test_segmentation_and_augmented_training_runs(tmp_path):
     """train() end to end on the GPU for the two widened rows: (a) SegmentationTraining + Res16UNet on per-voxel
     labels (two-phase prepare replays the plan with the transposed tables and parity-class orders of the decoder),
@@ -489,7 +489,7 @@ def test_bench_two_ranks_self_launched(tmp_path):
 
 
 @pytest.mark.long
-@pytest.mark.timeout(100)
+@pytest.mark.timeout(70)
 def test_one_rank_rccl_group_costs_little(tmp_path):
     """The whole data-parallel machinery (RCCL process group of ONE rank, gradient sink, bucket launches behind per-block events,
     branch on the weight-gradient stream, bench.py's own choice of hardware queues) against the plain single-GPU step, both at the
@@ -505,7 +505,7 @@ def test_one_rank_rccl_group_costs_little(tmp_path):
             env["BENCH_FORCE_REDUCER"] = "1"
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
                "--no-kernel-timing"]
-        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=90)
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=33)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
