@@ -115,12 +115,10 @@ def test_baseline_batch_forward_and_maps_match_oracle(oracle_maps):
         assert np.array_equal(got.cpu().numpy(), want), (kin.ts, kout.ts, ks)
 
 
-def _trimmed_rel_err(g, g64):
-    """Relative L2 error without the worst 1 % of output channels (last axis): see tests/test_gpu_resnet.py."""
-    C = g64.shape[-1]
-    d2 = ((g - g64) ** 2).reshape(-1, C).sum(0)
-    keep = torch.argsort(d2)[: C - max(1, C // 100)]
-    return float(torch.sqrt(d2[keep].sum() / (g64 ** 2).sum().clamp_min(1e-300)))
+def _rel_err(g, g64):
+    """Plain relative L2 error of one tensor -- every element counts (until round 4 the worst 1 % of output channels was
+    trimmed here; with the ReLU branches of the HIP run imposed on the yardstick there is nothing for a trim to excuse)."""
+    return float((g - g64).norm() / g64.norm().clamp_min(1e-300))
 
 
 def _relu_masks_of_hip_run(out):
@@ -138,6 +136,117 @@ def _relu_masks_of_hip_run(out):
         masks.append((arena[cnt : 2 * cnt].view(n_out, st.C) > 0).cpu())
         masks.append((arena[3 * cnt : 4 * cnt].view(n_out, st.C) > 0).cpu())
     return masks
+
+
+def _stem_masks_of_hip_run(out, model):
+    """The stem ReLU's branch decisions as the HIP backward kernels take them.  The trunk keeps only the POOLED sum of the
+    stem's ReLU output, so its backward kernels recompute z = gamma * xhat + beta from the kept convolution output y and
+    the batch's (mean, 1 / std) -- and the two kernels that do so round xhat differently (both are valid fp32):
+      * gamma / beta gradients (csrc/elementwise.hip, colreduce / bn_relu_pool_bwd_kernel; also the forward's own
+        decision):                      xhat = fl(fl(y - mean) * invstd),        z = fma(xhat, gamma, beta)
+      * the weight gradient (csrc/conv.hip, wgrad_stream_kernel<.., FUSE>): xhat = fma(y, invstd, fl(-mean * invstd)), z = fma(xhat, gamma, beta)
+    Both are reproduced here in exact fp32 arithmetic on the CPU (an fma through float64: the product of two floats is exact
+    there).  -> (mask for bn1.*, mask for conv1.kernel), each [n0, C0] bool."""
+    node = trunk_node(out)
+    x, w0, arena0, nbr0, nbr_pool, i2o, pad, b16, _ = node.saved[0]
+    assert not b16, "fp32 storage only"
+    n0, n1, C0 = x.shape[0], nbr_pool.shape[0], w0.shape[-1]
+    a = arena0.detach().cpu()
+    y = a[: n0 * C0].view(n0, C0)
+    mean, invstd = a[n0 * C0 + n1 * C0 : n0 * C0 + n1 * C0 + C0], a[n0 * C0 + n1 * C0 + C0 : n0 * C0 + n1 * C0 + 2 * C0]
+    ga, be = model.bn1.bn.weight.detach().cpu(), model.bn1.bn.bias.detach().cpu()
+
+    def fma(p, q, r):
+        return (p.double() * q.double() + r.double()).float()
+
+    xh_bn = (y - mean) * invstd
+    xh_w = fma(y, invstd, -mean * invstd)
+    return fma(xh_bn, ga, be) > 0, fma(xh_w, ga, be) > 0
+
+
+def _float64_grads_under_hip_branches(name, state, masks, coords, feats, labels, dtype=torch.float64, stem_mask=None):
+    """One forward + backward of the CPU oracle in `dtype` at the weights `state`, with the ReLU branch decisions of the HIP
+    run (`masks`, forward order, every ReLU behind the stem's; `stem_mask`: the stem's, or None = it runs naturally)
+    imposed through oracle.me_cpu.RELU_HOOK.  -> (logits, {name: gradient}, [(relu index, elements whose
+    branch differs from this run's own, largest |z| / rms(z) among them, where)])."""
+    from nerf_downstream_amd.co3d_3d.src.models import get_model
+    from oracle import me_cpu as OME
+
+    m = get_model(name, 28, 51, ME=OME)
+    if dtype == torch.float64:
+        m = m.double()
+    m.load_state_dict({k: (v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu()) for k, v in state.items()})
+    m.train()
+    calls, flips = [0], []
+
+    def hook(z):
+        k = calls[0]
+        calls[0] += 1
+        if k == 0 and stem_mask is None:
+            return torch.relu(z)
+        mk = stem_mask if k == 0 else masks[k - 1]
+        assert mk.shape == z.shape, (k, mk.shape, z.shape)
+        diff = (z > 0) != mk
+        nf = int(diff.sum())
+        zd = z.detach()
+        where = [tuple(int(v) for v in ix) for ix in diff.nonzero()[:4]] if nf else []
+        flips.append((k, nf, float(zd[diff].abs().max() / zd.std()) if nf else 0.0, where))
+        return z * mk.to(z.dtype)
+
+    OME.RELU_HOOK = hook
+    try:
+        o = m(m.process_input({"coordinates": coords, "features": feats.to(dtype)}))
+        loss = F.cross_entropy(o, labels)
+        loss.backward()
+    finally:
+        OME.RELU_HOOK = None
+    assert calls[0] == len(masks) + 1, (calls[0], len(masks) + 1)
+    return o.detach(), float(loss), {k: p.grad for k, p in m.named_parameters()}, flips
+
+
+def _assert_gradients_match_float64(tag, name, hip_grads, state, masks, coords, feats, labels, stem_masks=None, verbose=False):
+    """The rigorous form of "the HIP gradient is the reference's gradient" (no trim, no flip allowance):
+      (1) wherever a ReLU branch of the HIP run differs from the float64 run's own, the float64 pre-activation is zero to
+          fp32 rounding: |z| <= 1e-4 of the tensor's standard deviation -- the flips are legitimate, and each is NAMED in
+          the output (layer, element);
+      (2) with the HIP run's branches imposed on the float64 run, every parameter gradient matches it to rounding: plain
+          relative L2 <= 2e-4 per tensor, the stem's three included: `stem_masks` = _stem_masks_of_hip_run -- bn1.* against
+          the float64 run under the decisions of the kernel that computes them, conv1.kernel under those of the
+          weight-gradient kernel (a second float64 run, only when the two masks differ somewhere)."""
+    sm_bn, sm_w = stem_masks if stem_masks is not None else (None, None)
+    out64, loss64, g64, flips = _float64_grads_under_hip_branches(name, state, masks, coords, feats, labels, stem_mask=sm_bn)
+    if sm_w is not None:
+        ndiff = int((sm_bn != sm_w).sum())
+        print(f"[{tag}] stem ReLU: the weight-gradient kernel and the norm-gradient kernels decide {ndiff} element(s) of {sm_bn.numel()} differently")
+        if ndiff:
+            _, _, g64w, flips_w = _float64_grads_under_hip_branches(name, state, masks, coords, feats, labels, stem_mask=sm_w)
+            g64 = dict(g64, **{"conv1.kernel": g64w["conv1.kernel"]})
+            flips = flips + [f for f in flips_w if f[0] == 0]
+    nflip = sum(f[1] for f in flips)
+    zmax = max(f[2] for f in flips)
+    named = "; ".join(f"relu {f[0]}: {f[1]} element(s) e.g. {f[3][:2]} |z|/sd {f[2]:.1e}" for f in flips if f[1])
+    print(f"[{tag}] ReLU branches of the HIP run that differ from the float64 run's own: {nflip} element(s) in "
+          f"{sum(1 for f in flips if f[1])} of {len(masks) + (stem_masks is not None)} layers, largest |z|/sd(z) there {zmax:.2e}" + (f" -- {named}" if named else ""))
+    assert zmax <= 1e-4, flips
+    worst, bad, table = (None, 0.0), [], []
+    for k, g in hip_grads.items():
+        e = _rel_err(g.detach().cpu().double(), g64[k])
+        bound = 2e-4 if (stem_masks is not None or not (k.startswith("conv1") or k.startswith("bn1"))) else 1e-3
+        table.append(f"{k:34s} hip {e:.2e}  bound {bound:.0e}")
+        if e > worst[1]:
+            worst = (k, e)
+        if not e <= bound:
+            bad.append((k, e))
+    if bad or verbose or os.environ.get("MINK_TEST_VERBOSE"):
+        print(f"[{tag}] per-tensor gradient error vs float64 (HIP's ReLU branches imposed):\n  " + "\n  ".join(table))
+    assert not bad, (tag, bad)
+    flat_g = torch.cat([hip_grads[k].detach().cpu().double().flatten() for k in hip_grads])
+    flat_o = torch.cat([g64[k].flatten() for k in hip_grads])
+    cos = float(torch.dot(flat_g, flat_o) / (flat_g.norm() * flat_o.norm()))
+    tot = float((flat_g - flat_o).norm() / flat_o.norm())
+    print(f"[{tag}] worst per-tensor gradient error vs float64: {worst[0]} {worst[1]:.2e}; all parameters: relative L2 {tot:.2e}, cosine {cos:.10f}")
+    assert cos > 0.999999, cos
+    return out64, loss64, nflip, worst, tot
 
 
 def _bench_like_step(hip, batch, labels, passes=3):
@@ -255,73 +364,13 @@ def test_baseline_batch_backward_and_every_map_match_oracle(oracle_maps, name, b
     # branch with no effect on the loss but a finite one on the gradient, and at this size such elements exist in every
     # stage (~1e-6 relative differences in z between two fp32 summation orders x 0.5-50 M activations per stage): the
     # oracle's own fp32 run sits 9e-4 from the float64 gradient upstream of one.  So the float64 run is made with the
-    # BRANCH DECISIONS OF THE HIP RUN imposed (h > 0 of every ReLU output the trunk kept for its backward pass), and two
-    # things are asserted: (1) wherever HIP's branch differs from the float64 run's own, the float64 pre-activation is
-    # zero to fp32 rounding (|z| <= 1e-4 of the tensor's rms) -- the flips are legitimate; (2) with the branches agreed,
-    # every parameter gradient matches to rounding: relative L2 <= 2e-4 (or 8x the error the oracle's fp32 run makes under
-    # the same imposed branches), no flip allowance.  The stem ReLU (52.8 M elements, only its pooled sum is kept) runs
-    # naturally on both sides; a flip there moves the three stem tensors by <= 1.4e-4 of their norm: bound 1e-3 for them.
+    # BRANCH DECISIONS OF THE HIP RUN imposed (h > 0 of every ReLU output the trunk kept for its backward pass); see
+    # _assert_gradients_match_float64 for the two assertions (legitimate flips; every tensor to rounding, every element
+    # counted, no allowance).
     masks = _relu_masks_of_hip_run(out)
-    n_relu = 1 + 2 * (len(masks) // 2)
-    assert len(masks) + 1 == n_relu
-
-    def oracle_grads(dtype):
-        m = get_model(name, 28, 51, ME=OME)
-        if dtype == torch.float64:
-            m = m.double()
-        m.load_state_dict({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in ref.state_dict().items()})
-        m.train()
-        calls, flips = [0], []
-
-        def hook(z):
-            k = calls[0]
-            calls[0] += 1
-            if k == 0:
-                return torch.relu(z)
-            mk = masks[k - 1]
-            assert mk.shape == z.shape, (k, mk.shape, z.shape)
-            diff = (z > 0) != mk
-            nf = int(diff.sum())
-            zd = z.detach()
-            flips.append((k, nf, float(zd[diff].abs().max() / zd.std()) if nf else 0.0))
-            return z * mk.to(z.dtype)
-
-        OME.RELU_HOOK = hook
-        try:
-            o = m(m.process_input({"coordinates": coords, "features": feats.to(dtype)}))
-            F.cross_entropy(o, labels).backward()
-        finally:
-            OME.RELU_HOOK = None
-        assert calls[0] == n_relu, (calls[0], n_relu)
-        return o.detach(), dict(m.named_parameters()), flips
-
-    out64, rp64, flips64 = oracle_grads(torch.float64)
-    _, rp32, _ = oracle_grads(torch.float32)
+    out64, _, _, _, _ = _assert_gradients_match_float64(f"{name} B={batch}", name, {k: hp[k].grad for k in hp}, ref.state_dict(), masks,
+                                                        coords, feats, labels, stem_masks=_stem_masks_of_hip_run(out, hip))
     assert float((out.detach().cpu().double() - out64).abs().max()) < 1e-3
-    nflip = sum(f[1] for f in flips64)
-    zmax = max(f[2] for f in flips64)
-    print(f"[{name} B={batch}] ReLU branches of the HIP run that differ from the float64 run's own: {nflip} elements in "
-          f"{sum(1 for f in flips64 if f[1])} of {n_relu - 1} layers, largest |z|/rms(z) there {zmax:.2e}")
-    assert zmax <= 1e-4, flips64
-    worst, bad, table = (None, 0.0, 0.0), [], []
-    for k in hp:
-        g64 = rp64[k].grad
-        e_hip, e_ref = _trimmed_rel_err(hp[k].grad.cpu().double(), g64), _trimmed_rel_err(rp32[k].grad.double(), g64)
-        if e_hip > worst[1]:
-            worst = (k, e_hip, e_ref)
-        bound = max(1e-3 if (k.startswith("conv1") or k.startswith("bn1")) else 2e-4, 8.0 * e_ref)
-        table.append(f"{k:34s} hip {e_hip:.2e}  oracle-fp32 {e_ref:.2e}  bound {bound:.2e}")
-        if not e_hip <= bound:
-            bad.append(k)
-    if bad or os.environ.get("MINK_TEST_VERBOSE"):
-        print("per-tensor gradient error vs float64 (HIP's ReLU branches imposed):\n  " + "\n  ".join(table))
-    assert not bad, bad
-    flat_g = torch.cat([hp[k].grad.cpu().double().flatten() for k in hp])
-    flat_o = torch.cat([rp64[k].grad.flatten() for k in hp])
-    cos = float(torch.dot(flat_g, flat_o) / (flat_g.norm() * flat_o.norm()))
-    print(f"[{name} B={batch}] worst per-tensor gradient error vs float64: {worst[0]} {worst[1]:.2e} (oracle fp32: {worst[2]:.2e}); "
-          f"cosine over all parameters {cos:.8f}")
-    assert cos > 0.9999, cos
     # the gradients sit in the reducer's flat buffer (the bench's layout): every .grad is a view of it
     lo, hi = reducer.flat.data_ptr(), reducer.flat.data_ptr() + 4 * reducer.flat.numel()
     assert all(lo <= p.grad.data_ptr() < hi for p in hip.parameters())
@@ -348,9 +397,11 @@ def test_fixed_split_top1_matches_oracle(oracle_maps):
     implementation -- not even the reference against itself -- can reproduce a 300-step trajectory, and the trained top-1
     of two runs differs by a few validation scenes.  Hence three assertions:
       1. every training step is the reference's step: at steps 0 / 100 / 200 / 299 of the HIP run, the oracle evaluated
-         at the SAME weights and batch gives the same loss (1e-4) and the same gradient (relative L2 1e-3, or -- where
-         ReLU inputs at zero make the fp32 gradient itself ambiguous -- no further from the float64 gradient than twice
-         the oracle's own fp32 distance; at one probe of the four a ReLU flip on our side alone is accepted);
+         at the SAME weights and batch gives the same loss (1e-4), and a float64 run of the oracle with the HIP step's
+         ReLU branch decisions imposed gives the same gradient, tensor by tensor (2e-4, stem included), at ALL FOUR probes;
+         every branch that differs from the float64 run's own is named and has |z| <= 1e-4 sd (zero to fp32 rounding).
+         (Round 4 had loosened this to "1e-2 everywhere, 3 of 4 close" after a red run at step 200; that run's 2.3e-3 is
+         what ONE flipped element upstream of ~100 k voxels does to an un-imposed comparison.)
       2. top-1 of a given network is the reference's top-1: the HIP-trained weights evaluated on the whole validation
          split by the HIP path and by the oracle agree within 0.1 points (in fact scene by scene) -- the reference's
          "+-0.1 %" in the only form that is well posed;
@@ -364,40 +415,31 @@ def test_fixed_split_top1_matches_oracle(oracle_maps):
     probes = {}
 
     def probe(step, model, batch, loss):
+        # the oracle (fp32) at the same weights and batch: the loss
         ref = get_model("ResNet14", 28, 51, ME=OME)
         ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
         ref.train()
         cb = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
-        oloss = F.cross_entropy(ref(ref.process_input(cb)), cb["labels"].long())
-        oloss.backward()
-        g = torch.cat([p.grad.detach().cpu().double().flatten() for p in model.parameters()])
-        og = torch.cat([p.grad.double().flatten() for p in ref.parameters()])
-        # yardstick: the same step in float64.  A ReLU whose input is 0 up to rounding takes either branch with no effect
-        # on the loss but a finite effect on the gradient, so two fp32 evaluations (the oracle's and ours, which differ in
-        # summation order only) each sit at such a distance from the float64 gradient -- largest on fresh weights (step 0)
-        ref64 = get_model("ResNet14", 28, 51, ME=OME).double()
-        ref64.load_state_dict({k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()})
-        ref64.train()
-        cb64 = dict(cb, features=cb["features"].double())
-        F.cross_entropy(ref64(ref64.process_input(cb64)), cb["labels"].long()).backward()
-        g64 = torch.cat([p.grad.flatten() for p in ref64.parameters()])
-        probes[step] = (abs(float(loss) - float(oloss)), float((g - og).norm() / og.norm()),
-                        float((g - g64).norm() / g64.norm()), float((og - g64).norm() / g64.norm()))
+        with torch.no_grad():
+            oloss = F.cross_entropy(ref(ref.process_input(cb)), cb["labels"].long())
+        # the gradient: against float64 with THIS step's ReLU branches of the HIP run imposed (the trunk's kept
+        # activations are still alive behind loss.grad_fn)
+        node = trunk_node(loss)
+        assert node is not None, "the probe step did not take the native trunk"
+        masks = _relu_masks_of_hip_run(loss)
+        _, loss64, nflip, worst, tot = _assert_gradients_match_float64(
+            f"probe step {step}", "ResNet14", {k: p.grad for k, p in model.named_parameters()}, model.state_dict(), masks,
+            cb["coordinates"], cb["features"], cb["labels"].long(), stem_masks=_stem_masks_of_hip_run(loss, model))
+        probes[step] = (abs(float(loss) - float(oloss)), abs(float(loss) - loss64), nflip, worst, tot)
 
     hip, lh = _fit(None, dev, probe_steps=(0, 100, 200, SPLIT["steps"] - 1), probe=probe)
-    print("per-step parity along the HIP trajectory (|loss diff|, gradient: HIP vs oracle, HIP vs float64, oracle vs float64):", probes)
+    print("per-step parity along the HIP trajectory (|loss - oracle fp32|, |loss - float64 under HIP's branches|, flipped ReLU elements, "
+          "worst tensor, all-parameter relative L2):", probes)
     assert len(probes) == 4
-    # A ReLU whose input is zero to rounding takes either branch; which of the two fp32 evaluations (ours, the oracle's) lands
-    # on the other side of the float64 run at a given step is a coin toss per such element (step 0 of this very run: the
-    # ORACLE sits 1.2e-3 from float64 and we sit 9e-7; at step 200 it was our turn in round 4, after a summation order
-    # changed).  So: the loss agrees at every probe; every gradient is within a flip's reach of float64 (1e-2; a wrong kernel
-    # is O(1)); and at three of the four probes it is as close to float64 as the reference is (or within 1e-3 of the oracle).
-    close = 0
-    for step, (dl, dg, e_hip, e_ref) in probes.items():
-        assert dl < 1e-4, (step, dl)
-        assert e_hip < 1e-2 and e_ref < 1e-2, (step, e_hip, e_ref)
-        close += dg < 1e-3 or e_hip <= 2.0 * e_ref
-    assert close >= 3, probes
+    # Every probe, no exception: the loss is the oracle's (1e-4), and the gradient is the float64 gradient under the HIP run's
+    # own (legitimate, named) branch decisions to 2e-4 per tensor (stem 1e-3) -- asserted inside the probe.
+    for step, (dl, dl64, _, _, _) in probes.items():
+        assert dl < 1e-4 and dl64 < 1e-4, (step, dl, dl64)
     # 2. evaluation parity of the trained network
     logits_h, labels = _val_logits(hip, dev)
     ref = get_model("ResNet14", 28, 51, ME=OME)
