@@ -809,7 +809,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 constexpr int CLDC = BN + 4;         // row stride of the C tile (floats)
 constexpr int CKP = 9;               // offsets per workgroup the rulebook has room for
 constexpr int CD = 3;                // ring of global-load register sets (an item is requested CD - 1 items ahead; 4 sets spill at 128 VGPRs)
-constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * LDA + CKP * CM + 32) * 4 + CKP * CM + 4 * CM; }
+// Layout of the gathered-row tile.  The operand read is lane (n = lane & 15, kq = lane >> 4) -> the 16-byte piece kq (+ 4
+// for the second half) of row n; ds_read_b128 is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32:
+// MI355X_MICROARCH.md, LDS), so one group holds rows {0-3, 12-15} at piece kq and rows {4-11} at piece kq + 1.  With the
+// padded stride of the dense kernels (36 floats) rows 13 and 4 of such a group start on the same bank: every operand read
+// was a 2-way conflict (8 LDS cycles for 4) -- and the LDS, not the vector memory, is what the non-matrix part of an item
+// waits for (16 waves x ~130 LDS cycles per item against 3,072 matrix cycles per SIMD).  Here rows are NOT padded (32
+// floats) and piece p of row n sits at piece p ^ ((n >> 1) & 7): two rows fill the 64 banks, the XOR spreads the eight
+// rows of equal parity in a group over the eight pieces; the staging stores (8 lanes = the 8 pieces of one row) stay
+// conflict-free.  MINK_CSWZ=0: the padded layout with stride MINK_CLDA (A/B builds).
+#ifndef MINK_CSWZ
+#define MINK_CSWZ 1
+#endif
+#ifndef MINK_CLDA
+#define MINK_CLDA 36
+#endif
+// MINK_CPF: the gather stage keeps the byte offsets of its thread's rows in registers for all channel chunks of an offset
+// (one LDS read per offset instead of one per item, requested a step ahead) and the gathers are global loads with a scalar
+// base (x + chunk) and that 32-bit lane offset: two instructions per item where there were two LDS round trips and ten
+// 64-bit address instructions at the head of every step.
+// MINK_CCIN: the accumulators of an offset START as the C rows they belong to (read behind the previous offset's write,
+// under the barrier wait) and are written back when the offset is complete: no read-add-write chain at the end of an
+// offset, no v_pk_add / zeroing moves beside the MFMAs, one LDS read for the four row indices of a lane.
+#ifndef MINK_CPF
+#define MINK_CPF 1
+#endif
+#ifndef MINK_CCIN
+#define MINK_CCIN 1
+#endif
+constexpr bool CSWZ = MINK_CSWZ, CPF = MINK_CPF, CCIN = MINK_CCIN;
+constexpr int CLDA = CSWZ ? BK : MINK_CLDA;
+constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * CLDA + CKP * CM + 32) * 4 + CKP * CM + 4 * CM; }
 
 // CM: rows per tile.  64: 39 KB of LDS, four workgroups (16 waves) per CU -- the latency of an item's chain (barrier,
 // LDS stores, operand reads, scatter) is hidden by the other workgroups; 128: half the weight traffic.
@@ -831,13 +861,14 @@ constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * LDA + CK
 template <bool W_T, int CM, bool PERM = false, bool ABL = false, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_gemm_kernel(GemmParams p) {
   const int abl = ABL ? p.stagger : 0;
+  constexpr bool CCIN = mink::CCIN && (W_T || !PERM);  // (the forward-layout class-permuted form -- tests only -- has no registers to spare)
   constexpr int T = 64 * NWV, SPW = 4 / NWV;  // threads, column strips per wave
   constexpr int NBLK = CM / 16, NH = CM / 64, NA = CM / (T / 8);
   constexpr int NU = ((PERM ? 27 : CKP) + NWV - 1) / NWV;  // offsets of the slice a wave looks at (cs, cs + NWV, ...)
   extern __shared__ __attribute__((aligned(16))) unsigned char c_smem[];
   float *sC = reinterpret_cast<float *>(c_smem);             // [CM + 1][CLDC]; row CM takes the padding lanes
-  float *sA = sC + (CM + 1) * CLDC;                          // [2][CM][LDA] compacted gathered rows
-  int *s_src = reinterpret_cast<int *>(sA + 2 * CM * LDA);   // [CKP][CM] input row of the p-th compacted row (padding: row 0)
+  float *sA = sC + (CM + 1) * CLDC;                          // [2][CM][CLDA] compacted gathered rows
+  int *s_src = reinterpret_cast<int *>(sA + 2 * CM * CLDA);   // [CKP][CM] input row of the p-th compacted row (padding: row 0)
   int *s_cnt = s_src + CKP * CM;                             // [32] compacted rows per offset of the slice
   unsigned char *s_lrow = reinterpret_cast<unsigned char *>(s_cnt + 32);  // [CKP][CM] tile row of the p-th compacted row
   int *s_orow = reinterpret_cast<int *>(s_lrow + CKP * CM);  // PERM: [CM] output row of a tile row (-1: padding)
@@ -896,6 +927,8 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
     }
     __syncthreads();
   }
+  // s_lrow is laid out [slot][n][block]: the (up to four) tile rows of lane n's compacted rows are one 4-byte read
+  auto lri = [](int pos) { return (pos & 15) * (CM / 16) + (pos >> 4); };
   unsigned amask = 0u;  // PERM: live offsets of the tile
   if (PERM) {
     for (int j = 0; j < nk; ++j)
@@ -924,6 +957,9 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
   // ---- staging of the gathered rows: rows a_r + (T / 8) i, float4 column a_cc
   const int a_cc = tid & 7, a_r = tid >> 3;
   constexpr int ARP = T / 8;  // rows per staging pass
+  static_assert(!CSWZ || (ARP % 16 == 0 && BK == 32), "the XOR term must not depend on the staging pass");
+  const int a_sw = 4 * (CSWZ ? (a_cc ^ ((a_r >> 1) & 7)) : a_cc);                     // staging store: float offset inside the row
+  const int r_sw0 = 4 * (CSWZ ? (kq ^ ((n >> 1) & 7)) : kq), r_sw1 = 4 * (CSWZ ? ((kq + 4) ^ ((n >> 1) & 7)) : kq + 4);  // operand read, halves 0 / 1
   const float *xcol = p.x + 4 * a_cc;
   // The ring's global loads are issued through inline asm and waited for with hand-counted s_waitcnt: every step issues the
   // same NA + NW loads in the same order, so "the rows of item it + 1 have arrived" is vmcnt(NA + 2 NW) and "the weights of
@@ -961,14 +997,14 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
           const unsigned long long b = __ballot(v >= 0);
           if (v >= 0) {
             const int pos = cnt + wave_rank(b);
-            s_src[slot * CM + pos] = v, s_lrow[slot * CM + pos] = (unsigned char)(lane + 64 * hh);
+            s_src[slot * CM + pos] = v, s_lrow[slot * CM + lri(pos)] = (unsigned char)(lane + 64 * hh);
           }
           cnt += __popcll(b);
         }
         // behind the compacted rows: input row 0 (read, multiplied into columns nobody keeps) and the spare C row
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh)
-          if (lane + 64 * hh >= cnt) s_src[slot * CM + lane + 64 * hh] = 0, s_lrow[slot * CM + lane + 64 * hh] = (unsigned char)CM;
+          if (lane + 64 * hh >= cnt) s_src[slot * CM + lane + 64 * hh] = 0, s_lrow[slot * CM + lri(lane + 64 * hh)] = (unsigned char)CM;
         if (!PERM && lane == 0) s_cnt[jj] = cnt;
       }
     }
@@ -1016,7 +1052,20 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
     // the two halves of an item's request: the gathered rows (gload_a, at the start of a step) and the weight fragment
     // (gload_w, behind the step's MFMAs, which read the previous fragment in place -- requested early, the registers would
     // have to be copied out first: eight v_mov beside 24 MFMAs); gload_w steps the iterator
+    unsigned sv[NA];  // CPF: byte offset (row and 16-byte column) of this thread's gathered rows of the gather stage's offset
+    auto load_src = [&]() __attribute__((always_inline)) {
+      const int j = nib(act_lo, act_hi, min(g_ka, na - 1));
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        sv[i] = (unsigned)((abl & 16) ? 0 : s_src[j * CM + a_r + ARP * i]) * (4u * (unsigned)p.ldx) + 16u * (unsigned)a_cc;  // (bit 16, timing only: every gather reads row 0)
+    };
     auto gload_a = [&](int slot) __attribute__((always_inline)) {
+      if constexpr (CPF) {
+        const unsigned long long xb = (unsigned long long)p.x + 4ull * (unsigned)((cbeg + g_cc) * BK);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ga[slot][i]) : "v"(sv[i]), "s"(xb));
+        return;
+      }
       const int ga_ = min(g_ka, na - 1);
       const int j = nib(act_lo, act_hi, ga_);
       const int c0 = (cbeg + g_cc) * BK;
@@ -1060,12 +1109,15 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(gwt[slot][q][h]) : "v"(vo), "s"(rw));
           }
       }
-      if (g_ka < na && ++g_cc == ncc) g_cc = 0, ++g_ka;
+      if (g_ka < na && ++g_cc == ncc) {
+        g_cc = 0, ++g_ka;
+        if constexpr (CPF) load_src();  // (used by the NEXT step's gload_a: the read has the barrier wait to arrive)
+      }
     };
     auto sts = [&](int slot, int buf) __attribute__((always_inline)) {
-      float *a = sA + buf * CM * LDA;
+      float *a = sA + buf * CM * CLDA + a_sw;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&a[(a_r + ARP * i) * LDA + 4 * a_cc]) = ga[slot][i];
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(&a[(a_r + ARP * i) * CLDA]) = ga[slot][i];
     };
 
     // The wait itself names no register; the empty asm statements behind it are the definition points of the ring's registers
@@ -1109,12 +1161,45 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
     // on a register the ring re-uses would make it insert s_waitcnt vmcnt(0) at the loop header -- a full drain every pass
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     if (n_items > 0) {  // uniform
+      if constexpr (CPF) load_src();
       gload_a(0), gload_w(0), gload_a(1), gload_w(1), gload_a(2), gload_w(2);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NA + 3 * NW));
       tie_rows(0);
       sts(0, 0);
     }
     MINK_LDS_BARRIER();
+    // CCIN: float index (row * CLDC) of the tile row behind each block of the offset being multiplied, for this lane's n
+    int crow[NBLK];
+    auto crows = [&](int j) __attribute__((always_inline)) {
+      static_assert(!CCIN || CM / 16 == 4, "four row indices per lane in one word");
+      const unsigned pk = *reinterpret_cast<const unsigned *>(s_lrow + j * CM + n * (CM / 16));
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) crow[b] = (int)((pk >> (8 * b)) & 255u) * CLDC;
+    };
+    auto cget = [&](auto lo_c, auto hi_c, int nbx) __attribute__((always_inline)) {
+      constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+#pragma unroll
+      for (int q = 0; q < SPW; ++q)
+#pragma unroll
+        for (int b = lo; b < hi; ++b)
+          if (b < nbx) acc[q][b] = *reinterpret_cast<const f32x4 *>(myC + 16 * q + crow[b]);
+    };
+    auto cput = [&](auto lo_c, auto hi_c, int nbx) __attribute__((always_inline)) {
+      constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+#pragma unroll
+      for (int q = 0; q < SPW; ++q)
+#pragma unroll
+        for (int b = lo; b < hi; ++b)
+          if (b < nbx) *reinterpret_cast<f32x4 *>(myC + 16 * q + crow[b]) = acc[q][b];
+    };
+    if constexpr (CCIN) {
+      if (n_items > 0) {  // uniform: the first offset of the round
+        const int nb0 = nib(nbs_lo, nbs_hi, 0);
+        crows(nib(act_lo, act_hi, 0));
+        cget(S0{}, S2{}, nb0);
+        if (nb0 > 2) cget(S2{}, std::integral_constant<int, 4>{}, nb0);
+      }
+    }
     int ka = 0, cc = 0;
     auto step = [&](int it, auto slot_c, auto nslot_c) __attribute__((always_inline)) {
       constexpr int slot = decltype(slot_c)::value;
@@ -1122,7 +1207,7 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
       constexpr int nslot = decltype(nslot_c)::value;
       wait_rows(nslot);
       sts(nslot, (it + 1) & 1);  // item it + 1 (after the last item: a re-read copy nobody multiplies)
-      const float *a = sA + (it & 1) * CM * LDA + n * LDA + 4 * kq;
+      const float *a = sA + (it & 1) * CM * CLDA + n * CLDA;
       // item it + CD takes the registers of item it NOW, not after the MFMAs: the compiler's s_waitcnt before the next
       // step's LDS stores is vmcnt(0..9) where the ring would allow 18 (it merges the loop-carried load scores
       // conservatively), so a load issued at the end of a step was waited for a few hundred cycles later; issued here
@@ -1146,7 +1231,7 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 6>{}), u1.z, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 7>{}), u1.w, c, 0, 0, 0);
       };
-      auto xr = [&](int blk, int half) __attribute__((always_inline)) { return *reinterpret_cast<const float4 *>(a + blk * 16 * LDA + 16 * half); };
+      auto xr = [&](int blk, int half) __attribute__((always_inline)) { return *reinterpret_cast<const float4 *>(a + blk * 16 * CLDA + (half ? r_sw1 : r_sw0)); };
       // The operands of every block are read up front (rows past the compacted count hold stale data that is read but
       // never multiplied), then one accumulation chain per block that exists.  Each accumulator is written in ONE
       // place per item: the paired form (two blocks' MFMAs alternating, a single-block tail) made the compiler keep
@@ -1158,18 +1243,29 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
       for (int b = 0; b < NBLK; ++b) u[b][0] = xr((abl & 128) ? 0 : b, 0), u[b][1] = xr((abl & 128) ? 0 : b, 1);  // (bit 7, timing only: one block's operands)
 #pragma unroll
       for (int b = 0; b < NBLK; ++b)
-        if (b < nb && !(abl & 32)) {  // uniform (bit 5, timing only: no matrix work)
+        if ((b == 0 || b < nb) && !(abl & 32)) {  // uniform; an item has at least one block (bit 5, timing only: no matrix work)
           mfma8(std::integral_constant<int, 0>{}, acc[0][b], u[b][0], u[b][1]);
           if constexpr (SPW > 1) mfma8(std::integral_constant<int, 1>{}, acc[SPW - 1][b], u[b][0], u[b][1]);
         }
       if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
         cc = 0, ++ka;
         if (!(abl & 64)) {  // (bit 6, timing only: no scatter)
+        if constexpr (CCIN) {
+          // (each accumulator is named in ONE place per role: see the note at `scatter` below)
+          cput(S0{}, S2{}, nb);
+          if (nb > 2) cput(S2{}, std::integral_constant<int, 4>{}, nb);
+          if (ka < na) {  // uniform: the next offset's accumulators start as the rows they belong to
+            const int j2 = nib(act_lo, act_hi, ka), nb2 = nib(nbs_lo, nbs_hi, ka);
+            crows(j2);
+            cget(S0{}, S2{}, nb2);
+            if (nb2 > 2) cget(S2{}, std::integral_constant<int, 4>{}, nb2);
+          }
+        } else {
         auto scatter = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
           constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
           int lr[hi - lo];
 #pragma unroll
-          for (int b = lo; b < hi; ++b) lr[b - lo] = b < nb ? (int)s_lrow[j * CM + b * 16 + n] : CM;
+          for (int b = lo; b < hi; ++b) lr[b - lo] = b < nb ? (int)s_lrow[j * CM + n * (CM / 16) + b] : CM;
 #pragma unroll
           for (int q = 0; q < SPW; ++q) {
             float4 c[hi - lo];
@@ -1191,6 +1287,7 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
         if constexpr (NBLK > 4) {
           if (nb > 4) scatter(std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
           if (nb > 6) scatter(std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+        }
         }
         }
       }
@@ -2402,7 +2499,8 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
   const bool stats_split = want_stats && zs > 1 && (cout & 3) == 0 && cout <= 1024 && (ldy & 3) == 0 &&
                            (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
   if (compact_perm_shape(n_virtual, K, cin, cout, row_perm != nullptr) && row_perm && vec && !p.accumulate && !stats_out &&
-      (ldy & 3) == 0 && 4ll * K * cin * cout < (1ll << 31) && (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0) {
+      (ldy & 3) == 0 && 4ll * K * cin * cout < (1ll << 31) && 4ll * n_in * ldx < (1ll << 32) &&  // (32-bit gather offsets)
+      (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0) {
     // class-permuted rows, every live offset of a tile, split over channel chunks (compact_gemm_kernel<.., PERM>)
     constexpr int CMT = 64;
     constexpr int smem = compact_smem(CMT);
@@ -2438,7 +2536,7 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
   unsigned tiles_x = grid.x;  // row tiles that wrote statistics partials
   const bool compact = g_compact && g_math == 0 && vec && !row_perm && !p.accumulate && K >= 8 && p.kper <= CKP && cin >= 64 &&
                        cin % BK == 0 && cout % BN == 0 && (ldy & 3) == 0 && 4ll * K * cin * cout < (1ll << 31) &&
-                       (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
+                       4ll * n_in * ldx < (1ll << 32) && (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
   if (compact) {  // row-compacted offsets, C tile in LDS (compact_gemm_kernel)
     constexpr int CMT = 64;
     constexpr int smem = compact_smem(CMT);

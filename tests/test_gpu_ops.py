@@ -558,6 +558,26 @@ def test_stem_weight_gradient_on_bf16_matrix_cores(oracle_maps):
     assert 1e-6 < rel < 1e-2, rel
 
 
+def _chain_tolerance(xd, w, nd, ref, scale, flip=False):
+    """Bound for max |y - float64| / max |y| of the row-compacted kernels.  Since round 5 an output element is ONE fp32
+    accumulation chain over all its ~K x cin products (an offset's accumulators START as the C rows they belong to; until
+    round 4 every offset was summed from zero and then added to C: K short chains) -- the order of a plain fp32 GEMM over
+    the flattened (offset, channel) axis.  The yardstick is therefore measured, not modelled: the same terms summed one
+    fused step at a time in fp32, offsets and channels ascending (torch on the GPU: IEEE fp32), against the same float64
+    reference; the kernel may be at most twice as far away (its MFMAs add four products per step in another association),
+    and never needs more than the 2e-6 that held before for the short chains."""
+    K, cin, cout = w.shape
+    s = torch.zeros(nd.shape[0], cout, device=xd.device)
+    for k in range(K):
+        sel = nd[:, k] >= 0
+        xs = torch.where(sel[:, None], xd[nd[:, k].clamp_min(0).long()], torch.zeros((), device=xd.device))
+        wk = w[K - 1 - k if flip else k]
+        for c in range(cin):
+            s.addcmul_(xs[:, c : c + 1], wk[c][None, :])
+    err_seq = float((s.cpu().double() - ref).abs().max()) / scale
+    return max(2e-6, 2.0 * err_seq)
+
+
 @pytest.mark.parametrize("n_out,K,cin,cout", [(1, 27, 64, 64), (63, 27, 64, 128), (65, 27, 96, 64), (1000, 27, 128, 128),
                                               (4097, 27, 64, 64), (300, 8, 64, 64), (129, 9, 256, 64), (128, 27, 512, 512), (530, 27, 256, 256)])
 @pytest.mark.parametrize("transposed", [False, True])
@@ -590,6 +610,7 @@ def test_row_compacted_kernel_against_float64(n_out, K, cin, cout, transposed):
         ref[sel] += x[nbr[sel, k].long()].double() @ w[kw].double()
     xd, wd, nd, bd = x.to(dev), wk.to(dev), nbr.to(dev), bias.to(dev)
     scale = float(ref.abs().max()) + 1e-30
+    tol = _chain_tolerance(xd, w.to(dev), nd, ref, scale, flip=transposed)
     L = lib()
     assert L.mink_conv_plan(n_out, K, cin, cout, 0) * 9 >= K, "the planner must hand this shape to the compacted kernel"
     splits = sorted({-(-K // kper) for kper in range(1, 10)})
@@ -604,7 +625,7 @@ def test_row_compacted_kernel_against_float64(n_out, K, cin, cout, transposed):
                 y, part = Fn.gather_gemm(xd, wd, nd, cout, bias=bd if direct else None, stats=True)
             want = ref + (bias.double() if direct else 0.0)
             err = float((y.cpu().double() - want).abs().max()) / scale
-            assert err < 2e-6, (zs, err)
+            assert err < tol, (zs, err, tol)
             if part is not None:
                 s = part.sum(0).cpu()
                 assert torch.allclose(s[0], want.sum(0), rtol=1e-4, atol=1e-3 * scale), zs
@@ -615,7 +636,7 @@ def test_row_compacted_kernel_against_float64(n_out, K, cin, cout, transposed):
             L.mink_conv_set_stagger(1 << 30)
             y3 = Fn.gather_gemm(xd, wd, nd, cout, w_transposed=transposed, flip_k=transposed, bias=bd if direct else None)
             L.mink_conv_set_stagger(0)
-            assert float((y3 - y).abs().max()) / scale < 2e-6, zs
+            assert float((y3 - y).abs().max()) / scale < tol + 2e-6, zs  # (each within its own bound of float64)
     finally:
         Fn._FORCE_KSPLIT = 0
         L.mink_conv_set_stagger(0)
@@ -662,6 +683,7 @@ def test_row_compacted_kernel_over_permuted_rows_against_float64(n_out, K, cin, 
         ref[sel] += x[nbr[sel, k].long()].double() @ w[k].double()
     xd, wd, nd, pd = x.to(dev), wk.to(dev), nbr.to(dev), perm.to(dev)
     scale = float(ref.abs().max()) + 1e-30
+    tol = _chain_tolerance(xd, w.to(dev), nd, ref, scale)
     L = lib()
     ncc = cin // 32
     assert 1 <= L.mink_conv_plan(perm.numel(), K, cin, cout, 1) <= ncc, "the planner must hand this shape to the permuted compacted kernel"
@@ -670,13 +692,13 @@ def test_row_compacted_kernel_over_permuted_rows_against_float64(n_out, K, cin, 
             Fn._FORCE_KSPLIT = zs
             y = Fn.gather_gemm(xd, wd, nd, cout, w_transposed=transposed, row_perm=pd)
             err = float((y.cpu().double() - ref).abs().max()) / scale
-            assert err < 2e-6, (zs, err)
+            assert err < tol, (zs, err, tol)
             assert torch.equal(y, Fn.gather_gemm(xd, wd, nd, cout, w_transposed=transposed, row_perm=pd)), zs
             L.mink_conv_set_stagger(-(1 << 31))  # bit 31: the dense class-permuted kernel
             Fn._FORCE_KSPLIT = 1
             y3 = Fn.gather_gemm(xd, wd, nd, cout, w_transposed=transposed, row_perm=pd)
             L.mink_conv_set_stagger(0)
-            assert float((y3 - y).abs().max()) / scale < 4e-6, zs  # (two fp32 summation orders, each within 2e-6 of float64)
+            assert float((y3 - y).abs().max()) / scale < 2 * tol, zs  # (two fp32 summation orders, each within tol of float64)
     finally:
         Fn._FORCE_KSPLIT = 0
         L.mink_conv_set_stagger(0)
