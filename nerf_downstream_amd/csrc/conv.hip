@@ -1523,15 +1523,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       const float *db = sD + 32 * wn + col;
       const int sbeg = NARROW ? wa * (nsteps >> 1) : 0;
       const int send = NARROW ? sbeg + (nsteps >> 1) : nsteps;
-      if (!(p.ablate & 128))
-      for (int s = sbeg; s < send; s += 4) {  // 4 MFMAs per trip, all operands loaded up front
-        const int4 ro = *reinterpret_cast<const int4 *>(lrow + s);
-        const float a0 = xa[(s + 0) * XLD], a1 = xa[(s + 1) * XLD], a2 = xa[(s + 2) * XLD], a3 = xa[(s + 3) * XLD];
-        const float b0 = db[ro.x], b1 = db[ro.y], b2 = db[ro.z], b3 = db[ro.w];
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc[g], 0, 0, 0);
+      // 4 MFMAs per trip.  Software pipeline over the trips (round 5): the dy-row offsets of trip t + 2 and the eight operands
+      // of trip t + 1 are requested before the MFMAs of trip t -- as one trip at a time (round 4) every trip stood behind two
+      // dependent LDS round trips (row offsets -> dy values) plus a third for its second operand pair: ~300 exposed cycles
+      // per 256 of matrix work at two waves per SIMD (pipe busy 0.33-0.38).  Lists are padded to whole trips; the reads one
+      // and two trips past the end are clamped to the last trip and never used.
+#ifndef MINK_WPIPE
+#define MINK_WPIPE 1
+#endif
+      if (!MINK_WPIPE) {  // (A/B builds: the round-4 loop)
+        if (!(p.ablate & 128))
+          for (int s = sbeg; s < send; s += 4) {
+            const int4 ro = *reinterpret_cast<const int4 *>(lrow + s);
+            const float a0 = xa[(s + 0) * XLD], a1 = xa[(s + 1) * XLD], a2 = xa[(s + 2) * XLD], a3 = xa[(s + 3) * XLD];
+            const float b0 = db[ro.x], b1 = db[ro.y], b2 = db[ro.z], b3 = db[ro.w];
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc[g], 0, 0, 0);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc[g], 0, 0, 0);
+          }
+      } else if (!(p.ablate & 128) && sbeg < send) {  // uniform
+        const int last = send - 4;
+        auto rows_of = [&](int s_) __attribute__((always_inline)) { return *reinterpret_cast<const int4 *>(lrow + min(s_, last)); };
+        struct Ops { float a0, a1, a2, a3, b0, b1, b2, b3; };
+        auto ops_of = [&](int s_, const int4 &ro) __attribute__((always_inline)) {
+          const int t = min(s_, last);
+          return Ops{xa[(t + 0) * XLD], xa[(t + 1) * XLD], xa[(t + 2) * XLD], xa[(t + 3) * XLD], db[ro.x], db[ro.y], db[ro.z], db[ro.w]};
+        };
+        auto mfma4 = [&](const Ops &o) __attribute__((always_inline)) {
+          __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks every read to its use: the round-4 loop again)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a0, o.b0, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1, o.b1, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a2, o.b2, acc[g], 0, 0, 0);
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a3, o.b3, acc[g], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        // two trips per pass, two operand sets in turn: no register rotation beside the MFMAs
+        int4 r1 = rows_of(sbeg);
+        Ops A = ops_of(sbeg, r1);
+        r1 = rows_of(sbeg + 4);
+        for (int s = sbeg; s < send; s += 8) {
+          const int4 r2 = rows_of(s + 8);
+          const Ops B = ops_of(s + 4, r1);
+          mfma4(A);
+          if (s + 4 < send) {  // uniform
+            r1 = rows_of(s + 12);
+            A = ops_of(s + 8, r2);
+            mfma4(B);
+          }
+        }
       }
       if (g + 1 < ng) {
         __syncthreads();  // everyone done reading sX
