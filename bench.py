@@ -37,7 +37,11 @@ elif int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BENCH_FORCE_R
     # The HIP runtime reads it when it is loaded -- before `import torch`.  SEVEN, not eight: with the bucket-launch stream of
     # round 4 a rank has five busy streams, and at eight hardware queues the step falls off a cliff (one-rank RCCL group,
     # ResNet14 B=16: 4 queues 4.27 ms, 5: 4.11, 6: 3.95, 7: 3.81, 8: 5.7-6.0; ResNet34 B=4: 7: 4.3-4.6, 8: 12.6).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "7")
+    # Round 5: the cliff was a FIFTH busy hardware queue (the stream the collectives were issued from); they now go out from inside
+    # the backward call on the weight-gradient stream -- nerf_downstream_amd/hwqueues.py has the measurements and the rule.
+    from nerf_downstream_amd.hwqueues import configure as _configure_hw_queues
+
+    _configure_hw_queues(data_parallel=True)
     # (this pool's host driver only supports dmabuf IPC: without it RCCL fails in hipIpcGetMemHandle; already exported on the
     #  boxes -- kept here for an environment that lost it)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -286,6 +290,16 @@ def main():
     if force_reducer:
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
+    _dummies = []
+    if int(os.environ.get("BENCH_DUMMY_STREAMS", "0")) > 0:
+        # measurement hook (scripts/cliff_profile.sh): N idle streams, each used once BEFORE the process group exists, so that the
+        # hardware queues the HIP runtime hands out in order of first use are taken and RCCL's stream lands N queues further on
+        for _ in range(int(os.environ["BENCH_DUMMY_STREAMS"])):
+            st_ = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st_):
+                torch.zeros(16, device=dev).add_(1.0)
+            _dummies.append(st_)
+        torch.cuda.synchronize()
     if world > 1 or force_reducer:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")

@@ -634,6 +634,12 @@ int mink_bn_small_bwd(const float *dy, int32_t nslab, const float *addend, float
  * `branch`) has been queued and ordered before it -- what a data-parallel caller makes a bucket's all-reduce wait for,
  * instead of for the tail of the streams (the whole backward pass is queued by the time this call returns).
  *
+ * mink_set_block_done_hook (backward, data parallelism): called ON THE HOST, inside mink_net_backward, at the very point
+ * where done_events[i] would be recorded -- block i's kernels are queued and ex->wgrad is ordered after them -- so that the
+ * caller can issue that block's collective from ex->wgrad right there (what is queued on that stream so far IS what the
+ * collective must wait for): no event, no stream of its own for the launches.  (A fifth busy hardware queue is what the
+ * "eight hardware queue cliff" of DESIGN section 6 turned out to be.)  The hook must not call back into mink_net_*.  NULL = off.
+ *
  * mink_set_stage_hook: instrumentation (race tests, timelines): called on the host before the stem (stage -1) and before
  * every block (stage i) of forward (backward = 0) and backward (= 1; there the stem comes last).  NULL = off. */
 typedef struct {
@@ -658,6 +664,8 @@ typedef struct {
 
 typedef void (*MinkStageHook)(int32_t stage, int32_t backward);
 int mink_set_stage_hook(MinkStageHook hook);
+typedef void (*MinkBlockDoneHook)(int32_t block);
+int mink_set_block_done_hook(MinkBlockDoneHook hook);
 int mink_event_create(void **event_out);
 int mink_event_destroy(void *event);
 int mink_stream_wait_event(void *stream, void *event);

@@ -73,6 +73,7 @@ class Net(ctypes.Structure):
 
 
 STAGE_HOOK = ctypes.CFUNCTYPE(None, _i32, _i32)  # MinkStageHook
+BLOCK_DONE_HOOK = ctypes.CFUNCTYPE(None, _i32)  # MinkBlockDoneHook
 
 
 class ClassPartitionDesc(ctypes.Structure):
@@ -190,6 +191,7 @@ SIGNATURES = {
     "mink_bn_small_fwd": (ctypes.c_int, [_p, _i32, _i64, _i32, _p, _f32, _f32, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
     "mink_bn_small_bwd": (ctypes.c_int, [_p, _i32, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
     "mink_set_stage_hook": (ctypes.c_int, [_p]),
+    "mink_set_block_done_hook": (ctypes.c_int, [_p]),
     "mink_event_create": (ctypes.c_int, [_p]),
     "mink_event_destroy": (ctypes.c_int, [_p]),
     "mink_stream_wait_event": (ctypes.c_int, [_p, _p]),

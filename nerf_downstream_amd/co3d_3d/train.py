@@ -27,7 +27,11 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     # one hardware queue for every stream of a rank (compute, prepare, weight-gradient, bucket launches + RCCL's): the HIP
     # default of 4 makes two of them share one and serialise; read when the HIP runtime is loaded, i.e. before `import torch`.
     # Seven: at eight the step falls off a cliff (bench.py: 3.81 ms at 7, 5.7-6.0 at 8 with a one-rank RCCL group)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "7")
+    # (round 5: the cliff is a fifth busy hardware queue -- nerf_downstream_amd/hwqueues.py; the collectives no longer have a stream
+    #  of their own, and an inherited value on the wrong side is refused there)
+    from nerf_downstream_amd.hwqueues import configure as _configure_hw_queues
+
+    _configure_hw_queues(data_parallel=True)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -854,6 +854,11 @@ constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * CLDA + C
 // balanced whatever the class is).  p.kper is then the number of 32-channel chunks per slice.
 // ABL: the timing-only switches of scripts/kbench.py cab (p.stagger bits 2-7) are compiled in -- forward kernel only; the
 // production instantiations carry none of their branches
+// (Round 5, measured and removed: 128-row tiles with EIGHT waves, two per column strip taking every second block of an offset --
+//  half the LDS operand reads and a third of the padding per row, same 16 waves per CU: 4-8 % SLOWER on the stride-1 layers
+//  (l1.conv2 92-97 us against 86-91), 14-40 % slower on the class-permuted data gradients: the two waves a workgroup has on
+//  each SIMD leave the barrier together and want the matrix pipe and the LDS at the same moment, where the four waves of four
+//  different workgroups are out of step by themselves.)
 // NWV: waves per workgroup (4: a wave owns ONE 16-column strip; 2: a wave owns TWO strips -- the per-item instruction stream is
 // then paid once per 48 MFMAs instead of once per 24 and a block's LDS operands feed both strips; bit-identical results, and
 // measured 8-14 % SLOWER on every layer (two waves per SIMD hide each other's latencies worse than four: DESIGN.md Appendix A),
@@ -2344,6 +2349,7 @@ static int g_wgrad_bf16 = 1;  // bf16 math: stem weight gradient on the bf16 MFM
 static int g_wgrad_bf16_off = 0;
 static int g_b16t_off = 0;      // set_stagger bit 11: the bf16-storage stem weight gradient without the LDS transposition (A/B tests)
 static int g_compact = 1;  // fp32 mid layers on compact_gemm_kernel (set_stagger bit 30: the dense kernel, for the tests that compare the two)
+static int g_compact_cin32 = 0;  // set_stagger bit 8 (measurement only, scripts/kbench.py stemc): the class-permuted form also takes cin = 32
 static int g_compact_perm = 1;  // ... and the class-permuted strided data gradients (bit 31)
 static int g_wgrad_xcd = 1;  // streaming wgrad: groups of a row split share an XCD (stream_slot; bit 29: plain order)
 
@@ -2352,6 +2358,7 @@ extern "C" {
 int mink_conv_set_stagger(int units) {
   const int old = g_stagger;
   g_stagger = units & 255;
+  g_compact_cin32 = (units >> 8) & 1;
   g_b16t_off = (units >> 11) & 1;      // bit 11: bf16-storage stem weight gradient with 2-byte gathers (A/B)
   g_flat = !(units & 512);      // bit 9: no flattened-K stem path
   g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
@@ -2468,7 +2475,8 @@ static int compact_plan(int64_t n_rows, int K, int cout) {
 // is over 32-channel chunks; kbench ksweep: the largest that keeps the launch within ~800 workgroups (l2.conv1 three slices 51 us
 // against 57 at two or four, l3.conv1 five 53 against 57 at seven).
 static bool compact_perm_shape(int64_t n_rows, int K, int cin, int cout, int row_classes) {
-  return g_compact && g_compact_perm && g_math == 0 && row_classes && K >= 8 && cin >= 64 && cin % BK == 0 && cout % BN == 0 && n_rows >= 1;
+  return g_compact && g_compact_perm && g_math == 0 && row_classes && K >= 8 && cin >= (g_compact_cin32 ? 32 : 64) && cin % BK == 0 &&
+         cout % BN == 0 && n_rows >= 1;
 }
 static int compact_perm_plan(int64_t n_rows, int cin, int cout) {
   constexpr int cap = 850;

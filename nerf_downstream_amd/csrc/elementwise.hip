@@ -1184,7 +1184,13 @@ static bool small_attrs() {
 }
 static int small_width(int C) { return g_small_ch ? g_small_ch : (C >= 1024 ? 16 : 8); }
 
-int32_t mink_bn_small_rows(void) { return g_bn_small ? kSmallRows : 0; }
+// 0 when the device refuses the kernels' 67,840 bytes of LDS per workgroup (a part or context with 64 KB): the callers'
+// small_layer() test then never picks the one-launch path and the three-launch norm runs instead of failing
+int32_t mink_bn_small_rows(void) {
+  if (!g_bn_small) return 0;
+  static const bool attr_ok = small_attrs();
+  return attr_ok ? kSmallRows : 0;
+}
 
 int mink_bn_set_small(int32_t on) {
   const int old = g_bn_small ? (g_small_ch ? g_small_ch : 1) : 0;

@@ -46,6 +46,7 @@ int order_after(hipStream_t waiter, hipStream_t producer, int slot) {
   return MINK_OK;
 }
 
+MinkBlockDoneHook g_block_done_hook = nullptr;  // data parallelism: the caller issues a block's collective from ex->wgrad (mink_net_backward)
 MinkStageHook g_stage_hook = nullptr;  // test / timeline instrumentation between the stages of mink_net_*
 
 #define TRY(expr)        \
@@ -499,6 +500,11 @@ int bind_block(MinkBasicBlock &b, const BlockShape &sh, const MinkLevelMaps *lev
 
 extern "C" {
 
+int mink_set_block_done_hook(MinkBlockDoneHook hook) {
+  g_block_done_hook = hook;
+  return MINK_OK;
+}
+
 int mink_set_stage_hook(MinkStageHook hook) {
   g_stage_hook = hook;
   return MINK_OK;
@@ -600,12 +606,14 @@ int mink_net_backward(MinkNet *net, const MinkLevelMaps *levels, int32_t n_level
     PendingGrad next;
     TRY(block_backward_impl(&b, ex, &pending, may_defer ? &next : nullptr));
     pending = next;
-    if (done_events && done_events[i]) {
-      // everything this block wrote into parameter-gradient buffers is complete once this event fires: the weight
-      // gradients run on `wgrad`, the batch-norm gradients on `compute` / `branch`
-      TRY(order_after(wst, st, 7));
+    const bool want_event = done_events && done_events[i];
+    if (want_event || g_block_done_hook) {
+      // everything this block wrote into parameter-gradient buffers is complete behind this point of `wgrad`: the weight
+      // gradients run there, the batch-norm gradients on `compute` / `branch`
+      if (wst != st) TRY(order_after(wst, st, 7));
       if ((hipStream_t)ex->branch != st && (hipStream_t)ex->branch != wst) TRY(order_after(wst, (hipStream_t)ex->branch, 4));
-      MINK_HIP(hipEventRecord((hipEvent_t)done_events[i], wst));
+      if (want_event) MINK_HIP(hipEventRecord((hipEvent_t)done_events[i], wst));
+      if (g_block_done_hook) g_block_done_hook(i);
     }
     g = b.g_x;
     goff += sh.gtmp + sh.gx;

@@ -1,7 +1,9 @@
 """The Mink-ResNet trunk (stem + BasicBlocks) as ONE autograd node whose forward and backward are ONE native call each
 (`mink_net_forward` / `mink_net_backward`, include/mink_hip.h) instead of one Python autograd node and one FFI call per
 operator -- or, as until round 3, one call per residual block.  Same kernels in the same order as the module-by-module
-path (which stays, and is what the tests compare this against bit for bit); what changes is the host cost: ~300 launches
+path (which stays, and is what the tests compare this against bit for bit -- with the one-launch batch norm of the few-row
+layers, `mink_bn_set_small`, on BOTH sides or off on both: its sums run in another order than the three-launch norm's, and the
+module path only takes it where functional.py does; the bitwise tests pin the setting); what changes is the host cost: ~300 launches
 per training step at ~20 us of Python each were as slow as the GPU's own 4 ms; one call per block still cost Mink-ResNet34
 at four scenes per GPU (BASELINE config #3's per-GPU shape) 3.6 ms of host per 4.7 ms step.  Here the host's per-step work
 is a handful of per-LEVEL map records, two allocations and two calls, whatever the depth.
@@ -12,15 +14,20 @@ modules/resnet_block.py:53-69 (BasicBlock).
 The descriptors are persistent ctypes objects: what never changes between steps (weight / batch-norm pointers, shapes,
 gradient-sink addresses) is written once; per step only the level records and the stem's few fields are stored."""
 import ctypes
+import os
 
 import torch
 
-from .._lib import STAGE_HOOK, Exec, LevelMaps, Net
+from .._lib import BLOCK_DONE_HOOK, STAGE_HOOK, Exec, LevelMaps, Net
 from .._lib import BasicBlock as _BlockDesc
 from .._lib import check, lib
 from . import functional as Fn
 from .coords import CoordinateMapKey
 
+# Data parallelism: a block's collective is issued from inside mink_net_backward, on the weight-gradient stream, at the point behind
+# which its gradients are complete (mink_set_block_done_hook).  MINK_DP_LAUNCH=stream: the round-4 scheme -- one event per block and
+# a stream of its own for the launches, a FIFTH busy hardware queue (the cliff of DESIGN section 6 at GPU_MAX_HW_QUEUES >= 8).
+_DP_LAUNCH_IN_CALL = os.environ.get("MINK_DP_LAUNCH", "call") != "stream"
 _KEEPALIVE = []  # gradient scratch of the running backward pass: the weight-gradient stream reads it until the final join
 Fn._AFTER_JOIN.append(_KEEPALIVE.clear)
 _ALIGN = 64  # floats: kNetAlign of csrc/trunk.hip (every block's region starts on a 256-byte boundary)
@@ -35,6 +42,25 @@ class _Stage:
 class _Plan:
     __slots__ = ("stages", "params", "norms", "stem", "out_ts", "ptrs", "ex", "sources", "net", "blocks", "levels", "n_levels",
                  "sizes", "grad_key", "events", "need_nbr3")
+
+
+class _Events:
+    """The per-block completion events of a plan (mink_net_backward's done_events); destroyed with the plan -- a model whose plan
+    is rebuilt (stale parameters) or dropped no longer leaks them."""
+
+    def __init__(self, L, n):
+        self.L, self.n = L, n
+        self.arr = (ctypes.c_void_p * n)()
+        for i in range(n):
+            check(L.mink_event_create(ctypes.byref(self.arr, i * ctypes.sizeof(ctypes.c_void_p))))
+
+    def __del__(self):
+        try:
+            for i in range(self.n):
+                if self.arr[i]:
+                    self.L.mink_event_destroy(self.arr[i])
+        except Exception:  # (interpreter shutdown: the library may already be gone)
+            pass
 
 
 def plan_for(model):
@@ -456,21 +482,52 @@ class TrunkFunction(torch.autograd.Function):
             sd.norm.dgamma, sd.norm.dbeta = ptrs[1], ptrs[2]
         g_buf = torch.empty(grad_floats, dtype=torch.float32, device=dev)
         collect = views is not None and getattr(sink, "_collect", False)
-        evp = None
-        if collect:
+        evp, hook_err = None, []
+        in_call = collect and _DP_LAUNCH_IN_CALL and hasattr(sink, "stage_stream")
+        if in_call:
+            # the library calls back after every block, at the point of its weight-gradient stream behind which that block's
+            # gradients are complete: the block is reported, and a bucket it completes is all-reduced, right there
+            many = getattr(sink, "ready_many", None)
+            stages = plan.stages
+
+            def _block_done(si):
+                try:
+                    st = stages[si]
+                    sink.stage_stream = side
+                    if many is not None:
+                        many(params[st.pidx : st.pidx + st.np])
+                    else:
+                        for i in range(st.pidx, st.pidx + st.np):
+                            sink.ready(params[i])
+                except BaseException as exc:  # (an exception must not unwind through the native frame)
+                    hook_err.append(exc)
+                finally:
+                    sink.stage_stream = None
+
+            cb = BLOCK_DONE_HOOK(_block_done)
+            check(L.mink_set_block_done_hook(ctypes.cast(cb, ctypes.c_void_p)))
+        elif collect:
             if plan.events is None:
-                plan.events = (ctypes.c_void_p * len(plan.stages))()
-                for i in range(len(plan.stages)):
-                    check(L.mink_event_create(ctypes.byref(plan.events, i * ctypes.sizeof(ctypes.c_void_p))))
-            evp = plan.events
+                plan.events = _Events(L, len(plan.stages))
+            evp = plan.events.arr
         _arm_hook(L, cur, bwd_skew=tuple({br, side} - {cur}) if Fn._SKEW else ())
-        check(L.mink_net_backward(ctypes.byref(plan.net), lv, plan.n_levels, arena.data_ptr(), act_floats, g_out.data_ptr(),
-                                  g_buf.data_ptr(), grad_floats, exp, evp))
+        try:
+            check(L.mink_net_backward(ctypes.byref(plan.net), lv, plan.n_levels, arena.data_ptr(), act_floats, g_out.data_ptr(),
+                                      g_buf.data_ptr(), grad_floats, exp, evp))
+        finally:
+            if in_call:
+                L.mink_set_block_done_hook(None)
+        if hook_err:
+            raise hook_err[0]
         Fn.log_phase("stem_backward_end", cur)
         if Fn._TIMING_MODE == 1:
             Fn.note_table(nbr0, *[t for ts_ in tables for t in ts_], *bwd_tables)
         _KEEPALIVE.append((g_buf, g_out, flat, gw_pad, bwd_tables))  # (never the gradients handed to autograd: a second reference makes it clone them at once)
-        if collect:
+        if in_call:
+            sink.flush()
+            for i in range(3):
+                sink.ready(params[i])
+        elif collect:
             # every block's gradients are queued: report them in backward order, each with the event behind which they are
             # complete, so that a bucket's all-reduce waits for exactly its own blocks and overlaps the rest of backward
             many = getattr(sink, "ready_many", None)

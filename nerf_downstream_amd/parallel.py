@@ -92,6 +92,7 @@ class BucketedGradAllReduce:
         # all-reduce is then issued from a stream of its own that waits for that event only (`_launch`), not for the
         # tail of the compute streams -- which by then is the end of backward.
         self.stage_event = None
+        self.stage_stream = None  # set while a block-done hook of the native trunk reports a block (see _launch)
         self._bucket_event = [None] * len(self.buckets)
         self._launch_stream = None
         self.launch_log = []  # (bucket, start, end) of every collective issued, in issue order (tests compare ranks)
@@ -176,7 +177,7 @@ class BucketedGradAllReduce:
             if ready[b] == buckets[b][2]:
                 self._bucket_event[b] = self.stage_event
                 done = True
-        if done and not self.defer:
+        if done and (not self.defer or self.stage_stream is not None):
             self._drain()
 
     def gradients(self):
@@ -204,12 +205,19 @@ class BucketedGradAllReduce:
             from .minkowski import functional as Fn
 
             dev = self.flat.device
+            if self.stage_stream is not None:
+                # in-call launch (mink_set_block_done_hook): the library has ordered `stage_stream` (its weight-gradient stream)
+                # behind everything this bucket's blocks queued, and nothing later is queued on it yet: the collective waits for
+                # exactly its own gradients, with no event and no stream of its own
+                with torch.cuda.stream(self.stage_stream):
+                    self._work.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
+                return
             ev = self._bucket_event[b]
             if ev is not None:
                 from ._lib import check, lib
 
                 if self._launch_stream is None:
-                    self._launch_stream = torch.cuda.Stream(device=dev)
+                    self._launch_stream = self._make_launch_stream(dev)
                 check(lib().mink_stream_wait_event(self._launch_stream.cuda_stream, ev))
                 with torch.cuda.stream(self._launch_stream):
                     self._work.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
@@ -226,6 +234,17 @@ class BucketedGradAllReduce:
                 self._work.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
             return
         self._work.append(dist.all_reduce(self.flat[s:e], op=self._op, group=self.group, async_op=True))
+
+    @staticmethod
+    def _make_launch_stream(dev):
+        """The stream the collectives are issued from (it carries event waits and records only).  MINK_DP_LAUNCH_STREAM=side:
+        the weight-gradient stream instead of a stream of its own -- one busy hardware queue fewer (measurement hook for the
+        hardware-queue cliff)."""
+        if os.environ.get("MINK_DP_LAUNCH_STREAM") == "side":
+            from .minkowski import functional as Fn
+
+            return Fn._side_stream(dev)
+        return torch.cuda.Stream(device=dev)
 
     def _on_grad(self, p):
         if not self._collect:
@@ -260,7 +279,7 @@ class BucketedGradAllReduce:
             from ._lib import check, lib
 
             if self._launch_stream is None:
-                self._launch_stream = torch.cuda.Stream(device=self.flat.device)
+                self._launch_stream = self._make_launch_stream(self.flat.device)
             wait, ls = lib().mink_stream_wait_event, self._launch_stream.cuda_stream
             with torch.cuda.stream(self._launch_stream):
                 for b in todo:
@@ -317,7 +336,16 @@ class BucketedGradAllReduce:
         if self._avg and self._work:
             # RCCL runs the collectives of one communicator on ONE stream in issue order: the current stream waiting for the last
             # of them has waited for all (each wait() is ~25 us of host time; gloo completes on the CPU and needs every one)
-            self._work[-1].wait()
+            # -- then the remaining Work objects are waited for too: by then each wait() returns at once (their collectives are
+            # behind the last one on that stream), and a torch build that keeps the tensors of an async collective alive in its
+            # Work until wait() releases them here instead of at garbage collection.  MINK_DP_WAIT_ALL=1: wait in issue order.
+            if os.environ.get("MINK_DP_WAIT_ALL") == "1":
+                for w in self._work:
+                    w.wait()
+            else:
+                self._work[-1].wait()
+                for w in self._work[:-1]:
+                    w.wait()
         else:
             for w in self._work:
                 w.wait()
@@ -362,16 +390,25 @@ class FlatSGD(torch.optim.Optimizer):
     @classmethod
     def like(cls, sgd, reducer):
         """A FlatSGD with the hyper-parameters of an (unused) torch.optim.SGD."""
+        if len(sgd.param_groups) != 1:
+            raise ValueError(f"FlatSGD: one parameter group (one lr / momentum / weight decay for the flat buffer), got {len(sgd.param_groups)}")
         (g,) = sgd.param_groups
         if g.get("dampening", 0) or g.get("nesterov", False) or g.get("maximize", False):
             raise ValueError("FlatSGD: dampening / Nesterov / maximize are not implemented")
         return cls(reducer, lr=g["lr"], momentum=g.get("momentum", 0.0), weight_decay=g.get("weight_decay", 0.0))
 
-    def _check_homes(self, full):
+    def add_param_group(self, param_group):
+        if getattr(self, "param_groups", None):  # (torch's constructor adds the first one through this method)
+            raise ValueError("FlatSGD: one parameter group only -- the step is ONE kernel with one lr / momentum / weight decay over the flat buffer")
+        super().add_param_group(param_group)
+
+    def _check_homes(self, full=True):
+        """Every step, every parameter: its data and its .grad still live where the kernel reads and writes (two pointer compares
+        per parameter, ~20 us for ResNet34's 110 -- until round 4 the middle parameters were looked at every 64th step only)."""
         params = self.param_groups[0]["params"]
-        idx = range(len(params)) if full else (0, len(params) - 1)
-        for i in idx:
-            if params[i].data_ptr() != self._ptrs[i] or params[i].grad is not self.reducer._views[id(params[i])]:
+        views = self.reducer._views
+        for i, p in enumerate(params):
+            if p.data_ptr() != self._ptrs[i] or p.grad is not views[id(p)]:
                 raise RuntimeError("FlatSGD: a parameter (or its .grad) no longer lives in the flat buffers (load_state_dict(assign=True), "
                                    ".to(), a replaced .data or .grad?); rebuild reducer and optimizer")
 
@@ -380,11 +417,13 @@ class FlatSGD(torch.optim.Optimizer):
         from ._lib import check, lib
 
         loss = closure() if closure is not None else None
-        self._check_homes(full=self._steps % 64 == 0)
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatSGD: one parameter group only")
+        self._check_homes()
         self._steps += 1
         g = self.param_groups[0]
-        if g.get("dampening", 0) or g.get("nesterov", False):
-            raise ValueError("FlatSGD: dampening / Nesterov are not implemented")
+        if g.get("dampening", 0) or g.get("nesterov", False) or g.get("maximize", False):
+            raise ValueError("FlatSGD: dampening / Nesterov / maximize are not implemented")
         flat = self.reducer.flat
         check(lib().mink_sgd_step(self.flat_w.data_ptr(), flat.data_ptr(), self.flat_m.data_ptr(), flat.numel(), float(g["lr"]),
                                   float(g["momentum"]), float(g["weight_decay"]), int(self.clear_grads),

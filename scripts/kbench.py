@@ -394,3 +394,32 @@ if which == "cabp":  # the class-permuted data gradient of the stride-2 convolut
         pairs = int((nbr >= 0).sum())
         print(f"l@{2 * ts}.c1 dgrad rows={nbr_t.shape[0]} (perm {perm.numel()}) {cout}->{cin}, {pairs} pairs = {2e-9 * pairs * cin * cout:.2f} GFLOP: full {res[0]:.1f} / {res[6]:.1f} us, "
               f"no MFMA {res[1]:.1f}, + no scatter {res[2]:.1f}; gathers from row 0 {res[3]:.1f}, + one weight block {res[4]:.1f}; NO ITEMS {res[5]:.1f}")
+
+if which == "stemc":  # zero skipping in the stem, MEASURED (round-4 review, item 6): the row-compacted kernel on the stem's own shape --
+    # 32-channel padded rows, every live offset of a 64-row tile in rounds of nine (the class-permuted form with an identity
+    # permutation: un-split, direct epilogue) -- against the dense flattened-K kernel that runs in the step
+    from nerf_downstream_amd._lib import lib
+    nbr, _ = m.kernel_table(k1, k1, 3, 1)
+    xin = x.F.contiguous()
+    w = torch.randn(27, 28, 64, device=dev) * 0.05
+    x32 = torch.nn.functional.pad(xin, (0, 4)).contiguous()
+    w32 = torch.nn.functional.pad(w, (0, 0, 0, 4)).contiguous()
+    perm = torch.arange(nbr.shape[0], device=dev, dtype=torch.int32)
+    pairs = int((nbr >= 0).sum())
+    fl = 2.0 * pairs * 28 * 64
+    t = timeit(lambda: Fn.gather_gemm(xin, w, nbr, 64), reps)
+    y0 = Fn.gather_gemm(xin, w, nbr, 64)
+    print(f"stem fwd dense (flattened K, in the step): {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s useful; table fill {pairs / nbr.numel():.3f}")
+    lib().mink_conv_set_stagger(256)
+    Fn._PLAN_CACHE.clear()
+    Fn._FORCE_KSPLIT = 1
+    try:
+        t = timeit(lambda: Fn.gather_gemm(x32, w32, nbr, 64, row_perm=perm), reps)
+        y1 = Fn.gather_gemm(x32, w32, nbr, 64, row_perm=perm)
+    finally:
+        lib().mink_conv_set_stagger(0)
+        Fn._FORCE_KSPLIT = 0
+        Fn._PLAN_CACHE.clear()
+    print(f"stem fwd row-compacted per offset (32-channel rows, 16-row blocks, C tile in LDS): {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s useful; "
+          f"max |difference| {float((y1 - y0).abs().max()):.2e} of {float(y0.abs().max()):.2e}")
+
