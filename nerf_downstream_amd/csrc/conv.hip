@@ -1051,7 +1051,21 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
     };
     const int n_items = (abl & 4) ? 0 : na * ncc;  // (bit 2, timing only: prologue and epilogue alone)
 
-    int g_ka = 0, g_cc = 0;  // iterator of the global-load stage
+    // iterator of the global-load stage.  Scalar diet (round 5; PMC: 3.2 scalar instructions per MFMA, ~77 per item, in the
+    // in-order stream of a wave that has 24 MFMAs to issue): the byte offsets of the item's weight block and channel chunk are
+    // carried along and stepped by constants; the nibble / byte tables of the round are only unpacked when the offset changes.
+    int g_ka = 0, g_cc = 0;
+    auto wbase_of = [&](int a) {  // byte offset of the weight block of round entry a, first channel chunk of the slice
+      const int j = nib(act_lo, act_hi, a);
+      const int k = kof(a, j);
+      const int kw = p.flip_k ? K - 1 - k : k;
+      if (abl & 8) return 0;  // (bit 3, timing only: one weight block for every item)
+      return W_T ? 4 * ((kw * p.cout + n0) * p.cin + cbeg * BK) : 4 * ((kw * p.cin + cbeg * BK) * p.cout + n0);
+    };
+    const int g_wstep = (abl & 8) ? 0 : (W_T ? 4 * BK : 4 * BK * p.cout);  // one channel chunk further
+    int g_wo = na > 0 ? wbase_of(0) : 0;  // weight block of the stage's item (bytes)
+    unsigned g_xo = 4u * (unsigned)(cbeg * BK);  // channel chunk of the stage's item (bytes into a row)
+    int g_left = n_items - 1;             // steps the iterator may still take: past the end the last item is re-read
     // every call issues the same NA + (W_T ? 2 : 8) loads, whatever the item: the vmcnt distances of the ring are static
     // (a conditional load would make every wait a wait for ALL loads in flight); past the end the last item is re-read
     // the two halves of an item's request: the gathered rows (gload_a, at the start of a step) and the weight fragment
@@ -1059,20 +1073,19 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
     // have to be copied out first: eight v_mov beside 24 MFMAs); gload_w steps the iterator
     unsigned sv[NA];  // CPF: byte offset (row and 16-byte column) of this thread's gathered rows of the gather stage's offset
     auto load_src = [&]() __attribute__((always_inline)) {
-      const int j = nib(act_lo, act_hi, min(g_ka, na - 1));
+      const int j = nib(act_lo, act_hi, g_ka);
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         sv[i] = (unsigned)((abl & 16) ? 0 : s_src[j * CM + a_r + ARP * i]) * (4u * (unsigned)p.ldx) + 16u * (unsigned)a_cc;  // (bit 16, timing only: every gather reads row 0)
     };
     auto gload_a = [&](int slot) __attribute__((always_inline)) {
       if constexpr (CPF) {
-        const unsigned long long xb = (unsigned long long)p.x + 4ull * (unsigned)((cbeg + g_cc) * BK);
+        const unsigned long long xb = (unsigned long long)p.x + g_xo;
 #pragma unroll
         for (int i = 0; i < NA; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ga[slot][i]) : "v"(sv[i]), "s"(xb));
         return;
       }
-      const int ga_ = min(g_ka, na - 1);
-      const int j = nib(act_lo, act_hi, ga_);
+      const int j = nib(act_lo, act_hi, g_ka);
       const int c0 = (cbeg + g_cc) * BK;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
@@ -1081,13 +1094,8 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
       }
     };
     auto gload_w = [&](int slot) __attribute__((always_inline)) {
-      const int ga_ = min(g_ka, na - 1);
-      const int j = nib(act_lo, act_hi, ga_);
-      const int k = kof(ga_, j);
-      const int kw = p.flip_k ? K - 1 - k : k;
-      const int c0 = (cbeg + g_cc) * BK;
+      const int so = g_wo;
       if constexpr (!W_T) {
-        const int so = (abl & 8) ? 0 : 4 * ((kw * p.cin + c0) * p.cout + n0);  // (bit 3, timing only: one weight block for every item)
         if constexpr (PERM) {  // (the compiler does not hold the item's offset in a scalar register there: it goes into the lane offset)
 #pragma unroll
           for (int q = 0; q < SPW; ++q)
@@ -1104,8 +1112,7 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
             for (int e = 0; e < 8; ++e)
               asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(gw[slot][q][e]) : "v"(wv[q][e]), "s"(rw), "s"(sso));
         }
-      } else {
-        const int so = 4 * ((kw * p.cout + n0) * p.cin + c0);  // (added to the lane offset: see above)
+      } else {  // (the offset is added to the lane offset: see above)
 #pragma unroll
         for (int q = 0; q < SPW; ++q)
 #pragma unroll
@@ -1114,9 +1121,13 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(gwt[slot][q][h]) : "v"(vo), "s"(rw));
           }
       }
-      if (g_ka < na && ++g_cc == ncc) {
-        g_cc = 0, ++g_ka;
-        if constexpr (CPF) load_src();  // (used by the NEXT step's gload_a: the read has the barrier wait to arrive)
+      if (g_left > 0) {  // uniform
+        --g_left, g_wo += g_wstep, g_xo += 4u * BK;
+        if (++g_cc == ncc) {
+          g_cc = 0, ++g_ka;
+          g_wo = wbase_of(g_ka), g_xo = 4u * (unsigned)(cbeg * BK);
+          if constexpr (CPF) load_src();  // (used by the NEXT step's gload_a: the read has the barrier wait to arrive)
+        }
       }
     };
     auto sts = [&](int slot, int buf) __attribute__((always_inline)) {
@@ -1206,9 +1217,10 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
       }
     }
     int ka = 0, cc = 0;
+    int c_j = nib(act_lo, act_hi, 0), c_nb = nib(nbs_lo, nbs_hi, 0);  // rulebook slot and block count of the offset being multiplied
     auto step = [&](int it, auto slot_c, auto nslot_c) __attribute__((always_inline)) {
       constexpr int slot = decltype(slot_c)::value;
-      const int j = nib(act_lo, act_hi, ka), nb = nib(nbs_lo, nbs_hi, ka);  // nb >= 1
+      const int j = c_j, nb = c_nb;  // nb >= 1
       constexpr int nslot = decltype(nslot_c)::value;
       wait_rows(nslot);
       sts(nslot, (it + 1) & 1);  // item it + 1 (after the last item: a re-read copy nobody multiplies)
@@ -1254,13 +1266,14 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
         }
       if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
         cc = 0, ++ka;
+        if (ka < na) c_j = nib(act_lo, act_hi, ka), c_nb = nib(nbs_lo, nbs_hi, ka);  // uniform (the next offset's slot and blocks)
         if (!(abl & 64)) {  // (bit 6, timing only: no scatter)
         if constexpr (CCIN) {
           // (each accumulator is named in ONE place per role: see the note at `scatter` below)
           cput(S0{}, S2{}, nb);
           if (nb > 2) cput(S2{}, std::integral_constant<int, 4>{}, nb);
           if (ka < na) {  // uniform: the next offset's accumulators start as the rows they belong to
-            const int j2 = nib(act_lo, act_hi, ka), nb2 = nib(nbs_lo, nbs_hi, ka);
+            const int j2 = c_j, nb2 = c_nb;
             crows(j2);
             cget(S0{}, S2{}, nb2);
             if (nb2 > 2) cget(S2{}, std::integral_constant<int, 4>{}, nb2);
