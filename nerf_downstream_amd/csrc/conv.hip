@@ -893,6 +893,28 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
     if (slice >= Y * Z) return;  // (the launch is padded to whole runs)
     bx = (L % (8u * X)) >> 3, by = slice % Y, bz = slice / Y, gz = Z;
   }
+#ifndef MINK_CPRIO
+#define MINK_CPRIO 0
+#endif
+  // MINK_CPRIO (A/B builds): a static wave priority that differs between the workgroups sharing a CU.  PMC (round 5): in the
+  // item loop a wave waits ~2,300 cycles per item to issue its 24 MFMAs (768 cycles of pipe) while the pipe is 73 % busy --
+  // the four waves of a SIMD (four workgroups) run their MFMA bursts at the same time and their LDS / scalar phases at the
+  // same time.  With distinct priorities the first workgroup would run its burst unimpeded and the others fill its gaps.
+  // Measured (kbench all, two boxes): 1 or 2 gain 2-4 % on layer 1 and the strided data gradients alone, nothing on layers 2-4,
+  // and nothing in the step (3.58 ms with and without): off.
+  if constexpr (MINK_CPRIO == 1) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned pr = (lin >> 8) & 3u;  // (workgroups 256 apart in launch order tend to share a CU)
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  } else if constexpr (MINK_CPRIO == 2) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, whole register
+    const unsigned pr = hw & 3u;  // wave slot on its SIMD (bits 3:0)
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
   const int64_t o0 = (int64_t)bx * CM;
   const int n0 = by * BN;
   const int K = p.K;
