@@ -210,7 +210,7 @@ def _assert_gradients_match_float64(tag, name, hip_grads, state, masks, coords, 
           fp32 rounding: |z| <= 1e-4 of the tensor's standard deviation -- the flips are legitimate, and each is NAMED in
           the output (layer, element);
       (2) with the HIP run's branches imposed on the float64 run, every parameter gradient matches it to rounding: plain
-          relative L2 <= 2e-4 per tensor, the stem's three included: `stem_masks` = _stem_masks_of_hip_run -- bn1.* against
+          relative L2 <= 2e-5 per tensor (2e-4 until the stem's ReLU was imposed too), the stem's three included: `stem_masks` = _stem_masks_of_hip_run -- bn1.* against
           the float64 run under the decisions of the kernel that computes them, conv1.kernel under those of the
           weight-gradient kernel (a second float64 run, only when the two masks differ somewhere)."""
     sm_bn, sm_w = stem_masks if stem_masks is not None else (None, None)
@@ -231,7 +231,9 @@ def _assert_gradients_match_float64(tag, name, hip_grads, state, masks, coords, 
     worst, bad, table = (None, 0.0), [], []
     for k, g in hip_grads.items():
         e = _rel_err(g.detach().cpu().double(), g64[k])
-        bound = 2e-4 if (stem_masks is not None or not (k.startswith("conv1") or k.startswith("bn1"))) else 1e-3
+        # (measured with every branch imposed, rounds 4-5: <= 4e-6 on every tensor of ResNet14 at 16 scenes, ResNet34 at 4 and
+        #  the four training probes -- 2e-5 leaves 5x for another summation order and still sits 100x under a dropped row)
+        bound = 2e-5 if stem_masks is not None else (2e-4 if not (k.startswith("conv1") or k.startswith("bn1")) else 1e-3)
         table.append(f"{k:34s} hip {e:.2e}  bound {bound:.0e}")
         if e > worst[1]:
             worst = (k, e)
