@@ -1435,12 +1435,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   __shared__ int s_cnt[G * 2];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = blockIdx.x % p.ngroups;
-  const int tile_id = blockIdx.x / p.ngroups;
+  // Workgroup -> (offset group / weight tile bx, row split by).  All workgroups of one row split read the same rows of x and
+  // dy; in plain launch order (x fastest) they are dealt round-robin to the eight XCDs and every L2 fetches those rows for
+  // itself (layer 1: 175 MB of traffic beyond L2 for 24 MB of operands, PMC r04).  When the split count is a multiple of
+  // eight the workgroups of a split are given to consecutive slots of ONE XCD (as stream_slot does for the stem).
+  unsigned wbx = blockIdx.x, wby = blockIdx.y;
+  if (!(p.ablate & 4096) && (gridDim.y & 7u) == 0u) {  // uniform
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7u, slot = lin >> 3;
+    wbx = slot % gridDim.x, wby = (slot / gridDim.x) * 8u + xcd;
+  }
+  const int grp = wbx % p.ngroups;
+  const int tile_id = wbx / p.ngroups;
   const int ci0 = (tile_id / p.ct_tiles) * WT, co0 = (tile_id % p.ct_tiles) * WT;
   const int k0 = grp * G;
   const int ng = min(G, p.K - k0);  // offsets handled by this workgroup (uniform)
-  const int64_t rbeg = (int64_t)blockIdx.y * p.rows_per_split;
+  const int64_t rbeg = (int64_t)wby * p.rows_per_split;
   const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
 
   const int d_c4 = tid & 15, d_rr = tid >> 4;       // dy staging: float4 column, rows d_rr + 16 i
@@ -1623,7 +1632,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   }
 
   // ---- epilogue: (narrow: add the two pair halves through LDS) then store the partial slab
-  float *dst = p.out + (int64_t)blockIdx.y * p.K * p.cin * p.cout;
+  float *dst = p.out + (int64_t)wby * p.K * p.cin * p.cout;
   const int co = co0 + 32 * wn + col;
 #pragma unroll
   for (int g = 0; g < G; ++g) {

@@ -423,3 +423,22 @@ if which == "stemc":  # zero skipping in the stem, MEASURED (round-4 review, ite
     print(f"stem fwd row-compacted per offset (32-channel rows, 16-row blocks, C tile in LDS): {t*1e3:8.1f} us {fl/t/1e9:7.1f} TF/s useful; "
           f"max |difference| {float((y1 - y0).abs().max()):.2e} of {float(y0.abs().max()):.2e}")
 
+
+if which == "wxcdmid":  # tiled weight gradient of layer 1 / 2: the workgroups of a row split on one XCD (default) against plain launch order (bit 29)
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    for ts in (4, 8):
+        c = chans[ts]
+        nbr, _ = m.kernel_table(keys[ts], keys[ts], 3, 1)
+        xin = torch.randn(nbr.shape[0], c, device=dev)
+        gy = torch.randn(nbr.shape[0], c, device=dev)
+        res, outs = [], []
+        for st in (0, 1 << 29, 0, 1 << 29):
+            lib().mink_conv_set_stagger(st)
+            res.append(timeit(lambda: Fn.conv_wgrad(xin, gy, nbr, (27, c, c)), reps) * 1e3)
+            outs.append(Fn.conv_wgrad(xin, gy, nbr, (27, c, c)))
+        lib().mink_conv_set_stagger(0)
+        print(f"l@{ts}.c2 wgrad rows={nbr.shape[0]} {c}->{c}: splits on one XCD {res[0]:.1f} / {res[2]:.1f} us, plain order {res[1]:.1f} / {res[3]:.1f} us; bitwise equal: {bool(torch.equal(outs[0], outs[1]))}")
