@@ -1496,11 +1496,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     for (int i = 0; i < XNI; ++i) *reinterpret_cast<float4 *>(&sX[(x_rr + XRP * i) * XLD + 4 * x_c4]) = rx[i];
   };
 
+  // BUF (round 5): the table entries and the dy tile of the NEXT tile are requested before the MFMAs of this tile's last
+  // offset and wait in registers: the tile prologue no longer starts with a memory round trip (one of its two).
+  constexpr bool PF = BUF && G <= 3;  // (nine accumulators leave no registers for it)
+  int nb_n[G];
+  float4 dy_n[8];
+  auto request_tile = [&](int64_t r0) __attribute__((always_inline)) {
+    const int64_t row = r0 + tid;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const bool ok = tid < WROWS && row < rend && g < ng;
+      const int v = raw_load_i32(bn, (int)(ok ? (unsigned)row * K4 + 4u * (unsigned)(k0 + g) : 0x80000000u), 0, 0);
+      nb_n[g] = ok ? v : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t rw_ = r0 + d_rr + 16 * i;
+      dy_n[i] = __builtin_bit_cast(float4, raw_load_v4(bd, (int)((rw_ < rend ? (unsigned)rw_ * ldy4 : 0x80000000u) + d_coff), 0, 0));
+    }
+  };
+  if constexpr (PF) {
+    if (rbeg < rend) request_tile(rbeg);
+  }
   for (int64_t r0 = rbeg; r0 < rend; r0 += WROWS) {
     __syncthreads();  // previous tile fully consumed
     // ---- this tile's neighbour entries (one row per thread of waves 0/1) and dy tile
     int nb[G], rank[G];
-    if (tid < WROWS) {
+    if constexpr (PF) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) nb[g] = nb_n[g];
+    } else if (tid < WROWS) {
       const int64_t row = r0 + tid;
       if constexpr (BUF) {
 #pragma unroll
@@ -1520,7 +1545,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
       const int64_t row = r0 + r;
       const int co = co0 + 4 * d_c4;
       float4 v;
-      if constexpr (BUF)
+      if constexpr (PF)
+        v = dy_n[i];
+      else if constexpr (BUF)
         v = __builtin_bit_cast(float4, raw_load_v4(bd, (int)((row < rend ? (unsigned)row * ldy4 : 0x80000000u) + d_coff), 0, 0));
       else if (VEC)
         v = ld4_sel(p.dy, row * p.ldy + co, row < rend && co < p.cout);
@@ -1565,6 +1592,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
     for (int g = 0; g < G; ++g) {
       if (g < ng) {  // uniform
       if (g + 1 < ng) gather(g + 1);  // in flight during the MFMAs below
+      else if constexpr (PF) {
+        if (r0 + WROWS < rend) request_tile(r0 + WROWS);  // (uniform) the next tile's table entries and dy rows, likewise
+      }
       const int m = s_cnt[2 * g] + s_cnt[2 * g + 1];
       const int nsteps = ((m + 15) & ~15) >> 1;  // multiple of 8; lane half h takes pairs [h*nsteps, (h+1)*nsteps)
       const int *lrow = s_row + g * LL + h * nsteps;

@@ -7,14 +7,18 @@ per-rank BatchNorm statistics, mean of gradients across ranks once per step.  He
 * all parameter gradients live in ONE flat fp32 buffer (`.grad` tensors are views), laid out
   in REVERSE registration order so the buffer fills front-to-back as backward proceeds
   (layer4 -- 74 % of the bytes -- first);
-* the buffer is cut into buckets of >= 32 MiB (one parameter tensor is never split; Mink-ResNet34's 81 MB are 4 messages of
-  >= 32 MB and the stem's, ResNet14's 11 MB one and the stem's: few, large collectives are what xGMI's point-to-point links
-  want, and every collective costs the host ~50 us of a step that is host-bound under data parallelism -- 15 buckets of >= 8 MiB
-  were 0.77 ms per ResNet34 step); the LAST bucket, which cannot overlap with anything, holds only the stem convolution +
-  its batch norm (0.2 MB);
+* the buffer is cut into buckets of >= 32 MiB (one parameter tensor is never split; Mink-ResNet34's 63.5 M parameters = 254 MB
+  are six messages of 25-54 MiB and the stem's, Mink-ResNet14's 14.4 M = 57.6 MB two and the stem's: few, large collectives
+  are what xGMI's point-to-point links want, and every collective costs the host ~50 us of a step that is nearly host-bound
+  under data parallelism -- 15 buckets of >= 8 MiB were 0.77 ms per ResNet34 step); the LAST bucket, which cannot overlap with
+  anything, holds only the stem convolution + its batch norm (0.2 MB);
 * a post-accumulate-grad hook counts ready parameters per bucket and launches the bucket's
   `all_reduce(async_op=True)` once it is complete -- RCCL runs it on its own HIP stream, overlapped
-  with the remaining backward kernels.  On the GPU (gradient-sink mode) a complete bucket is not
+  with the remaining backward kernels.  The native trunk (one call for the whole backward pass) reports its blocks through
+  a callback of the library at the point of the weight-gradient stream behind which a block's gradients are complete, and
+  the bucket a block completes is all-reduced FROM that stream right there (round 5: no event per block, no stream of its
+  own for the launches -- a fifth busy hardware queue is what made a step 1.5-3x slower at GPU_MAX_HW_QUEUES >= 8,
+  hwqueues.py).  On the GPU (gradient-sink mode) a complete bucket is not
   launched from inside the backward of the small deep layers, where the host is what the GPU waits
   for, but at the next `flush()` point: behind the backward of a wide-and-shallow layer -- a static
   property of the layer, so every rank issues its collectives at the same points;
