@@ -507,18 +507,21 @@ def test_bench_two_ranks_self_launched(tmp_path):
 
 
 @pytest.mark.long
-@pytest.mark.timeout(70)
+@pytest.mark.timeout(100)
 def test_one_rank_rccl_group_costs_little(tmp_path):
-    """The whole data-parallel machinery (RCCL process group of ONE rank, gradient sink, bucket launches behind per-block events,
-    branch on the weight-gradient stream, bench.py's own choice of hardware queues) against the plain single-GPU step, both at the
-    bench's default shape: within 15 %.  Guards the cliff round 4 found late -- 5.7-6.0 ms against 3.7 at eight hardware queues --
-    with a bound a real overhead (measured: +2.6 %) stays far inside."""
+    """The whole data-parallel machinery (RCCL process group of ONE rank, gradient sink, collectives issued from inside the backward
+    call on the weight-gradient stream, branch on that stream too) against the plain single-GPU step, both at the bench's default
+    shape: within 15 % -- at bench.py's own choice of hardware queues AND at sixteen.  Guards the cliff round 4 found (5.7-6.0 ms
+    against 3.7 at eight or more hardware queues) and round 5 explained (a FIFTH busy queue: the stream the collectives were issued
+    from): with four busy queues by construction the queue count must not matter.  Measured overhead: +3.5 %."""
     import json
     import subprocess
 
-    def run(force):
-        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPU_MAX_HW_QUEUES")}
+    def run(force, queues=None):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPU_MAX_HW_QUEUES", "MINK_DP_LAUNCH")}
         env.update(MASTER_PORT=str(_free_port()), MASTER_ADDR="127.0.0.1")
+        if queues:
+            env["GPU_MAX_HW_QUEUES"] = str(queues)
         if force:
             env["BENCH_FORCE_REDUCER"] = "1"
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
@@ -527,10 +530,11 @@ def test_one_rank_rccl_group_costs_little(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
-    plain, dp = run(False), run(True)
+    plain, dp, dp16 = run(False), run(True), run(True, queues=16)
     assert "RCCL" in dp["config"]["collective"] and "none" in plain["config"]["collective"]
-    assert abs(dp["config"]["final_loss"] - plain["config"]["final_loss"]) <= 1e-3 * max(1.0, abs(plain["config"]["final_loss"]))
-    assert dp["ms_per_step"] <= 1.15 * plain["ms_per_step"], (dp["ms_per_step"], plain["ms_per_step"])
+    for d in (dp, dp16):
+        assert abs(d["config"]["final_loss"] - plain["config"]["final_loss"]) <= 1e-3 * max(1.0, abs(plain["config"]["final_loss"]))
+        assert d["ms_per_step"] <= 1.15 * plain["ms_per_step"], (d["ms_per_step"], plain["ms_per_step"])
 
 
 def test_scannet_plenoxel_segmentation_on_gpu(tmp_path):
