@@ -201,8 +201,8 @@ def roofline_from_timings(timings, pair_table):
     n, tot = len(g["ms"]), sum(g["ms"])
     avg_ms = tot / n
     achieved = g["flops"] / (tot * 1e-3) / 1e12
-    # (the mid-layer weight gradients run on the exact-fp32 matrix cores in every mode)
-    peak = MFMA_F32_PEAK_TFLOPS if (g["tags"][0].startswith("wgrad") and g["meta"]["cin"] > 32) else MFMA_PEAK_TFLOPS
+    # (since round 5 the mid-layer weight gradients run on the bf16 matrix cores under --math bf16 too: wgrad16_kernel)
+    peak = MFMA_PEAK_TFLOPS
     return {
         "bound": "mfma",
         "kernel": g["tags"][0],
@@ -527,9 +527,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"fp32": "f32",
-                      "bf16": "bf16 (MFMA operands of forward, data gradient and the stem weight gradient; fp32 accumulate; "
+                      "bf16": "bf16 (MFMA operands of every convolution: forward, data gradient and weight gradient; fp32 accumulate; "
                       + ("bf16 storage of the input features and the stem output, fp32 storage below" if args.storage == "bf16" else "fp32 storage")
-                      + "; mid-layer weight gradients fp32)",
+                      + ")",
                       "bf16x3": "f32 via split-bf16 MFMA (3 products)"}[args.math],
             "data": "synthetic",
             "config": {

@@ -2358,6 +2358,151 @@ static WgradPlan wgrad_plan(int64_t n_out, int K, int cin, int cout) {
   return pl;
 }
 
+// ------------------------------------------------ tiled weight gradient on the bf16 matrix cores (mid layers, --math bf16)
+// BASELINE config #4 ("MFMA bf16 on the rulebook GEMM") for the twelve mid-layer weight gradients, which until round 4 stayed on
+// wgrad_kernel's exact-fp32 MFMAs (0.8 ms of that step's weight-gradient stream).  Same ownership as wgrad_kernel -- workgroup =
+// (G offsets) x (64 x 64 ci / co tile) x (row range); per 128-row tile the dy tile is staged once, per offset the rows that have
+// a neighbour are compacted (wave64 ballot + prefix rank) and only their x rows gathered -- but both tiles live in LDS as
+// bf16, ROW-major as they arrive (an 8-byte store per gathered float4), and the MFMA fragments come out of them through
+// gfx950's transposing LDS read (ds_read_b64_tr_b16: sixteen lanes hand in four rows x sixteen channels and each receives its
+// channel of the four rows): v_mfma_f32_32x32x16_bf16 contracts SIXTEEN pairs per instruction where the fp32 kernel's
+// 32x32x2 contracts two.  The dy rows of an offset's pairs are reached through the pair list (a lane's row address is its
+// own: no compacted copy of the tile).  LDS: 2 x 128 rows x 128 bytes + lists = 37 KB -> four workgroups per CU where the
+// fp32 kernel's 74 KB allow two.  fp32 accumulation, fp32 slabs, deterministic (no atomics).  cin, cout multiples of 64,
+// 16-byte aligned operands, 32-bit buffer offsets (the launcher checks).
+// Bank conflicts of the transposing read: a half-wave reads four rows x 64 bytes; with 128-byte rows, rows r and r + 2 would
+// share banks, so the two 64-byte halves of a row are swapped on rows with bit 1 set (a row's pieces then cover all 256 bytes
+// over any four consecutive rows).
+template <int G>
+__global__ __launch_bounds__(256, 4) void wgrad16_kernel(WgradParams p) {
+  constexpr int LL = WROWS;  // list length (pair count padded to 16, <= 128)
+  constexpr int PITCH = 64;  // halfwords per row of both images
+  __shared__ __attribute__((aligned(16))) unsigned short sD[WROWS * PITCH];  // dy tile, bf16 [row][co]
+  __shared__ __attribute__((aligned(16))) unsigned short sX[WROWS * PITCH];  // gathered x rows of one offset, bf16 [pair][ci]
+  __shared__ int s_row[G * LL];  // tile row of the p-th pair (padding: row 0)
+  __shared__ int s_src[G * LL];  // its x row (padding: -1 = a row beyond x: zeros)
+  __shared__ int s_cnt[G * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned wbx = blockIdx.x, wby = blockIdx.y;
+  if (!(p.ablate & 4096) && (gridDim.y & 7u) == 0u) {  // uniform: the workgroups of a row split share an XCD (see wgrad_kernel)
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7u, slot = lin >> 3;
+    wbx = slot % gridDim.x, wby = (slot / gridDim.x) * 8u + xcd;
+  }
+  const int grp = wbx % p.ngroups, tile_id = wbx / p.ngroups;
+  const int ci0 = (tile_id / p.ct_tiles) * WT, co0 = (tile_id % p.ct_tiles) * WT;
+  const int k0 = grp * G;
+  const int ng = min(G, p.K - k0);
+  const int64_t rbeg = (int64_t)wby * p.rows_per_split;
+  const int64_t rend = min(p.n_out, rbeg + p.rows_per_split);
+  const int c4 = tid & 15, rr = tid >> 4;  // staging: float4 column, rows rr + 16 i (both tiles)
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, col = lane & 31;
+  // image address of (row, halfword column c): the 64-byte halves of a row are swapped where bit 1 of the row is set
+  auto img = [](int row, int c) { return row * PITCH + (c ^ ((row & 2) << 4)); };
+  // transposing read: this lane hands in four channels (4 (lane & 3) .. of the sixteen at 16 ((lane >> 4) & 1)) of row (lane & 15) >> 2
+  const int tr_row = 8 * h + ((lane & 15) >> 2), tr_c = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  f32x16 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = (f32x16){0};
+  const i32x4 bx = raw_rsrc(p.x, p.x_bytes), bd = raw_rsrc(p.dy, p.dy_bytes), bn = raw_rsrc(p.nbr, p.nbr_bytes);
+  const unsigned ldx4 = 4u * (unsigned)p.ldx, ldy4 = 4u * (unsigned)p.ldy, K4 = 4u * (unsigned)p.K;
+  const unsigned x_coff = 4u * (unsigned)(ci0 + 4 * c4), d_coff = 4u * (unsigned)(co0 + 4 * c4);
+  float4 rx[8];
+  auto gather = [&](int g) __attribute__((always_inline)) {  // x rows of the compacted pairs of offset g -> registers (-1: zeros)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      rx[i] = __builtin_bit_cast(float4, raw_load_v4(bx, (int)(__umul24((unsigned)s_src[g * LL + rr + 16 * i], ldx4) + x_coff), 0, 0));
+  };
+  auto put = [&](unsigned short *im, int row, const float4 &v) __attribute__((always_inline)) {
+    *reinterpret_cast<uint2 *>(im + img(row, 4 * c4)) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) put(sX, rr + 16 * i, rx[i]);
+  };
+  for (int64_t r0 = rbeg; r0 < rend; r0 += WROWS) {
+    __syncthreads();  // previous tile fully consumed
+    int nb[G], rank[G];
+    if (tid < WROWS) {
+      const int64_t row = r0 + tid;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const bool ok = row < rend && g < ng;
+        const int v = raw_load_i32(bn, (int)(ok ? (unsigned)row * K4 + 4u * (unsigned)(k0 + g) : 0x80000000u), 0, 0);
+        nb[g] = ok ? v : -1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t row = r0 + rr + 16 * i;
+      const float4 v = __builtin_bit_cast(float4, raw_load_v4(bd, (int)((row < rend ? (unsigned)row * ldy4 : 0x80000000u) + d_coff), 0, 0));
+      put(sD, rr + 16 * i, v);
+    }
+    if (tid < WROWS) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const unsigned long long mm = __ballot(nb[g] >= 0);
+        rank[g] = wave_rank(mm);
+        if (lane == 0) s_cnt[2 * g + wave] = __popcll(mm);
+      }
+    }
+    __syncthreads();
+    if (tid < WROWS) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (nb[g] >= 0) {
+          const int pos = (wave == 1 ? s_cnt[2 * g] : 0) + rank[g];
+          s_row[g * LL + pos] = tid, s_src[g * LL + pos] = nb[g];
+        }
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {  // tail pairs: dy row 0 times a zero x row
+        const int m = s_cnt[2 * g] + s_cnt[2 * g + 1];
+        const int t = tid - WROWS;
+        if (t < ((m + 15) & ~15) - m) s_row[g * LL + m + t] = 0, s_src[g * LL + m + t] = -1;
+      }
+    }
+    __syncthreads();
+    gather(0);
+    stash();
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g < ng) {  // uniform
+        if (g + 1 < ng) gather(g + 1);  // in flight during the MFMAs below
+        const int m = s_cnt[2 * g] + s_cnt[2 * g + 1];
+        const int nk16 = (m + 15) >> 4;  // sixteen pairs per MFMA
+        for (int kk = 0; kk < nk16; ++kk) {
+          const int pa = 16 * kk + tr_row;  // this lane's pair of the low half (high half: + 4)
+          const int r_lo = s_row[g * LL + pa], r_hi = s_row[g * LL + pa + 4];
+          const uint2 a_lo = lds_tr16(sX + img(pa, 32 * wm + tr_c)), a_hi = lds_tr16(sX + img(pa + 4, 32 * wm + tr_c));
+          const uint2 b_lo = lds_tr16(sD + img(r_lo, 32 * wn + tr_c)), b_hi = lds_tr16(sD + img(r_hi, 32 * wn + tr_c));
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y)),
+                                                           __builtin_bit_cast(bf16x8v, make_uint4(b_lo.x, b_lo.y, b_hi.x, b_hi.y)), acc[g], 0, 0, 0);
+        }
+        if (g + 1 < ng) {
+          __syncthreads();  // everyone done reading sX
+          stash();
+          __syncthreads();
+        }
+      }
+    }
+  }
+  // ---- epilogue: the partial slab (C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h)
+  float *dst = p.out + (int64_t)wby * p.K * p.cin * p.cout;
+  const int co = co0 + 32 * wn + col;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (g < ng) {  // uniform
+      const int k = k0 + g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+        dst[((int64_t)k * p.cin + ci) * p.cout + co] = acc[g][r];
+      }
+    }
+  }
+}
+
 template <int G>
 static void launch_wgrad(const WgradParams &p, dim3 grid, hipStream_t st) {
   const bool vec = (((uintptr_t)p.x | (uintptr_t)p.dy) & 15) == 0 && ((p.ldx | p.ldy | p.cin | p.cout) & 3) == 0;
@@ -2826,7 +2971,12 @@ static int wgrad_impl(const float *x, int64_t n_in, int32_t ldx, int32_t cin, co
   } else if (bf16_stream) wgrad_stream_bf16_kernel<false><<<grid, 256, 0, st>>>(p);
   else if (pl.G == 9 && stream_ok && g_wgrad_stream && flat) wgrad_stream_kernel<4, false, true><<<grid, 256, 0, st>>>(p);
   else if (pl.G == 9 && stream_ok && g_wgrad_stream) wgrad_stream_kernel<4><<<grid, 256, 0, st>>>(p);
-  else if (pl.G == 9) launch_wgrad<9>(p, grid, st);
+  else if (g_math == 1 && g_wgrad_bf16 && !g_wgrad_bf16_off && pl.G != 9 && cin % WT == 0 && cout % WT == 0 && p.buf_ok &&
+           (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && ((ldx | ldy) & 3) == 0) {
+    // --math bf16: the mid-layer weight gradients on the bf16 matrix cores too (wgrad16_kernel)
+    if (pl.G == 3) wgrad16_kernel<3><<<grid, 256, 0, st>>>(p);
+    else wgrad16_kernel<1><<<grid, 256, 0, st>>>(p);
+  } else if (pl.G == 9) launch_wgrad<9>(p, grid, st);
   else if (pl.G == 3) launch_wgrad<3>(p, grid, st);
   else launch_wgrad<1>(p, grid, st);
   MINK_CHECK_LAUNCH();

@@ -558,6 +558,54 @@ def test_stem_weight_gradient_on_bf16_matrix_cores(oracle_maps):
     assert 1e-6 < rel < 1e-2, rel
 
 
+@pytest.mark.parametrize("n_out,cin,cout,K", [(1000, 64, 64, 27), (4097, 64, 128, 27), (129, 128, 64, 27), (530, 256, 256, 27), (70, 512, 512, 27),
+                                              (36754, 64, 64, 27)])
+def test_mid_layer_weight_gradient_on_the_bf16_matrix_cores(n_out, cin, cout, K):
+    """wgrad16_kernel (BASELINE config #4 for the mid-layer weight gradients: bf16 operands, row-major bf16 tiles in LDS, fragments
+    through the transposing LDS read, fp32 accumulation) on synthetic tables with the mid-layer fill -- ragged row counts (partial
+    tiles, partial 16-pair MFMA steps, an offset nobody has, one a whole tile lacks):
+      * against a float64 sum of the SAME operands rounded to bf16 (what the kernel is asked to compute): fp32-accumulation accuracy;
+      * against the exact-fp32 kernel: within bf16 operand rounding (and not equal to it: the bf16 kernel really ran);
+      * bitwise against itself."""
+    from nerf_downstream_amd import minkowski as ME
+    from nerf_downstream_amd._lib import lib
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(n_out + cin + 3 * cout)
+    n_in = max(4, n_out + 17)
+    nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
+    nbr[torch.rand(n_out, K, generator=g) < 0.45] = -1
+    nbr[:, K // 2 - 1] = -1
+    if n_out > 300:
+        nbr[128:256, 1] = -1
+    x = torch.randn(n_in, cin, generator=g)
+    dy = torch.randn(n_out, cout, generator=g)
+    xb, dyb = x.bfloat16().double(), dy.bfloat16().double()
+    ref = torch.zeros(K, cin, cout, dtype=torch.float64)
+    for k in range(K):
+        sel = nbr[:, k] >= 0
+        ref[k] = xb[nbr[sel, k].long()].T @ dyb[sel]
+    xd, dyd, nd = x.to(dev), dy.to(dev), nbr.to(dev)
+    exact = Fn.conv_wgrad(xd, dyd, nd, (K, cin, cout))
+    old = ME.set_conv_math("bf16")
+    try:
+        got = Fn.conv_wgrad(xd, dyd, nd, (K, cin, cout))
+        again = Fn.conv_wgrad(xd, dyd, nd, (K, cin, cout))
+        lib().mink_conv_set_stagger(1 << 28)  # bit 28: bf16 math keeps the exact-fp32 weight-gradient kernel
+        kept = Fn.conv_wgrad(xd, dyd, nd, (K, cin, cout))
+    finally:
+        lib().mink_conv_set_stagger(0)
+        ME.set_conv_math(old)
+    scale = float(ref.abs().max()) + 1e-30
+    err = float((got.cpu().double() - ref).abs().max()) / scale
+    assert err < 2e-5, err  # fp32 accumulation of <= n_out products of bf16 operands (exact products: 16 significant bits)
+    assert torch.equal(got, again)
+    assert torch.equal(kept, exact)  # the switch really selects the fp32 kernel ...
+    rel = float((got - exact).norm() / exact.norm())
+    assert 1e-4 < rel < 1e-2, rel  # ... and the default really rounds the operands to bf16
+
+
 def _chain_tolerance(xd, w, nd, ref, scale, flip=False):
     """Bound for max |y - float64| / max |y| of the row-compacted kernels.  Since round 5 an output element is ONE fp32
     accumulation chain over all its ~K x cin products (an offset's accumulators START as the C rows they belong to; until
