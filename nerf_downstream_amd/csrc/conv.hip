@@ -303,6 +303,18 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
          ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
 }
 __device__ __forceinline__ float bf16_residual(float a) { return a - (float)(__bf16)a; }
+using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8v pack_bits_bf16x8(const float (&v)[8]) {  // registers that already hold bf16 bits in their low halves
+  auto lo = [&](int i) { return __float_as_uint(v[i]); };
+  const uint4 u = make_uint4(lo(0) | (lo(1) << 16), lo(2) | (lo(3) << 16), lo(4) | (lo(5) << 16), lo(6) | (lo(7) << 16));
+  return __builtin_bit_cast(bf16x8v, u);
+}
+__device__ __forceinline__ bf16x8v pack_bf16x8(const float (&v)[8]) {
+  const uint4 u = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+  return __builtin_bit_cast(bf16x8v, u);
+}
 
 template <bool W_T, bool STAGE, int FLAT, int MATH>
 __global__ __launch_bounds__(256, 2) void gather_gemm2_kernel(GemmParams p) {
@@ -863,7 +875,11 @@ constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * CLDA + C
 // then paid once per 48 MFMAs instead of once per 24 and a block's LDS operands feed both strips; bit-identical results, and
 // measured 8-14 % SLOWER on every layer (two waves per SIMD hide each other's latencies worse than four: DESIGN.md Appendix A),
 // so only NWV = 4 is instantiated).
-template <bool W_T, int CM, bool PERM = false, bool ABL = false, int NWV = 4>
+// MATH = 1 (--math bf16; the class-permuted data gradients): the same kernel with ONE v_mfma_f32_16x16x32_bf16 per block and item where
+// the fp32 form issues eight 16x16x4 -- the item's weight fragment and a block's gathered operands are rounded to bf16 in registers
+// (eight cvt_pk per block and item), LDS and global traffic unchanged: the kernel then runs at its "no matrix work" time, which for the
+// strided data gradients is far under what the dense bf16 kernel takes (the table there is two thirds empty per offset).
+template <bool W_T, int CM, bool PERM = false, bool ABL = false, int NWV = 4, int MATH = 0>
 __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_gemm_kernel(GemmParams p) {
   const int abl = ABL ? p.stagger : 0;
   constexpr bool CCIN = mink::CCIN && (W_T || !PERM);  // (the forward-layout class-permuted form -- tests only -- has no registers to spare)
@@ -1261,6 +1277,13 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
           else return gw[slot][q][e];
         };
         using std::integral_constant;
+        if constexpr (MATH == 1) {  // channels 16 (e >> 2) + 4 kq + (e & 3) of the item in slot e of both fragments
+          const float wv8[8] = {wf(integral_constant<int, 0>{}), wf(integral_constant<int, 1>{}), wf(integral_constant<int, 2>{}), wf(integral_constant<int, 3>{}),
+                                wf(integral_constant<int, 4>{}), wf(integral_constant<int, 5>{}), wf(integral_constant<int, 6>{}), wf(integral_constant<int, 7>{})};
+          const float xv8[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack_bf16x8(wv8), pack_bf16x8(xv8), c, 0, 0, 0);
+          return;
+        }
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 0>{}), u0.x, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 1>{}), u0.y, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 2>{}), u0.z, c, 0, 0, 0);
@@ -1942,18 +1965,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WgradParams p) {
 // Pipeline per wave: table entries of block b+1 are fetched during block b and broadcast through a wave-private LDS
 // slot; the x gathers run one three-offset sub-batch ahead of the MFMAs; FUSE recomputes dY from the conv output and
 // the pooled gradient as the fp32 kernel does (parents one block ahead).
-using bf16x8v = __attribute__((ext_vector_type(8))) __bf16;
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ bf16x8v pack_bits_bf16x8(const float (&v)[8]) {  // registers that already hold bf16 bits in their low halves
-  auto lo = [&](int i) { return __float_as_uint(v[i]); };
-  const uint4 u = make_uint4(lo(0) | (lo(1) << 16), lo(2) | (lo(3) << 16), lo(4) | (lo(5) << 16), lo(6) | (lo(7) << 16));
-  return __builtin_bit_cast(bf16x8v, u);
-}
-__device__ __forceinline__ bf16x8v pack_bf16x8(const float (&v)[8]) {
-  const uint4 u = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-  return __builtin_bit_cast(bf16x8v, u);
-}
 
 // B16 (bf16 STORAGE of the full-resolution stage, stem16.hip): x is the bf16 copy of the input ([n][32], 64-byte rows) and
 // `dy` -- FUSE: the convolution output -- is bf16 too; the operands are then 2-byte loads that need no conversion.
@@ -2568,6 +2579,7 @@ static int g_wgrad_bf16 = 1;  // bf16 math: stem weight gradient on the bf16 MFM
 static int g_wgrad_bf16_off = 0;
 static int g_b16t_off = 0;      // set_stagger bit 11: the bf16-storage stem weight gradient without the LDS transposition (A/B tests)
 static int g_compact = 1;  // fp32 mid layers on compact_gemm_kernel (set_stagger bit 30: the dense kernel, for the tests that compare the two)
+static int g_compact_perm16 = 1;  // --math bf16: the class-permuted data gradients on compact_gemm_kernel<.., MATH = 1> (set_stagger bit 27 = off: the dense bf16 kernel, A/B)
 static int g_compact_cin32 = 0;  // set_stagger bit 8 (measurement only, scripts/kbench.py stemc): the class-permuted form also takes cin = 32
 static int g_compact_perm = 1;  // ... and the class-permuted strided data gradients (bit 31)
 static int g_wgrad_xcd = 1;  // streaming wgrad: groups of a row split share an XCD (stream_slot; bit 29: plain order)
@@ -2578,6 +2590,7 @@ int mink_conv_set_stagger(int units) {
   const int old = g_stagger;
   g_stagger = units & 255;
   g_compact_cin32 = (units >> 8) & 1;
+  g_compact_perm16 = !((units >> 27) & 1);
   g_b16t_off = (units >> 11) & 1;      // bit 11: bf16-storage stem weight gradient with 2-byte gathers (A/B)
   g_flat = !(units & 512);      // bit 9: no flattened-K stem path
   g_wgrad_stream = !(units & 1024);  // bit 10: tiled (LDS) wgrad kernel for the stem
@@ -2585,7 +2598,7 @@ int mink_conv_set_stagger(int units) {
   g_wgrad_xcd = !((units >> 29) & 1);    // bit 29: plain workgroup order in the streaming weight-gradient kernels (A/B)
   g_compact = !((units >> 30) & 1);      // bit 30: mid layers back on gather_gemm2_kernel (A/B)
   g_compact_perm = !(((unsigned)units >> 31) & 1u);  // bit 31: class-permuted strided data gradients back on gather_gemm2_kernel (A/B)
-  g_wgrad_force = (units >> 12) & 0xFFFF;  // bits 12-15: force G (1, 3, 9), bits 16-27: force the row split count
+  g_wgrad_force = (units >> 12) & 0x7FFF;  // bits 12-15: force G (1, 3, 9), bits 16-26: force the row split count
   return old;
 }
 
@@ -2694,8 +2707,8 @@ static int compact_plan(int64_t n_rows, int K, int cout) {
 // is over 32-channel chunks; kbench ksweep: the largest that keeps the launch within ~800 workgroups (l2.conv1 three slices 51 us
 // against 57 at two or four, l3.conv1 five 53 against 57 at seven).
 static bool compact_perm_shape(int64_t n_rows, int K, int cin, int cout, int row_classes) {
-  return g_compact && g_compact_perm && g_math == 0 && row_classes && K >= 8 && cin >= (g_compact_cin32 ? 32 : 64) && cin % BK == 0 &&
-         cout % BN == 0 && n_rows >= 1;
+  return g_compact && g_compact_perm && (g_math == 0 || (g_math == 1 && g_compact_perm16)) && row_classes && K >= 8 &&
+         cin >= (g_compact_cin32 ? 32 : 64) && cin % BK == 0 && cout % BN == 0 && n_rows >= 1;
 }
 static int compact_perm_plan(int64_t n_rows, int cin, int cout) {
   constexpr int cap = 850;
@@ -2766,6 +2779,7 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
   const bool stats_split = want_stats && zs > 1 && (cout & 3) == 0 && cout <= 1024 && (ldy & 3) == 0 &&
                            (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
   if (compact_perm_shape(n_virtual, K, cin, cout, row_perm != nullptr) && row_perm && vec && !p.accumulate && !stats_out &&
+      (g_math == 0 || w_transposed) &&  // (bf16 math: the data-gradient form only)
       (ldy & 3) == 0 && 4ll * K * cin * cout < (1ll << 31) && 4ll * n_in * ldx < (1ll << 32) &&  // (32-bit gather offsets)
       (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0) {
     // class-permuted rows, every live offset of a tile, split over channel chunks (compact_gemm_kernel<.., PERM>)
@@ -2788,6 +2802,11 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
       MINK_REQUIRE(abl_ok, "gather_gemm: %d bytes of LDS per workgroup refused", smem);
       compact_gemm_kernel<true, CMT, true, true><<<cgrid, 256, smem, st>>>(p);
+    } else if (w_transposed && g_math == 1) {
+      static const bool a16_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<true, CMT, true, false, 4, 1>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
+      MINK_REQUIRE(a16_ok, "gather_gemm: %d bytes of LDS per workgroup refused", smem);
+      compact_gemm_kernel<true, CMT, true, false, 4, 1><<<cgrid, 256, smem, st>>>(p);
     } else if (w_transposed) compact_gemm_kernel<true, CMT, true><<<cgrid, 256, smem, st>>>(p);
     else compact_gemm_kernel<false, CMT, true><<<cgrid, 256, smem, st>>>(p);
     MINK_CHECK_LAUNCH();
@@ -2801,6 +2820,8 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
   }
   if (stats_direct) p.stats = (float *)stats_ws;
   unsigned tiles_x = grid.x;  // row tiles that wrote statistics partials
+  // (--math bf16 keeps the stride-1 mid layers on the dense bf16 kernel: the row-compacted form with one bf16 MFMA per block and item,
+  //  measured round 5, is no faster there -- l1.conv2 57 / 60 us against 56 / 56 forward / data gradient, l3 48 / 58 against 44 / 46)
   const bool compact = g_compact && g_math == 0 && vec && !row_perm && !p.accumulate && K >= 8 && p.kper <= CKP && cin >= 64 &&
                        cin % BK == 0 && cout % BN == 0 && (ldy & 3) == 0 && 4ll * K * cin * cout < (1ll << 31) &&
                        4ll * n_in * ldx < (1ll << 32) && (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;

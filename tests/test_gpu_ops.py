@@ -752,6 +752,65 @@ def test_row_compacted_kernel_over_permuted_rows_against_float64(n_out, K, cin, 
         L.mink_conv_set_stagger(0)
 
 
+@pytest.mark.parametrize("n_out,K,cin,cout,pure", [(130, 27, 64, 64, True), (1000, 27, 128, 64, True), (517, 27, 256, 128, False), (300, 9, 512, 64, True)])
+def test_permuted_rows_kernel_on_the_bf16_matrix_cores(n_out, K, cin, cout, pure):
+    """--math bf16: the class-permuted data gradient on compact_gemm_kernel<.., MATH = 1> (one v_mfma_f32_16x16x32_bf16 per block and
+    item, operands rounded to bf16 in registers) against a float64 sum of the SAME operands rounded to bf16, bitwise against itself,
+    and against the dense bf16 kernel it replaces (set_stagger bit 27)."""
+    from nerf_downstream_amd import minkowski as ME
+    from nerf_downstream_amd._lib import lib
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(n_out * 7 + K + cin + int(pure))
+    n_in = max(4, n_out // 3 + 5)
+    nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
+    cls = torch.randint(0, 8, (n_out,), generator=g)
+    if pure:
+        keep = torch.zeros(8, K, dtype=torch.bool)
+        for c in range(8):
+            keep[c, torch.randperm(K, generator=g)[: 1 + c]] = True
+        nbr[~keep[cls]] = -1
+        nbr[torch.rand(n_out, K, generator=g) < 0.3] = -1
+    else:
+        nbr[torch.rand(n_out, K, generator=g) < 0.5] = -1
+    segs = []
+    for c in range(8):
+        rows = torch.nonzero(cls == c).flatten().to(torch.int32)
+        segs += [rows, torch.full(((-len(rows)) % 128,), -1, dtype=torch.int32)]
+    perm = torch.cat(segs)
+    x = torch.randn(n_in, cin, generator=g)
+    w = torch.randn(K, cin, cout, generator=g) * 0.1
+    wk = w.transpose(1, 2).contiguous()  # the data-gradient form reads W[k] as [cout][cin]
+    xb, wb = x.bfloat16().double(), w.bfloat16().double()
+    ref = torch.zeros(n_out, cout, dtype=torch.float64)
+    for k in range(K):
+        sel = nbr[:, k] >= 0
+        ref[sel] += xb[nbr[sel, k].long()] @ wb[k]
+    xd, wd, nd, pd = x.to(dev), wk.to(dev), nbr.to(dev), perm.to(dev)
+    scale = float(ref.abs().max()) + 1e-30
+    L = lib()
+    old = ME.set_conv_math("bf16")
+    try:
+        for zs in (1, 2):
+            Fn._FORCE_KSPLIT = zs
+            y = Fn.gather_gemm(xd, wd, nd, cout, w_transposed=True, row_perm=pd)
+            err = float((y.cpu().double() - ref).abs().max()) / scale
+            assert err < 1e-5, (zs, err)  # exact products of bf16 operands, fp32 accumulation
+            assert torch.equal(y, Fn.gather_gemm(xd, wd, nd, cout, w_transposed=True, row_perm=pd)), zs
+        L.mink_conv_set_stagger(1 << 27)  # the dense bf16 kernel
+        Fn._FORCE_KSPLIT = 1
+        Fn._PLAN_CACHE.clear()
+        y3 = Fn.gather_gemm(xd, wd, nd, cout, w_transposed=True, row_perm=pd)
+        assert float((y3 - y).abs().max()) / scale < 2e-5
+        assert not torch.equal(y3, y)  # (another kernel, another summation order: the switch really switches)
+    finally:
+        Fn._FORCE_KSPLIT = 0
+        L.mink_conv_set_stagger(0)
+        Fn._PLAN_CACHE.clear()
+        ME.set_conv_math(old)
+
+
 @pytest.mark.parametrize("B,C,ncls,rows", [(16, 512, 51, 33), (3, 2048, 40, 5), (5, 64, 7, 1), (2, 96, 130, 40)])
 def test_classifier_head_matches_torch(B, C, ncls, rows):
     """mink_head_forward/backward (global average pooling + the kernel-volume-1 `final` convolution with bias, reference
