@@ -1442,6 +1442,10 @@ struct WgradParams {
 // raw buffer loads -- a missing neighbour / a row past the end / a column past the width is an out-of-range offset that
 // returns zeros, so a load costs one 24-bit multiply-add instead of a 64-bit address, a select and (as the guarded form
 // compiled) a branch around every load.
+// (Round 5, measured and removed: 64-row tiles -- 36 KB of LDS, four workgroups per CU instead of two: l1.conv2 102.5 us against 96.7,
+//  l3 93 / 82, only l4 63 / 66.5; the step 3.61-3.62 ms against 3.57-3.58.  Half the rows per tile pad an offset's pairs to 16 twice as
+//  often and pay the tile's three barriers twice per 128 rows; occupancy was not what held this kernel back.  The bf16 form, whose
+//  matrix work is a sixteenth, does gain from four workgroups per CU: wgrad16_kernel.)
 template <int G, bool NARROW, bool VEC, bool BUF = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   static_assert(!BUF || VEC, "buffer loads are 16 bytes wide");
