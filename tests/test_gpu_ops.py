@@ -295,8 +295,13 @@ def test_convolution_reduced_math(oracle_maps, mode, tol, cin, cout, stride, ts)
     for a, b in [(y.F, oy.F), (F_g.grad, F_c.grad)]:
         scale = float(b.detach().abs().max())
         assert float((a.detach().cpu() - b.detach()).abs().max()) <= tol * scale, (mode, float((a.detach().cpu() - b.detach()).abs().max()), scale)
-    # the weight gradient stays in exact fp32
-    assert torch.allclose(conv.kernel.grad.cpu(), oconv.kernel.grad, atol=ATOL * max(1.0, float(oconv.kernel.grad.abs().max())), rtol=RTOL)
+    gw, ogw = conv.kernel.grad.cpu(), oconv.kernel.grad
+    if mode == "bf16" and cin % 64 == 0 and cout % 64 == 0:
+        # round 5: under --math bf16 the mid-layer weight gradients run on the bf16 matrix cores too (wgrad16_kernel)
+        err = float((gw - ogw).abs().max()) / float(ogw.abs().max())
+        assert 1e-5 < err <= tol, err  # (really bf16 operands, and within their accuracy)
+    else:  # split-bf16 and the narrow stem keep the exact-fp32 weight-gradient kernels
+        assert torch.allclose(gw, ogw, atol=ATOL * max(1.0, float(ogw.abs().max())), rtol=RTOL)
 
 
 def test_fused_bn_relu_sumpool(oracle_maps):
