@@ -2720,7 +2720,8 @@ static int compact_perm_plan(int64_t n_rows, int cin, int cout) {
   // (n_rows is the padded length of the class permutation: up to 127 padding rows per class, whose tiles exit at once)
   const int64_t tiles = cdiv(std::max<int64_t>(n_rows - 512, 64), 64) * cdiv(cout, BN);
   int best = 1;
-  for (int zs = 2; zs <= std::min(ncc, 5); ++zs) {  // (a split that does not divide the chunk count just has a shorter last slice)
+  // (up to nine slices where the launch stays under the cap: layer 4 at four scenes per GPU, 5 slices 33 us, 9 slices 27 -- ksplit_sweep, round 5)
+  for (int zs = 2; zs <= std::min(ncc, 9); ++zs) {  // (a split that does not divide the chunk count just has a shorter last slice)
     if (tiles * zs > cap || zs * 4 * n_rows * cout > (128ll << 20)) break;
     best = zs;
   }
