@@ -366,6 +366,8 @@ def main():
 
     if "BENCH_WGRAD_OVERLAP" in os.environ:
         Fn.set_wgrad_overlap(os.environ["BENCH_WGRAD_OVERLAP"] != "0")
+    if os.environ.get("BENCH_PREPARE_ON_COMPUTE") == "1" and dev.type == "cuda":  # (timing experiment: the map build in line with the step)
+        model._side = torch.cuda.current_stream()
     state = {"tf": model.process_input(batches[0])}
     reuse_maps, tf_cache = os.environ.get("BENCH_ABLATE_MAPS", "0") == "1", {}
 
@@ -469,11 +471,78 @@ def main():
     if n_tail and not args.no_kernel_timing:
         Fn.kernel_timings()  # (drop the tail's launches: the record covers the K timed steps only; ~20 us, no table read-back)
     fence()
+    step_marks = [] if (os.environ.get("BENCH_STEP_TIMES") and dev.type == "cuda") else None  # (diagnostic: GPU time of every timed step)
+    probe_lib = None
+    if step_marks is not None and os.environ.get("BENCH_CLOCK_PROBE"):  # (diagnostic: scripts/ubench/clock_probe.hip after every step)
+        import ctypes
+
+        probe_lib = ctypes.CDLL(os.environ["BENCH_CLOCK_PROBE"])
+        probe_out = torch.zeros(args.steps, 2, dtype=torch.int64, device=dev)
+        trace_ms = int(os.environ.get("BENCH_CLOCK_TRACE_MS", "0"))  # a resident one-wave kernel sampling the clock under load
+        if trace_ms:
+            trace_out = torch.zeros(trace_ms * 10, 2, dtype=torch.int32, device=dev)
+            trace_stream = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            probe_lib.clock_trace(ctypes.c_void_p(trace_out.data_ptr()), trace_ms * 10, 10000, ctypes.c_void_p(trace_stream.cuda_stream))
+        else:
+            torch.cuda.synchronize()
+    if step_marks is not None and os.environ.get("BENCH_STEP_PHASES"):
+        Fn._PHASE_LOG = []
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if step_marks is not None and i == int(os.environ.get("BENCH_PAUSE_AT", "-1")):  # (diagnostic: what a pause in mid-run does)
+            torch.cuda.synchronize()
+            if os.environ.get("BENCH_PAUSE_BUSY") == "1":
+                a_ = torch.randn(4096, 4096, device=dev)
+                t_ = time.perf_counter()
+                while time.perf_counter() - t_ < 0.2:
+                    a_ = (a_ @ a_) * 1e-4
+                torch.cuda.synchronize()
+            else:
+                time.sleep(0.2)
         loss = step(args.warmup + i)
+        if step_marks is not None:
+            if probe_lib is not None:
+                probe_lib.clock_probe(ctypes.c_void_p(probe_out[i].data_ptr()), 1000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            ev_ = torch.cuda.Event(enable_timing=True)
+            ev_.record()
+            step_marks.append((ev_, time.perf_counter()))
+            lead_ = int(os.environ.get("BENCH_MAX_LEAD", "0"))  # (diagnostic: hold the host at most this many steps ahead)
+            if lead_ and len(step_marks) > lead_:
+                step_marks[-1 - lead_][0].synchronize()
     fence()
     dt = time.perf_counter() - t0
+    if step_marks and rank == 0:
+        print("[bench] GPU ms between the ends of consecutive timed steps: " +
+              " ".join(f"{a[0].elapsed_time(b[0]):.2f}" for a, b in zip(step_marks, step_marks[1:])), file=sys.stderr)
+        print("[bench] host ms between queuing the ends of consecutive timed steps: " +
+              " ".join(f"{(b[1] - a[1]) * 1e3:.2f}" for a, b in zip(step_marks, step_marks[1:])), file=sys.stderr)
+        print("[bench] how far the GPU's end of a step lies behind the host's queuing of it, relative to the first timed step (ms): " +
+              " ".join(f"{step_marks[0][0].elapsed_time(m[0]) - (m[1] - step_marks[0][1]) * 1e3:.1f}" for m in step_marks[1:]), file=sys.stderr)
+    if probe_lib is not None and rank == 0:
+        khz = probe_lib.clock_probe_ref_khz()
+        t_ = probe_out.cpu().double()
+        print(f"[bench] shader clock seen by a probe kernel after every timed step (MHz; reference counter {khz} kHz): " +
+              " ".join(f"{x:.0f}" for x in (t_[:, 0] / t_[:, 1] * khz / 1e3).tolist()), file=sys.stderr)
+    if probe_lib is not None and trace_ms and rank == 0:
+        torch.cuda.synchronize()
+        t_ = trace_out.cpu().double().view(-1, 20, 2).sum(1)  # 2 ms per printed value
+        print("[bench] shader clock under load, every 2 ms from the start of the timed region (MHz): " +
+              " ".join(f"{x:.0f}" for x in (t_[:, 0] / t_[:, 1] * 100).tolist()), file=sys.stderr)
+    if step_marks is not None and Fn._PHASE_LOG and rank == 0:
+        log, Fn._PHASE_LOG = Fn._PHASE_LOG, None
+        begins = [k for k, (n, _, _) in enumerate(log) if n == "step_begin"]
+        per = []
+        for b0, b1 in zip(begins[:-1], begins[1:]):
+            e0 = log[b0][1]
+            d_ = {n: e0.elapsed_time(e) for n, e, _ in log[b0:b1]}
+            d_["next_step_begin"] = e0.elapsed_time(log[b1][1])
+            per.append(d_)
+        names = sorted(per[-1], key=lambda n: per[-1][n])
+        print("[bench] phases of every timed step (GPU ms after its step_begin): " + " ".join(names), file=sys.stderr)
+        for k, d_ in enumerate(per):
+            print(f"[bench]   step {k:3d}: " + " ".join(f"{d_.get(n, float('nan')):7.3f}" for n in names), file=sys.stderr)
+    Fn._PHASE_LOG = None
     timings = Fn.kernel_timings() if not args.no_kernel_timing else {}
     Fn.enable_kernel_timing(False)
 

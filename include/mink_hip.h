@@ -47,6 +47,8 @@ extern "C" {
 /* Device-side status word bits (written by the coordinate kernels into `status`). */
 #define MINK_STATUS_RANGE 1u     /* a coordinate fell outside the packable range */
 #define MINK_STATUS_UNSORTED 2u  /* batch column is not non-decreasing */
+#define MINK_STATUS_NOT_ASCENDING 4u /* mink_coords_build_levels, informational: the input rows' keys are not strictly ascending
+                                        (when CLEAR the rows were their own unique rows and level 0's hash map was left empty) */
 
 const char *mink_last_error(void);
 int mink_abi_version(void);
@@ -97,6 +99,11 @@ int mink_coords_unique(const uint64_t *keys, int64_t n, uint64_t *table_keys, in
  *   in2out of level l), index_a[l][n] (first-occurrence rows; may be NULL for l > 0).
  *   meta[nlev+2] (device int32): unique rows per level, then the status word, then the batch
  *   count (batch index of the last row + 1).  The caller reads `meta` back once.
+ * Input rows whose packed keys are strictly ascending (the order of a voxel grid's `links`) need no hash insert at
+ * level 0: every row is compared with the one before it, and only when a pair is out of order
+ * (MINK_STATUS_NOT_ASCENDING in the status word) does level 0 go through its hash map.  In the ascending case that
+ * map is left EMPTY (all slots cleared): a caller that wants look-ups through it inserts the level's rows itself
+ * (mink_coords_make_keys + mink_coords_unique).
  * The hash map of level l > 0 occupies only the first mink_table_capacity(rows of level l-1) slots of its
  * buffer -- the capacity for the rows it really receives, computed on the device; a later look-up in it
  * (mink_kernel_map) must be given that capacity, which the caller can compute once it has read `meta`.

@@ -20,6 +20,17 @@ void set_error(const char *fmt, ...) {
 
 constexpr int kBlock = 256;  // 4 waves
 
+// Timing diagnostic (MINK_DIAG_DUP, bit mask): launch an idempotent map kernel a second time -- what the step pays for one
+// more of it is what it pays for the first.  1 = 3x3x3 tables, 2 = block insert, 4 = leader pass 2, 8 = level insert,
+// 16 = leader pass 1, 32 = block fill, 64 = 0xFF fills.
+static int diag_dup() {
+  static const int v = [] {
+    const char *e = getenv("MINK_DIAG_DUP");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 // ------------------------------------------------------------------------------ keys
 __device__ __forceinline__ uint64_t dev_table_capacity(int64_t n) {
   uint64_t cap = 64;
@@ -30,10 +41,32 @@ __device__ __forceinline__ uint64_t dev_table_capacity(int64_t n) {
 // clear_keys / clear_vals (optional): the hash map these keys are about to be inserted into is emptied by the same launch
 // (clear_cap slots, or the capacity for the device-resident row count) -- one launch per level less in the pyramid
 template <int MODE>  // 0 = float field rows, 1 = int32 rows
+__device__ __forceinline__ bool row_key(const void *__restrict__ coords, int64_t i, int out_ts, uint64_t &key) {
+  int b, x, y, z;
+  if (MODE == 0) {
+    const float4 c = reinterpret_cast<const float4 *>(coords)[i];
+    b = (int)floorf(c.x), x = (int)floorf(c.y), y = (int)floorf(c.z), z = (int)floorf(c.w);
+  } else {
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    b = c.x, x = c.y, y = c.z, z = c.w;
+  }
+  if (out_ts > 1) x = floor_to(x, out_ts), y = floor_to(y, out_ts), z = floor_to(z, out_ts);
+  return pack_key(b, x, y, z, key);
+}
+
+// Level 0 of a pyramid: rows whose keys are STRICTLY ascending (the order of a voxel grid's `links`, of np.nonzero) are
+// their own unique rows, and no hash insert is needed to find that out -- every row compares its key with the row before it
+// and the first wave that sees a pair out of order sets MINK_STATUS_NOT_ASCENDING (one coherent look at the word per
+// offending wave, one atomic until it is seen set).  The unique kernels of level 0 read the word (asc_fast).
+__device__ __forceinline__ bool asc_fast(const uint32_t *asc_status) {
+  return asc_status && !(*asc_status & MINK_STATUS_NOT_ASCENDING);
+}
+
+template <int MODE>
 __device__ __forceinline__ void make_keys_body(const void *__restrict__ coords, int64_t n_host, const int *__restrict__ n_dev,
                                                int out_ts, uint64_t *__restrict__ keys, uint32_t *status,
                                                unsigned long long *__restrict__ clear_keys, int *__restrict__ clear_vals,
-                                               uint64_t clear_cap) {
+                                               uint64_t clear_cap, bool check_order = false) {
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;  // device-resident row count (level chains)
   if (clear_keys) {
     const uint64_t cap = n_dev ? dev_table_capacity(n) : clear_cap;
@@ -44,29 +77,29 @@ __device__ __forceinline__ void make_keys_body(const void *__restrict__ coords, 
   }
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  int b, x, y, z;
-  if (MODE == 0) {
-    const float4 c = reinterpret_cast<const float4 *>(coords)[i];
-    b = (int)floorf(c.x), x = (int)floorf(c.y), y = (int)floorf(c.z), z = (int)floorf(c.w);
-  } else {
-    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
-    b = c.x, x = c.y, y = c.z, z = c.w;
-  }
-  if (out_ts > 1) x = floor_to(x, out_ts), y = floor_to(y, out_ts), z = floor_to(z, out_ts);
   uint64_t key;
-  if (!pack_key(b, x, y, z, key)) {
+  if (!row_key<MODE>(coords, i, out_ts, key)) {
     atomicOr(status, MINK_STATUS_RANGE);
     key = 0;  // keep the pipeline well-defined; the host raises on the status word
   }
   keys[i] = key;
+  if (check_order) {
+    uint64_t before = 0;
+    const bool bad = i > 0 && (!row_key<MODE>(coords, i - 1, out_ts, before) || before >= key);
+    const unsigned long long m = __ballot(bad);
+    if (bad && (threadIdx.x & 63) == __builtin_ctzll(m) &&
+        !(__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & MINK_STATUS_NOT_ASCENDING))
+      atomicOr(status, MINK_STATUS_NOT_ASCENDING);
+  }
 }
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restrict__ coords, int64_t n_host,
                                                            const int *__restrict__ n_dev, int out_ts,
                                                            uint64_t *__restrict__ keys, uint32_t *status,
                                                            unsigned long long *__restrict__ clear_keys = nullptr,
-                                                           int *__restrict__ clear_vals = nullptr, uint64_t clear_cap = 0) {
-  make_keys_body<MODE>(coords, n_host, n_dev, out_ts, keys, status, clear_keys, clear_vals, clear_cap);
+                                                           int *__restrict__ clear_vals = nullptr, uint64_t clear_cap = 0,
+                                                           bool check_order = false) {
+  make_keys_body<MODE>(coords, n_host, n_dev, out_ts, keys, status, clear_keys, clear_vals, clear_cap, check_order);
 }
 
 // ---------------------------------------------------------------------------- unique
@@ -75,34 +108,60 @@ __global__ __launch_bounds__(kBlock) void make_keys_kernel(const void *__restric
 // field's row count (a 2 M-slot table per level for 173 k / 37 k / 8 k ... rows cost 125 MB of clearing per batch and
 // scattered the few keys over 25 MB each).
 
+// Runs of equal keys in ADJACENT lanes insert once.  Device-scope atomics are what a map build costs the convolutions it runs
+// beside (a second launch of a hash insert adds 0.13-0.22 ms to a step, a second launch of the 3x3x3 tables nothing:
+// DESIGN.md Appendix A), and rows arrive in scan order: the cells of a 4^3 block, and the children of a coarser cell, sit
+// next to each other.  `head_mask` = ballot of the lanes that start a run; a lane's run starts at the highest head at or below it.
+__device__ __forceinline__ uint64_t shfl_up1_u64(uint64_t v) {
+  const unsigned lo = __shfl_up((unsigned)v, 1), hi = __shfl_up((unsigned)(v >> 32), 1);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ int run_head_lane(unsigned long long head_mask, int lane) {
+  return 63 - __builtin_clzll(head_mask & ((2ull << lane) - 1ull));
+}
+
 __global__ __launch_bounds__(kBlock) void insert_kernel(const uint64_t *__restrict__ keys, int64_t n_host,
                                                         const int *__restrict__ n_dev, unsigned long long *tkeys,
-                                                        int *tvals, uint64_t mask, int *__restrict__ slot_of_row) {
+                                                        int *tvals, uint64_t mask, int *__restrict__ slot_of_row,
+                                                        const uint32_t *__restrict__ asc_status) {
+  if (asc_fast(asc_status)) return;  // (ascending level 0: nothing to look up, the map stays empty)
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   if (n_dev) mask = dev_table_capacity(n) - 1;  // chained level: the map is sized for the rows that arrive
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t key = keys[i];
-  uint64_t s = mix64(key) & mask;
-  for (;;) {
-    const unsigned long long prev = atomicCAS(&tkeys[s], (unsigned long long)kEmptyKey, (unsigned long long)key);
-    if (prev == kEmptyKey || prev == key) break;
-    s = (s + 1) & mask;
+  if ((int64_t)blockIdx.x * kBlock >= n) return;  // (whole workgroups: every lane of a live wave reaches the shuffles)
+  const bool live = i < n;
+  const int lane = threadIdx.x & 63;
+  const uint64_t key = live ? keys[i] : kEmptyKey;  // (no packed key is all ones: an idle lane never joins a run)
+  const uint64_t before = shfl_up1_u64(key);
+  const bool head = live && (lane == 0 || before != key);
+  const unsigned long long head_mask = __ballot(head);
+  int s32 = 0;
+  if (head) {
+    uint64_t s = mix64(key) & mask;
+    for (;;) {
+      const unsigned long long prev = atomicCAS(&tkeys[s], (unsigned long long)kEmptyKey, (unsigned long long)key);
+      if (prev == kEmptyKey || prev == key) break;
+      s = (s + 1) & mask;
+    }
+    atomicMin(&tvals[s], (int)i);  // first occurrence wins (the head is the lowest row of its run)
+    s32 = (int)s;
   }
-  atomicMin(&tvals[s], (int)i);  // first occurrence wins
-  slot_of_row[i] = (int)s;
+  s32 = __shfl(s32, live ? run_head_lane(head_mask, lane) : lane);
+  if (live) slot_of_row[i] = s32;
 }
 
 // flag first occurrences, count them per block
 __global__ __launch_bounds__(kBlock) void flag_kernel(const int *__restrict__ tvals, const int *__restrict__ slot_of_row,
                                                       int64_t n_host, const int *__restrict__ n_dev,
-                                                      uint8_t *__restrict__ flags, int *__restrict__ block_counts) {
+                                                      uint8_t *__restrict__ flags, int *__restrict__ block_counts,
+                                                      const uint32_t *__restrict__ asc_status) {
   __shared__ int s_cnt[kBlock / 64];
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool fast = asc_fast(asc_status);
   bool first = false;
   if (i < n) {
-    first = tvals[slot_of_row[i]] == (int)i;
+    first = fast || tvals[slot_of_row[i]] == (int)i;
     flags[i] = first;
   }
   const unsigned long long m = __ballot(first);
@@ -177,7 +236,8 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint64_t *__restri
                                                         const int *__restrict__ slot_of_row,
                                                         const int *__restrict__ block_offsets, int64_t n_host,
                                                         const int *__restrict__ n_dev, int *tvals,
-                                                        int *__restrict__ out_coords, int *__restrict__ unique_index) {
+                                                        int *__restrict__ out_coords, int *__restrict__ unique_index,
+                                                        const uint32_t *__restrict__ asc_status) {
   __shared__ int s_cnt[kBlock / 64];
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -191,16 +251,17 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint64_t *__restri
     for (int w = 0; w < wave; ++w) uid += s_cnt[w];
     if (unique_index) unique_index[uid] = (int)i;
     reinterpret_cast<int4 *>(out_coords)[uid] = unpack_key(keys[i]);
-    tvals[slot_of_row[i]] = uid;
+    if (!asc_fast(asc_status)) tvals[slot_of_row[i]] = uid;
   }
 }
 
 __global__ __launch_bounds__(kBlock) void inverse_kernel(const int *__restrict__ tvals,
                                                          const int *__restrict__ slot_of_row, int64_t n_host,
-                                                         const int *__restrict__ n_dev, int *__restrict__ inverse) {
+                                                         const int *__restrict__ n_dev, int *__restrict__ inverse,
+                                                         const uint32_t *__restrict__ asc_status) {
   const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n) inverse[i] = tvals[slot_of_row[i]];
+  if (i < n) inverse[i] = asc_fast(asc_status) ? (int)i : tvals[slot_of_row[i]];
 }
 
 // Level chains: the inverse map of level l and the keys of level l + 1 (made from level l's unique rows, with level l + 1's
@@ -213,11 +274,12 @@ __global__ __launch_bounds__(kBlock) void inverse_next_keys_kernel(const int *__
                                                                    uint64_t *__restrict__ keys, uint32_t *status,
                                                                    unsigned long long *__restrict__ next_tkeys,
                                                                    int *__restrict__ next_tvals, const int *__restrict__ coords0,
-                                                                   const int *__restrict__ n0, int *last_out) {
+                                                                   const int *__restrict__ n0, int *last_out,
+                                                                   const uint32_t *__restrict__ asc_status) {
   {
     const int64_t n = n_dev ? (int64_t)*n_dev : n_host;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) inverse[i] = tvals[slot_of_row[i]];
+    if (i < n) inverse[i] = asc_fast(asc_status) ? (int)i : tvals[slot_of_row[i]];
   }
   if (last_out && blockIdx.x == 0 && threadIdx.x == 0) {
     const int n = *n0;
@@ -279,19 +341,43 @@ __device__ __forceinline__ uint64_t blk_hash(uint64_t key) {
 __device__ __forceinline__ void blk_insert_body(const int *__restrict__ coords, int64_t n, int ts, unsigned long long *table,
                                                 uint64_t mask, int *__restrict__ slot_of_row) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+  const bool live = i < n;  // (callers drop whole idle workgroups; every lane of a live wave reaches the shuffles)
+  const int lane = threadIdx.x & 63;
+  const int4 c = reinterpret_cast<const int4 *>(coords)[live ? i : n - 1];
   uint64_t key;
   int local;
   block_key(c.x, c.y, c.z, c.w, ts, key, local);  // rows of a map are always in range
-  uint64_t s = blk_hash(key) & mask;
-  for (;;) {
-    const unsigned long long prev = atomicCAS(&table[2 * s], (unsigned long long)kEmptyKey, (unsigned long long)key);
-    if (prev == kEmptyKey || prev == key) break;
-    s = (s + 1) & mask;
+  if (!live) key = kEmptyKey;
+  // adjacent lanes in the same block (scan order: the z run of a block, ~4 rows) insert once, with the OR of their cells
+  const uint64_t before = shfl_up1_u64(key);
+  const bool head = live && (lane == 0 || before != key);
+  const unsigned long long head_mask = __ballot(head);
+  int s32 = 0;
+  {
+    // run length of a head = distance to the next head (or to the end of the wave); idle lanes are heads of nothing
+    const unsigned long long later = (head_mask | ~__ballot(live)) >> lane >> 1;
+    const int len = head ? (later ? __builtin_ctzll(later) + 1 : 64 - lane) : 0;
+    unsigned long long bits = 1ull << local;
+    int maxlen = len;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, d));
+    for (int j = 1; j < maxlen; ++j) {
+      const int l2 = __shfl(local, min(lane + j, 63));
+      if (j < len) bits |= 1ull << l2;
+    }
+    if (head) {
+      uint64_t s = blk_hash(key) & mask;
+      for (;;) {
+        const unsigned long long prev = atomicCAS(&table[2 * s], (unsigned long long)kEmptyKey, (unsigned long long)key);
+        if (prev == kEmptyKey || prev == key) break;
+        s = (s + 1) & mask;
+      }
+      atomicAnd(&table[2 * s + 1], ~bits);  // the mask is kept inverted: the 0xFF fill of the table means "empty"
+      s32 = (int)s;
+    }
   }
-  atomicAnd(&table[2 * s + 1], ~(1ull << local));  // the mask is kept inverted: the 0xFF fill of the table means "empty"
-  slot_of_row[i] = (int)s;
+  s32 = __shfl(s32, live ? run_head_lane(head_mask, lane) : lane);
+  if (live) slot_of_row[i] = s32;
 }
 
 // One row per block (the one in its lowest occupied cell, the "leader") owns the block's run of `rowids`.  Runs are
@@ -823,7 +909,7 @@ static int64_t unique_nblocks(int64_t n) { return cdiv(n > 0 ? n : 1, kBlock); }
 // enqueue the five kernels of insert_and_map; n_dev (optional) holds the row count on the device
 static int unique_launch(const uint64_t *keys, int64_t n, const int *n_dev, uint64_t *table_keys, int32_t *table_vals,
                          int64_t cap, int32_t *out_coords, int32_t *unique_index, int32_t *inverse, int32_t *n_unique,
-                         void *workspace, hipStream_t st, bool skip_inverse = false) {
+                         void *workspace, hipStream_t st, bool skip_inverse = false, const uint32_t *asc_status = nullptr) {
   const int64_t nb = unique_nblocks(n);
   char *ws = (char *)workspace;
   int *slot_of_row = (int *)ws;
@@ -834,18 +920,19 @@ static int unique_launch(const uint64_t *keys, int64_t n, const int *n_dev, uint
   ws += align_up(4 * nb, 256);
   int *block_offsets = (int *)ws;
   const dim3 grid((unsigned)nb);
-  insert_kernel<<<grid, kBlock, 0, st>>>(keys, n, n_dev, (unsigned long long *)table_keys, table_vals,
-                                         (uint64_t)cap - 1, slot_of_row);
+  for (int rep = 0; rep < 1 + ((diag_dup() & 8) != 0); ++rep)
+    insert_kernel<<<grid, kBlock, 0, st>>>(keys, n, n_dev, (unsigned long long *)table_keys, table_vals,
+                                           (uint64_t)cap - 1, slot_of_row, asc_status);
   MINK_CHECK_LAUNCH();
-  flag_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, n_dev, flags, block_counts);
+  flag_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, n_dev, flags, block_counts, asc_status);
   MINK_CHECK_LAUNCH();
   scan_kernel<<<1, kScanBlock, 0, st>>>(block_counts, block_offsets, nb, n_unique);
   MINK_CHECK_LAUNCH();
   assign_kernel<<<grid, kBlock, 0, st>>>(keys, flags, slot_of_row, block_offsets, n, n_dev, table_vals, out_coords,
-                                         unique_index);
+                                         unique_index, asc_status);
   MINK_CHECK_LAUNCH();
   if (skip_inverse) return MINK_OK;  // (the caller fuses it with the next level's first pass)
-  inverse_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, n_dev, inverse);
+  inverse_kernel<<<grid, kBlock, 0, st>>>(table_vals, slot_of_row, n, n_dev, inverse, asc_status);
   MINK_CHECK_LAUNCH();
   return MINK_OK;
 }
@@ -926,15 +1013,16 @@ int mink_coords_build_levels(const void *coords, int mode, int64_t n, int32_t nl
       // (the level's hash map is emptied by the same launch; levels > 0: by the fused pass at the end of the previous level)
       if (mode == 0)
         make_keys_kernel<0><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status, (unsigned long long *)table_keys[l],
-                                                    table_vals[l], (uint64_t)cap);
+                                                    table_vals[l], (uint64_t)cap, true);
       else
         make_keys_kernel<1><<<grid, kBlock, 0, st>>>(src, n, n_dev, out_ts_host[l], keys, status, (unsigned long long *)table_keys[l],
-                                                    table_vals[l], (uint64_t)cap);
+                                                    table_vals[l], (uint64_t)cap, true);
       MINK_CHECK_LAUNCH();
     }
+    const uint32_t *asc = l == 0 ? status : nullptr;  // (strictly ascending input rows: level 0 without its hash insert)
     // index_a: first-occurrence rows (optional, kept for level 0), index_b: inverse / in2out
     int rc = unique_launch(keys, n, n_dev, table_keys[l], table_vals[l], cap, out_coords[l],
-                           index_a[l], index_b[l], meta + l, uws, st, true);
+                           index_a[l], index_b[l], meta + l, uws, st, true, asc);
     if (rc) return rc;
     // inverse of this level + keys (and emptied hash map) of the next; the last level: + batch count
     // (meta[nlev] = status word, meta[nlev+1] = batch index of the last input row + 1)
@@ -942,7 +1030,7 @@ int mink_coords_build_levels(const void *coords, int mode, int64_t n, int32_t nl
     inverse_next_keys_kernel<<<grid, kBlock, 0, st>>>(
         table_vals[l], slot_of_row, n, n_dev, index_b[l], last ? nullptr : (const void *)out_coords[l], last ? nullptr : meta + l,
         last ? 1 : out_ts_host[l + 1], keys, status, last ? nullptr : (unsigned long long *)table_keys[l + 1],
-        last ? nullptr : table_vals[l + 1], (const int *)out_coords[0], meta, last ? meta + nlev + 1 : nullptr);
+        last ? nullptr : table_vals[l + 1], (const int *)out_coords[0], meta, last ? meta + nlev + 1 : nullptr, asc);
     MINK_CHECK_LAUNCH();
   }
   return MINK_OK;
@@ -978,7 +1066,8 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
   auto flush_fills = [&]() -> int {
     if (n_fill == 0) return MINK_OK;
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(cdiv(fill_max, kBlock), 2048));
-    fill_ff_kernel<<<dim3((unsigned)blocks, (unsigned)n_fill), kBlock, 0, st>>>(fills);
+    for (int rep = 0; rep < 1 + ((diag_dup() & 64) != 0); ++rep)
+      fill_ff_kernel<<<dim3((unsigned)blocks, (unsigned)n_fill), kBlock, 0, st>>>(fills);
     MINK_CHECK_LAUNCH();
     n_fill = 0, fill_max = 0;
     return MINK_OK;
@@ -1033,13 +1122,14 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
     i0 = i;
     if (nb == 0) continue;
     const dim3 g((unsigned)cdiv(nmax, kBlock), (unsigned)nb);
-    blk_insert_kernel<<<g, kBlock, 0, st>>>(bb);
+    const int dup = diag_dup();
+    for (int rep = 0; rep < 1 + ((dup & 2) != 0); ++rep) blk_insert_kernel<<<g, kBlock, 0, st>>>(bb);
     MINK_CHECK_LAUNCH();
-    blk_leader_kernel<false><<<g, kBlock, 0, st>>>(bb);
+    for (int rep = 0; rep < 1 + ((dup & 16) != 0); ++rep) blk_leader_kernel<false><<<g, kBlock, 0, st>>>(bb);
     MINK_CHECK_LAUNCH();
-    blk_leader_kernel<true><<<g, kBlock, 0, st>>>(bb);
+    for (int rep = 0; rep < 1 + ((dup & 4) != 0); ++rep) blk_leader_kernel<true><<<g, kBlock, 0, st>>>(bb);
     MINK_CHECK_LAUNCH();
-    blk_fill_kernel<<<g, kBlock, 0, st>>>(bb);
+    for (int rep = 0; rep < 1 + ((dup & 32) != 0); ++rep) blk_fill_kernel<<<g, kBlock, 0, st>>>(bb);
     MINK_CHECK_LAUNCH();
   }
   // ---- pass 2: tables.  3x3x3 unit-offset tables (with / without the transposed table) and the small ones (pooling, 1x1x1)
@@ -1051,8 +1141,10 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
   auto flush27 = [&](int t) -> int {
     if (n27[t] == 0) return MINK_OK;
     const dim3 g((unsigned)cdiv(max27[t], kBlock), (unsigned)n27[t]);
-    if (t) kernel_map_blk27_kernel<true><<<g, kBlock, 0, st>>>(b27[1]);
-    else kernel_map_blk27_kernel<false><<<g, kBlock, 0, st>>>(b27[0]);
+    for (int rep = 0; rep < 1 + ((diag_dup() & 1) != 0); ++rep) {
+      if (t) kernel_map_blk27_kernel<true><<<g, kBlock, 0, st>>>(b27[1]);
+      else kernel_map_blk27_kernel<false><<<g, kBlock, 0, st>>>(b27[0]);
+    }
     MINK_CHECK_LAUNCH();
     n27[t] = 0, max27[t] = 0;
     return MINK_OK;

@@ -21,7 +21,7 @@ import torch
 from .._lib import check, lib
 
 ORIGIN_TS = 0
-_STATUS_RANGE, _STATUS_UNSORTED = 1, 2
+_STATUS_RANGE, _STATUS_UNSORTED, _STATUS_NOT_ASCENDING = 1, 2, 4
 
 
 def _stream():
@@ -78,7 +78,10 @@ class CoordinateMapKey:
 
 
 class _Level:
-    __slots__ = ("coords", "n", "tkeys", "tvals", "cap")
+    __slots__ = ("coords", "n", "tkeys", "tvals", "cap", "hash_empty")
+
+    def __init__(self):
+        self.hash_empty = False  # True: the pyramid found the rows strictly ascending and left this level's hash map empty
 
 
 class _Arena:
@@ -386,9 +389,22 @@ class CoordinateManager:
             self.levels[ts] = lev
             if l == 0:
                 self.field_unique_index, self.field_inverse = index_a[: m[0]], index_b[0, :n]
+                lev.hash_empty = not (m[nlev] & _STATUS_NOT_ASCENDING)  # (mink_coords_build_levels: no insert at level 0)
             else:
                 self.in2out[(ts_list[l - 1], ts)] = index_b[l, :n_prev]
             n_prev = m[l]
+
+    def hash_map(self, ts):
+        """(keys, vals, capacity) of level `ts`'s per-voxel hash map (values = row ids), for callers that look coordinates up
+        themselves (`mink_kernel_map`; the networks' tables come from the block index).  A field whose rows arrived strictly
+        ascending skipped the insert at level 0 (`MINK_STATUS_NOT_ASCENDING` clear): the map is filled here, on demand."""
+        lev = self.levels[ts]
+        if lev.hash_empty:
+            self._sync_lazy()
+            full, _, _ = self._unique(lev.coords, 1, lev.n, 1)  # rows of a level are unique: row ids come out as they are
+            lev.tkeys, lev.tvals, lev.cap, lev.hash_empty = full.tkeys, full.tvals, full.cap, False
+            self._note_lazy(lev.tkeys, lev.tvals)
+        return lev.tkeys, lev.tvals, lev.cap
 
     # ------------------------------------------------------------------ maps built on demand
     # A map requested for the first time is built on whatever stream asks for it.  With several

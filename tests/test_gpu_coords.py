@@ -66,6 +66,54 @@ def test_unique_stride_kernel_maps(oracle_maps, grid, negative, dup):
     assert np.array_equal(boff, np.searchsorted(c_ref[4][:, 0], np.arange(4)))
 
 
+@pytest.mark.parametrize("case", ["ascending", "one_duplicate", "one_swap", "last_pair_swapped", "single_row", "float_jitter"])
+def test_ascending_rows_skip_the_level_0_insert_and_nothing_else_does(oracle_maps, case):
+    """mink_coords_build_levels compares every row's key with the row before it: strictly ascending rows (a voxel grid's
+    `links` order) are their own unique rows and level 0 runs without its hash insert (the level's map stays empty until
+    `hash_map()` asks for it); ONE pair out of order -- a duplicate, a swap, anywhere -- and level 0 goes through the hash map.
+    Either way: unique rows, inverse map, the strided levels and a table equal the C oracle's, bit for bit."""
+    from nerf_downstream_amd import minkowski as ME
+
+    coords, _ = batch_scenes([11, 12], grid=40, cin=1, negative=True)
+    n = len(coords)
+    expect_fast = case in ("ascending", "single_row", "float_jitter")
+    if case == "one_duplicate":
+        coords = torch.cat([coords[: n // 2 + 1], coords[n // 2 :]])  # row n//2 twice, adjacent: ascending but not strictly
+    elif case == "one_swap":
+        coords[[n // 3, n // 3 + 1]] = coords[[n // 3 + 1, n // 3]]
+    elif case == "last_pair_swapped":
+        coords[[n - 2, n - 1]] = coords[[n - 1, n - 2]]
+    elif case == "single_row":
+        coords = coords[:1]
+    elif case == "float_jitter":  # (jitter inside the voxel: the floored keys are still ascending)
+        coords[:, 1:] += torch.from_numpy(np.random.default_rng(0).uniform(0, 0.999, (n, 3)).astype(np.float32))
+    tf = ME.TensorField(coordinates=coords.cuda(), features=torch.zeros(len(coords), 4).cuda())
+    m = tf.coordinate_manager
+    assert m.levels[1].hash_empty == expect_fast, case
+    q = oracle_maps.quantize(coords.numpy())
+    ui, inv = oracle_maps.unique(q)
+    assert np.array_equal(m.field_unique_index.cpu().numpy(), ui)
+    assert np.array_equal(m.field_inverse.cpu().numpy(), inv)
+    c1 = q[ui]
+    assert np.array_equal(m.levels[1].coords.cpu().numpy(), c1)
+    k1 = ME.CoordinateMapKey(1)
+    k2 = m.stride(k1, 2)
+    c2, i2o = oracle_maps.stride_map(c1, 2)
+    assert np.array_equal(m.levels[2].coords.cpu().numpy(), c2)
+    assert np.array_equal(m.stride_map(k1, k2).cpu().numpy(), i2o)
+    nbr, _ = m.kernel_table(k1, k2, 3, 1)
+    assert np.array_equal(nbr.cpu().numpy(), oracle_maps.kernel_map_table(c1, c2, oracle_maps.kernel_offsets(3, 1)))
+    tkeys, tvals, cap = m.hash_map(1)  # filled on demand after the shortcut: every row is found under its own id
+    assert not m.levels[1].hash_empty
+    from nerf_downstream_amd._lib import check, lib
+
+    off = oracle_maps.kernel_offsets(1, 1)
+    own = torch.empty(len(c1), 1, dtype=torch.int32, device="cuda")
+    check(lib().mink_kernel_map(tkeys.data_ptr(), tvals.data_ptr(), cap, m.levels[1].coords.data_ptr(), len(c1),
+                                np.ascontiguousarray(off, np.int32).ctypes.data, 1, own.data_ptr(), None, None))
+    assert torch.equal(own[:, 0].cpu(), torch.arange(len(c1), dtype=torch.int32))
+
+
 def test_full_size_properties():
     """BASELINE-size grid (128^3 shell, ~50k voxels x 4 samples): size-independent properties."""
     from nerf_downstream_amd import minkowski as ME
@@ -223,7 +271,8 @@ def test_block_index_tables_equal_the_per_voxel_hash():
         K = off.shape[0]
         ref = torch.empty(lout.n, K, dtype=torch.int32, device="cuda")
         ref_t = torch.full((lin.n, K), -1, dtype=torch.int32, device="cuda") if tr else None
-        check(lib().mink_kernel_map(lin.tkeys.data_ptr(), lin.tvals.data_ptr(), lin.cap, lout.coords.data_ptr(), lout.n,
+        tkeys, tvals, cap = m.hash_map(kin.ts)  # (level 0 of an ascending field skipped its insert: filled on demand)
+        check(lib().mink_kernel_map(tkeys.data_ptr(), tvals.data_ptr(), cap, lout.coords.data_ptr(), lout.n,
                                     off.ctypes.data, K, ref.data_ptr(), None if ref_t is None else ref_t.data_ptr(), None))
         torch.cuda.synchronize()
         assert torch.equal(nbr, ref), (kin.ts, kout.ts, ks)
