@@ -16,6 +16,7 @@ timed region) and `cpu_baseline` (the CPU oracle = restatement of ME's CPU algor
 the host cores on a bounded sample; N=1 only).
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -371,7 +372,27 @@ def main():
     state = {"tf": model.process_input(batches[0])}
     reuse_maps, tf_cache = os.environ.get("BENCH_ABLATE_MAPS", "0") == "1", {}
 
+    host_phase = collections.defaultdict(float) if os.environ.get("BENCH_HOST_PHASES") else None  # (diagnostic: host ms per phase)
+
     def step(i):
+        if host_phase is None or i < args.warmup:
+            return step_body(i)
+        marks = []
+        real = Fn.log_phase
+        Fn.log_phase = lambda name, stream: (marks.append((name, time.perf_counter())), real(name, stream))
+        try:
+            t_ = time.perf_counter()
+            loss = step_body(i)
+            marks.append(("returned", time.perf_counter()))
+        finally:
+            Fn.log_phase = real
+        for name, t in marks:
+            host_phase["-> " + name] += t - t_
+            t_ = t
+        host_phase["steps"] += 1
+        return loss
+
+    def step_body(i):
         # software pipeline: the TensorField (+ coordinate/kernel maps, built on a side stream) of
         # batch i+1 is prepared while batch i computes; every step builds exactly one set.  The
         # coordinate pyramid is launched first, its row counts are read back (and the kernel maps
@@ -392,6 +413,7 @@ def main():
             opt.zero_grad(set_to_none=True)
         Fn.log_phase("grads_cleared", torch.cuda.current_stream())
         out = model(tf)
+        Fn.log_phase("forward_queued", torch.cuda.current_stream())
         loss = cross_entropy(out, labels_dev[i % len(batches)])  # the trainer's own loss call (classification_training.py)
         loss.backward()
         Fn.log_phase("backward_queued", torch.cuda.current_stream())
@@ -488,6 +510,14 @@ def main():
             torch.cuda.synchronize()
     if step_marks is not None and os.environ.get("BENCH_STEP_PHASES"):
         Fn._PHASE_LOG = []
+    prof_ = None
+    if os.environ.get("BENCH_CPROFILE"):  # (diagnostic: where the host's time per step goes; backward on the calling thread so it is seen)
+        import cProfile
+
+        if os.environ["BENCH_CPROFILE"] != "mt":
+            torch.autograd.set_multithreading_enabled(False)
+        prof_ = cProfile.Profile()
+        prof_.enable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if step_marks is not None and i == int(os.environ.get("BENCH_PAUSE_AT", "-1")):  # (diagnostic: what a pause in mid-run does)
@@ -510,8 +540,18 @@ def main():
             lead_ = int(os.environ.get("BENCH_MAX_LEAD", "0"))  # (diagnostic: hold the host at most this many steps ahead)
             if lead_ and len(step_marks) > lead_:
                 step_marks[-1 - lead_][0].synchronize()
+    if prof_ is not None:
+        prof_.disable()
     fence()
     dt = time.perf_counter() - t0
+    if prof_ is not None and rank == 0:
+        import io
+        import pstats
+
+        for key in ("tottime", "cumulative"):
+            buf = io.StringIO()
+            pstats.Stats(prof_, stream=buf).sort_stats(key).print_stats(45)
+            print(f"[bench] host profile of {args.steps} timed steps by {key}:\n" + buf.getvalue(), file=sys.stderr)
     if step_marks and rank == 0:
         print("[bench] GPU ms between the ends of consecutive timed steps: " +
               " ".join(f"{a[0].elapsed_time(b[0]):.2f}" for a, b in zip(step_marks, step_marks[1:])), file=sys.stderr)
@@ -524,6 +564,10 @@ def main():
         t_ = probe_out.cpu().double()
         print(f"[bench] shader clock seen by a probe kernel after every timed step (MHz; reference counter {khz} kHz): " +
               " ".join(f"{x:.0f}" for x in (t_[:, 0] / t_[:, 1] * khz / 1e3).tolist()), file=sys.stderr)
+    if host_phase and rank == 0:
+        n_ = host_phase.pop("steps")
+        print("[bench] host ms per step spent before each mark (timed steps): " +
+              "  ".join(f"{k} {v / n_ * 1e3:.3f}" for k, v in host_phase.items()), file=sys.stderr)
     if probe_lib is not None and trace_ms and rank == 0:
         torch.cuda.synchronize()
         t_ = trace_out.cpu().double().view(-1, 20, 2).sum(1)  # 2 ms per printed value
