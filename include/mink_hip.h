@@ -154,8 +154,10 @@ typedef struct MinkKernelMapDesc {
   int32_t *blk_base;        /* [blk_cap] */
   int32_t *blk_slot;        /* [n_in] scratch: block slot of every input row */
   int32_t *blk_rowids;      /* [max(n_in, 8)] */
-  int32_t *blk_counter;     /* reserved */
-  int64_t blk_cap;          /* power of two >= 2 * n_in */
+  int32_t *blk_counter;     /* [1]: set non-zero by the build if blk_cap was too small (rows of blocks that found no slot are then
+                               missing from the tables: the caller's error, reported instead of a hang) */
+  int64_t blk_cap;          /* power of two >= 2 * the number of occupied blocks (<= n_in; the blocks of the map at tensor stride ts
+                               are the cells of the map at 4 ts, so a caller that holds that map knows the number) */
 } MinkKernelMapDesc;
 int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *descs, void *stream);
 

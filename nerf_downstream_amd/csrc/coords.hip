@@ -338,8 +338,10 @@ __device__ __forceinline__ uint64_t blk_hash(uint64_t key) {
   return h;
 }
 
+// (A table given too few slots for the blocks -- blk_cap is the caller's promise -- must not hang the card: probing stops after
+//  one trip round the table, the row is left out (slot -1: the later passes skip it) and *overflow is cleared from its 0xFF fill.)
 __device__ __forceinline__ void blk_insert_body(const int *__restrict__ coords, int64_t n, int ts, unsigned long long *table,
-                                                uint64_t mask, int *__restrict__ slot_of_row) {
+                                                uint64_t mask, int *__restrict__ slot_of_row, int *overflow) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < n;  // (callers drop whole idle workgroups; every lane of a live wave reaches the shuffles)
   const int lane = threadIdx.x & 63;
@@ -367,13 +369,22 @@ __device__ __forceinline__ void blk_insert_body(const int *__restrict__ coords, 
     }
     if (head) {
       uint64_t s = blk_hash(key) & mask;
-      for (;;) {
+      bool placed = false;
+      for (uint64_t probes = 0; probes <= mask; ++probes) {
         const unsigned long long prev = atomicCAS(&table[2 * s], (unsigned long long)kEmptyKey, (unsigned long long)key);
-        if (prev == kEmptyKey || prev == key) break;
+        if (prev == kEmptyKey || prev == key) {
+          placed = true;
+          break;
+        }
         s = (s + 1) & mask;
       }
-      atomicAnd(&table[2 * s + 1], ~bits);  // the mask is kept inverted: the 0xFF fill of the table means "empty"
-      s32 = (int)s;
+      if (placed) {
+        atomicAnd(&table[2 * s + 1], ~bits);  // the mask is kept inverted: the 0xFF fill of the table means "empty"
+        s32 = (int)s;
+      } else {
+        *overflow = 0;
+        s32 = -1;
+      }
     }
   }
   s32 = __shfl(s32, live ? run_head_lane(head_mask, lane) : lane);
@@ -397,10 +408,10 @@ __device__ __forceinline__ void blk_leader_body(const int *__restrict__ coords, 
   uint64_t key;
   int local;
   block_key(c.x, c.y, c.z, c.w, ts, key, local);
-  if (!live) local = -1;
   const int s = slot_of_row[i];
-  const unsigned long long m = ~table[2 * (int64_t)s + 1];
-  const bool leader = local == __builtin_ctzll(m);
+  if (!live || s < 0) local = -1;
+  const unsigned long long m = s < 0 ? 0ull : ~table[2 * (int64_t)s + 1];
+  const bool leader = m && local == __builtin_ctzll(m);
   const int cnt = leader ? __popcll(m) : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int incl = cnt;
@@ -439,6 +450,7 @@ __device__ __forceinline__ void blk_fill_body(const int *__restrict__ coords, in
   int local;
   block_key(c.x, c.y, c.z, c.w, ts, key, local);
   const int s = slot_of_row[i];
+  if (s < 0) return;  // (a row that found no slot: blk_insert_body)
   const unsigned long long m = ~table[2 * (int64_t)s + 1];
   rowids[base[s] + __popcll(m & ((1ull << local) - 1ull))] = (int)i;
 }
@@ -451,7 +463,7 @@ struct BlkBuild {
   int64_t n;
   unsigned long long *table;
   uint64_t mask;
-  int *slot, *base, *rowids;
+  int *slot, *base, *rowids, *overflow;
   int ts;
 };
 struct BlkBuildBatch {
@@ -460,7 +472,7 @@ struct BlkBuildBatch {
 __global__ __launch_bounds__(kBlock) void blk_insert_kernel(BlkBuildBatch b) {
   const BlkBuild &e = b.e[blockIdx.y];
   if ((int64_t)blockIdx.x * kBlock >= e.n) return;
-  blk_insert_body(e.coords, e.n, e.ts, e.table, e.mask, e.slot);
+  blk_insert_body(e.coords, e.n, e.ts, e.table, e.mask, e.slot, e.overflow);
 }
 template <bool ASSIGN>
 __global__ __launch_bounds__(kBlock) void blk_leader_kernel(BlkBuildBatch b) {
@@ -509,7 +521,7 @@ __device__ __forceinline__ void kernel_map_blk_body(const unsigned long long *__
   int local, v = -1;
   if (block_key(c.x, c.y + off.d[3 * k], c.z + off.d[3 * k + 1], c.w + off.d[3 * k + 2], ts, key, local)) {
     uint64_t s = blk_hash(key) & mask;
-    for (;;) {
+    for (uint64_t probes = 0; probes <= mask; ++probes) {  // (bounded: a table without a free slot must not hang the look-up)
       const ulonglong2 e = reinterpret_cast<const ulonglong2 *>(table)[s];
       if (e.x == key) {
         const unsigned long long m = ~e.y;
@@ -556,7 +568,7 @@ __device__ __forceinline__ void kernel_map_blk27_body(const unsigned long long *
       const uint64_t key = ((uint64_t)(unsigned)c.x << 48) | ((uint64_t)((unsigned)nx >> 2) << 32) |
                            ((uint64_t)((unsigned)ny >> 2) << 16) | (uint64_t)((unsigned)nz >> 2);
       uint64_t s = blk_hash(key) & mask;
-      for (;;) {
+      for (uint64_t probes = 0; probes <= mask; ++probes) {
         const ulonglong2 e = reinterpret_cast<const ulonglong2 *>(table)[s];
         if (e.x == key) {
           M[q] = ~e.y, B[q] = base[s];
@@ -1092,12 +1104,13 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
     if (!e.blk_table) continue;
     MINK_REQUIRE(e.K >= 1 && e.K <= 27 && e.n_out >= 0 && e.n_in >= 0 && e.n_out * e.K < (1ll << 31) && e.in_ts >= 1,
                  "kernel_map_batch: bad shape in descriptor %d", i);
-    MINK_REQUIRE(e.blk_cap >= 64 && (e.blk_cap & (e.blk_cap - 1)) == 0 && e.blk_cap >= 2 * e.n_in && e.blk_base && e.blk_slot &&
+    MINK_REQUIRE(e.blk_cap >= 64 && (e.blk_cap & (e.blk_cap - 1)) == 0 && e.blk_base && e.blk_slot &&
                      e.blk_rowids && e.blk_counter && e.in_coords && ((uintptr_t)e.blk_table & 15) == 0,
                  "kernel_map_batch: bad block-index buffers in descriptor %d", i);
     MINK_REQUIRE(e.n_out == 0 || (e.out_coords && e.nbr && ((uintptr_t)e.out_coords & 15) == 0), "kernel_map_batch: NULL/misaligned pointer");
     if (e.blk_build) {
       int rc = add_fill(e.blk_table, (int64_t)sizeof(uint64_t) * 2 * e.blk_cap);
+      if (!rc) rc = add_fill(e.blk_counter, sizeof(int32_t));  // (0xFFFFFFFF = every block found a slot)
       if (rc) return rc;
     }
   }
@@ -1116,7 +1129,7 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
       if (!e.blk_table || !e.blk_build || e.n_in <= 0) continue;
       BlkBuild &q = bb.e[nb++];
       q.coords = e.in_coords, q.n = e.n_in, q.table = (unsigned long long *)e.blk_table, q.mask = (uint64_t)e.blk_cap - 1;
-      q.slot = e.blk_slot, q.base = e.blk_base, q.rowids = e.blk_rowids, q.ts = e.in_ts;
+      q.slot = e.blk_slot, q.base = e.blk_base, q.rowids = e.blk_rowids, q.ts = e.in_ts, q.overflow = e.blk_counter;
       nmax = std::max(nmax, e.n_in);
     }
     i0 = i;

@@ -139,6 +139,7 @@ class CoordinateManager:
         self._lazy_seen = {}   # stream -> number of marks that stream is already ordered after
         self._replaying = False
         self._arena = None
+        self._blk_flags = {}
         self._arena_only = True  # False once a map was allocated outside the arena (the on-demand builders of stride() / tools)
 
     # ------------------------------------------------------------------ plan record / replay
@@ -235,7 +236,11 @@ class CoordinateManager:
         blk, need = {}, 0
         for ts_in in dict.fromkeys(t[0] for t in todo):
             n_pad = (max(self.levels[ts_in].n, 8) + 1) // 2 * 2  # regions stay 16-byte aligned (and hold the scan scratch)
-            cap = int(L.mink_table_capacity(self.levels[ts_in].n))
+            # capacity for the BLOCKS of the map, not for its rows: a 4^3-cell block of the map at tensor stride ts is a cell of
+            # the map at 4 ts, so a pyramid that holds that level knows the count exactly (B=16: 825 k rows in 37 k blocks --
+            # a 2 MB table that an XCD's L2 holds, where the capacity for the rows was 32 MB to fill and to probe)
+            coarse = self.levels.get(4 * ts_in)
+            cap = int(L.mink_table_capacity(coarse.n if coarse is not None else self.levels[ts_in].n))
             blk[ts_in] = [cap, need, True, n_pad]  # capacity, int32 offset into the index pool, still to build
             need += 4 * cap + cap + 2 * n_pad + 4  # table (2 x int64 per slot), base, slot, rowids, counter (+pad)
         bpool = self._take(need + 4, torch.int32)
@@ -262,6 +267,13 @@ class CoordinateManager:
             self.tables[(ts_in, ts_out, ks, dil)] = (nbr, nbr_t)
         check(lib().mink_kernel_map_batch(len(todo), ctypes.cast(descs, ctypes.c_void_p), _stream()))
         self._blk_pool = bpool  # (scratch of the call; kept until the manager goes so no stream bookkeeping is needed)
+        for ts_in, (cap, boff, _, n_pad) in blk.items():  # the builds' overflow words (MinkKernelMapDesc.blk_counter)
+            self._blk_flags[ts_in] = bpool[boff + 5 * cap + 2 * n_pad : boff + 5 * cap + 2 * n_pad + 1]
+
+    def block_index_ok(self):
+        """True when every block index built so far found a slot for every block (one host synchronisation; for tests and
+        tools -- the capacities this manager asks for are exact, see `_build_tables_batched`)."""
+        return all(int(f.item()) == -1 for f in self._blk_flags.values())
 
     def _take(self, shape, dtype):
         if self._arena is None:

@@ -114,6 +114,43 @@ def test_ascending_rows_skip_the_level_0_insert_and_nothing_else_does(oracle_map
     assert torch.equal(own[:, 0].cpu(), torch.arange(len(c1), dtype=torch.int32))
 
 
+def test_block_index_capacity_is_the_block_count_and_a_short_table_is_reported(oracle_maps, monkeypatch):
+    """The block index of the map at tensor stride ts is sized for the rows of the map at 4 ts (its blocks, exactly) when the
+    pyramid holds that level; tables through it equal the oracle's.  A table with too few slots (a caller's error at the C ABI)
+    does not hang: probing is bounded, the build reports it through `blk_counter`."""
+    from nerf_downstream_amd import minkowski as ME
+    from nerf_downstream_amd._lib import lib
+
+    coords, _ = batch_scenes([21, 22], grid=48, cin=1)
+    q = oracle_maps.quantize(coords.numpy())
+    c1 = q[oracle_maps.unique(q)[0]]
+    off = oracle_maps.kernel_offsets(3, 1)
+    ref = oracle_maps.kernel_map_table(c1, c1, off)
+
+    def field():
+        tf = ME.TensorField(coordinates=coords.cuda(), features=torch.zeros(len(coords), 4).cuda())
+        return tf.coordinate_manager
+
+    m = field()
+    k1 = ME.CoordinateMapKey(1)
+    m.stride(m.stride(k1, 2), 2)  # the level at 4 ts: the block count
+    nbr, _ = m.kernel_table(k1, k1, 3)
+    assert np.array_equal(nbr.cpu().numpy(), ref) and m.block_index_ok()
+    assert m._blk_pool.numel() < 6 * len(c1)  # (sized for the blocks: the capacity for the rows alone took 10 words per row)
+    m = field()  # no coarser level: the capacity for the rows
+    nbr, _ = m.kernel_table(k1, k1, 3)
+    assert np.array_equal(nbr.cpu().numpy(), ref) and m.block_index_ok()
+    m = field()
+    L = lib()
+    monkeypatch.setattr(L, "mink_table_capacity", lambda n: 64)  # far fewer slots than blocks
+    nbr, _ = m.kernel_table(k1, k1, 3)
+    torch.cuda.synchronize()
+    monkeypatch.undo()
+    assert not m.block_index_ok()
+    got = nbr.cpu().numpy()
+    assert got.min() >= -1 and got.max() < len(c1)  # rows are missing, nothing points outside the map
+
+
 def test_full_size_properties():
     """BASELINE-size grid (128^3 shell, ~50k voxels x 4 samples): size-independent properties."""
     from nerf_downstream_amd import minkowski as ME
