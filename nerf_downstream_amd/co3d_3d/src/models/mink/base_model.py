@@ -89,6 +89,9 @@ class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
             self._side.wait_stream(torch.cuda.current_stream(t.device))
         elif fence:
             self._side.wait_event(fence)
+        wait_gate = getattr(getattr(self._ME, "functional", None), "wait_prepare_gate", None)
+        if wait_gate is not None:  # (MINK_PREPARE_GATE: one map build per step, beside its middle)
+            wait_gate(self._side)
         return torch.cuda.stream(self._side)
 
     def _new_prepare_stream(self, device):

@@ -342,6 +342,29 @@ _HOME_STREAMS = {}  # device index -> the stream the network itself runs on (not
 _BRANCH_STREAMS = {}
 
 
+def _parse_gate(v):
+    """"f<i>" / "b<i>": before block i of the native trunk's forward / backward pass; "b-1": before the stem's backward; "0": off."""
+    if not v or v == "0":
+        return None
+    return (1 if v[0] == "b" else 0, int(v[1:]))
+
+
+# MINK_PREPARE_GATE (off by default): the prepare stream may start a batch's pyramid / plan only once the compute stream has
+# reached this point of its latest native-trunk pass -- one map build per step, beside the middle of the step, instead of a
+# prepare stream that follows the host however far ahead it is.  Sustained B=16 step 3.49 -> 3.42 ms; a short timed window
+# loses its map-free tail and host-bound shapes lose ~1 % (DESIGN.md Appendix A, profiles/r05_transient.txt).
+_PREPARE_GATE = _parse_gate(os.environ.get("MINK_PREPARE_GATE", "0"))  # (backward?, stage): see trunk._stage_hook
+_PREPARE_GATE_EVENT = {}  # device index -> event of the latest gate point
+
+
+def note_prepare_gate(stream):
+    _PREPARE_GATE_EVENT[stream.device.index] = stream.record_event()
+
+
+def wait_prepare_gate(stream):
+    ev = _PREPARE_GATE_EVENT.get(stream.device.index) if (_PREPARE_GATE_EVENT and stream is not None) else None
+    if ev is not None:
+        stream.wait_event(ev)
 _PHASE_LOG = None  # diagnostic (bench.py --timeline): [(name, timing event, host clock)] of every mark
 
 

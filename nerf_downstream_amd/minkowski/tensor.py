@@ -122,6 +122,7 @@ class TensorField:
             return
         plan, self._plan = self._plan, None
         Fn.skew(self._build_stream)
+        Fn.wait_prepare_gate(self._build_stream)
         with torch.cuda.stream(self._build_stream):
             m.finish_field()
             m.replay(plan)

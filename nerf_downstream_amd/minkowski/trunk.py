@@ -251,6 +251,9 @@ _HOOK_STATE = {"installed": False, "cur": None, "fwd_skew": (), "bwd_skew": ()}
 
 def _stage_hook(stage, backward):
     st = _HOOK_STATE
+    if Fn._PREPARE_GATE and Fn._PREPARE_GATE == (int(bool(backward)), stage):
+        # (the next batches' map builds start beside THIS point of a step and not before: functional._PREPARE_GATE)
+        Fn.note_prepare_gate(st["cur"])
     if backward:
         if stage < 0:
             Fn.log_phase("stem_backward_begin", st["cur"])
@@ -270,7 +273,7 @@ _HOOK_C = STAGE_HOOK(_stage_hook)
 
 
 def _arm_hook(L, cur, fwd_skew=(), bwd_skew=()):
-    want = bool(Fn._SKEW) or Fn._PHASE_LOG is not None
+    want = bool(Fn._SKEW) or Fn._PHASE_LOG is not None or bool(Fn._PREPARE_GATE)
     st = _HOOK_STATE
     if want:
         st["cur"], st["fwd_skew"], st["bwd_skew"] = cur, fwd_skew, bwd_skew

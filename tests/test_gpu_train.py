@@ -120,13 +120,16 @@ def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink, math):
     old_math, old_storage = ME.set_conv_math("bf16" if math == "bf16s" else math), ME.set_conv_storage("bf16" if math == "bf16s" else "fp32")
     try:
         # "multi-side": the data-parallel schedule of the native trunk -- the shortcut branch on the weight-gradient stream
+        # "multi-gated": the map builds held back to a point of the compute stream's latest pass (MINK_PREPARE_GATE=f0)
         for mode, (multi, lazy_fork) in {"single": (False, False), "multi": (True, False), "multi-lazy": (True, True),
-                                          "multi-side": (True, False)}.items():
+                                          "multi-side": (True, False), "multi-gated": (True, False)}.items():
             torch.manual_seed(5)
             m = get_model("ResNet14", 28, 5).to(dev)
             reducer = BucketedGradAllReduce(m) if sink else None
             _schedule(m, multi, lazy_fork)
             Fn.set_trunk_branch_on_side(mode == "multi-side")
+            Fn._PREPARE_GATE = (0, 0) if mode == "multi-gated" else None
+            Fn._PREPARE_GATE_EVENT.clear()
             if mode == "multi-side":
                 Fn.set_branch_fork(False)  # (as a data-parallel reducer leaves it)
                 assert Fn.trunk_branch_mode() == ("side" if math == "fp32" else None)  # (bf16 math: no branch at all under data parallelism)
@@ -136,9 +139,13 @@ def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink, math):
             if math == "bf16s":
                 assert node.saved[0][7] is True  # bf16 storage taken
             out[mode] = _train_steps(m, batches, labels, 5, reducer)
+            if mode == "multi-gated":
+                assert bool(Fn._PREPARE_GATE_EVENT) == native  # (the gate point is a stage of the native trunk)
             Fn.set_grad_sink(None)
     finally:
         Fn._SKEW = 0
+        Fn._PREPARE_GATE = None
+        Fn._PREPARE_GATE_EVENT.clear()
         Fn.set_wgrad_overlap(True)
         Fn.set_grad_sink(None)
         Fn.set_trunk_branch_on_side(False)
@@ -148,6 +155,7 @@ def test_multi_stream_schedule_is_bitwise_single_stream(grid, sink, math):
     assert torch.equal(out["single"], out["multi"])
     assert torch.equal(out["single"], out["multi-lazy"])
     assert torch.equal(out["single"], out["multi-side"])
+    assert torch.equal(out["single"], out["multi-gated"])
 
 
 def _free_port():
