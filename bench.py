@@ -510,6 +510,20 @@ def main():
             torch.cuda.synchronize()
     if step_marks is not None and os.environ.get("BENCH_STEP_PHASES"):
         Fn._PHASE_LOG = []
+    gc_log = None
+    if step_marks is not None:  # (diagnostic: which host pauses are garbage collections, which are device allocations)
+        import gc as gc_
+
+        gc_log, gc_t = [], [0.0]
+
+        def gc_cb(phase, info):
+            if phase == "start":
+                gc_t[0] = time.perf_counter()
+            else:
+                gc_log.append((info["generation"], time.perf_counter() - gc_t[0], gc_t[0]))
+
+        gc_.callbacks.append(gc_cb)
+        dev_alloc0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     prof_ = None
     if os.environ.get("BENCH_CPROFILE"):  # (diagnostic: where the host's time per step goes; backward on the calling thread so it is seen)
         import cProfile
@@ -553,6 +567,14 @@ def main():
             pstats.Stats(prof_, stream=buf).sort_stats(key).print_stats(45)
             print(f"[bench] host profile of {args.steps} timed steps by {key}:\n" + buf.getvalue(), file=sys.stderr)
     if step_marks and rank == 0:
+        if gc_log is not None:
+            import gc as gc_
+
+            gc_.callbacks.remove(gc_cb)
+            ms_ = torch.cuda.memory_stats(dev)
+            print("[bench] garbage collections inside the timed region (generation, ms, at host ms): " +
+                  " ".join(f"g{g}:{d * 1e3:.2f}@{(t - t0) * 1e3:.0f}" for g, d, t in gc_log) +
+                  f" | device allocations {ms_.get('num_device_alloc', 0) - dev_alloc0}, allocator retries {ms_.get('num_alloc_retries', 0)}", file=sys.stderr)
         print("[bench] GPU ms between the ends of consecutive timed steps: " +
               " ".join(f"{a[0].elapsed_time(b[0]):.2f}" for a, b in zip(step_marks, step_marks[1:])), file=sys.stderr)
         print("[bench] host ms between queuing the ends of consecutive timed steps: " +
