@@ -48,6 +48,22 @@ def kernel_offsets(kernel_size, in_ts, dilation=1):
     return _OFFSET_CACHE[key]
 
 
+_OFFSET_CT = {}
+
+
+def _kernel_offsets_ct(kernel_size, in_ts, dilation):
+    """`kernel_offsets` as the `offsets[81]` member of a MinkKernelMapDesc (filled once per shape: the per-batch table
+    plan assigns it to ~14 descriptors)."""
+    import ctypes
+
+    key = (kernel_size, in_ts, dilation)
+    v = _OFFSET_CT.get(key)
+    if v is None:
+        o = kernel_offsets(kernel_size, in_ts, dilation).ravel().tolist()
+        v = _OFFSET_CT[key] = (ctypes.c_int32 * 81)(*(o + [0] * (81 - len(o))))
+    return v
+
+
 def _kernel_offsets(kernel_size, in_ts, dilation):
     k = int(kernel_size)
     r = np.arange(k) - (k - 1) // 2 if k % 2 == 1 else np.arange(k)
@@ -99,19 +115,31 @@ class _Arena:
     def __init__(self, device):
         self.device, self.chunks, self.off, self.used = device, [], 0, 0
         self.first = int(_Arena.last_used * 1.1) + 4096  # (read before this arena starts counting)
+        self._typed = {}  # dtype -> the newest chunk seen as that type (a take is then one slice: ~20 takes per batch, host time)
 
     def take(self, shape, dtype):
-        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
-        numel = 1
-        for s in shape:
-            numel *= s
-        nbytes = max(numel, 1) * torch.empty(0, dtype=dtype).element_size()
-        need = (nbytes + 255) // 256 * 256
+        if isinstance(shape, (tuple, list)):
+            shape = tuple(int(s) for s in shape)
+            numel = 1
+            for s in shape:
+                numel *= s
+        else:
+            numel = int(shape)
+            shape = None
+        es = dtype.itemsize
+        need = (max(numel, 1) * es + 255) // 256 * 256
         if not self.chunks or self.off + need > self.chunks[-1].numel():
             size = max(need, self.first if not self.chunks else self.chunks[-1].numel() // 2)
-            self.chunks.append(torch.empty(size, dtype=torch.uint8, device=self.device))
+            self.chunks.append(torch.empty((size + 255) // 256 * 256, dtype=torch.uint8, device=self.device))
             self.off = 0
-        t = self.chunks[-1][self.off : self.off + nbytes].view(dtype)[:numel].view(shape)
+            self._typed.clear()
+        cv = self._typed.get(dtype)
+        if cv is None:
+            cv = self._typed[dtype] = self.chunks[-1].view(dtype)
+        o = self.off // es  # (offsets are multiples of 256 bytes)
+        t = cv[o : o + numel]
+        if shape is not None and len(shape) != 1:
+            t = t.view(shape)
         self.off += need
         self.used += need
         _Arena.last_used = self.used
@@ -246,21 +274,22 @@ class CoordinateManager:
         bpool = self._take(need + 4, torch.int32)
         bbase_ptr = bpool.data_ptr()
         off = 0
+        pool_ptr, pool_so = pool.data_ptr(), pool.storage_offset()  # (as_strided counts from the start of the storage)
+        ptrs = {ts: (lev.tkeys.data_ptr(), lev.tvals.data_ptr(), lev.coords.data_ptr()) for ts, lev in self.levels.items()}
         for d, (ts_in, ts_out, ks, dil, transposed), (na, nb) in zip(descs, todo, sizes):
             lin, lout = self.levels[ts_in], self.levels[ts_out]
             K = ks ** 3
-            nbr = pool[off : off + na].view(lout.n, K)
-            off += na
-            nbr_t = pool[off : off + nb].view(lin.n, K) if transposed else None
-            off += nb
-            d.in_table_keys, d.in_table_vals, d.in_cap = lin.tkeys.data_ptr(), lin.tvals.data_ptr(), lin.cap
-            d.out_coords, d.n_out, d.n_in = lout.coords.data_ptr(), lout.n, lin.n
-            d.nbr, d.nbr_t, d.K = nbr.data_ptr(), (nbr_t.data_ptr() if transposed else None), K
-            o = kernel_offsets(ks, ts_in, dil).ravel()
-            d.offsets[: o.size] = o.tolist()
+            # (host time: one view per table -- as_strided -- and pointers by arithmetic; this loop runs once per batch)
+            nbr = pool.as_strided((lout.n, K), (K, 1), pool_so + off)
+            nbr_t = pool.as_strided((lin.n, K), (K, 1), pool_so + off + na) if transposed else None
+            d.nbr, d.nbr_t, d.K = pool_ptr + 4 * off, ((pool_ptr + 4 * (off + na)) if transposed else None), K
+            off += na + nb
+            d.in_table_keys, d.in_table_vals, d.in_cap = ptrs[ts_in][0], ptrs[ts_in][1], lin.cap
+            d.out_coords, d.n_out, d.n_in = ptrs[ts_out][2], lout.n, lin.n
+            d.offsets = _kernel_offsets_ct(ks, ts_in, dil)
             cap, boff, build, n_pad = blk[ts_in]
             p0 = bbase_ptr + 4 * boff
-            d.in_coords, d.in_ts, d.blk_build, d.blk_cap = lin.coords.data_ptr(), ts_in, int(build), cap
+            d.in_coords, d.in_ts, d.blk_build, d.blk_cap = ptrs[ts_in][2], ts_in, int(build), cap
             d.blk_table, d.blk_base = p0, p0 + 16 * cap
             d.blk_slot, d.blk_rowids, d.blk_counter = p0 + 20 * cap, p0 + 20 * cap + 4 * n_pad, p0 + 20 * cap + 8 * n_pad
             blk[ts_in][2] = False
