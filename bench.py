@@ -677,6 +677,8 @@ def main():
                 "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
                 "collective": collective_desc,
                 "final_loss": loss_val,
+                "peak_memory_gb": ({"allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                                    "reserved": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2)} if dev.type == "cuda" else None),
             },
         }
         if timings:

@@ -351,7 +351,8 @@ def _parse_gate(v):
 
 # MINK_PREPARE_GATE (off by default): the prepare stream may start a batch's pyramid / plan only once the compute stream has
 # reached this point of its latest native-trunk pass -- one map build per step, beside the middle of the step, instead of a
-# prepare stream that follows the host however far ahead it is.  Sustained B=16 step 3.49 -> 3.42 ms; a short timed window
+# prepare stream that follows the host however far ahead it is.  Steady step times and fewer prepared batches in memory (peak
+# reserved 38.8 -> 26.7 GB), no throughput gain (3,000 steps: 3.43-3.44 ms against 3.41-3.43); a short timed window
 # loses its map-free tail and host-bound shapes lose ~1 % (profiles/r05_transient.txt).
 _PREPARE_GATE = _parse_gate(os.environ.get("MINK_PREPARE_GATE", "0"))  # (backward?, stage): see trunk._stage_hook
 _PREPARE_GATE_EVENT = {}  # device index -> event of the latest gate point
