@@ -98,7 +98,12 @@ class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
         new_stream = getattr(getattr(self._ME, "functional", None), "new_stream", None)
         import torch
 
-        return new_stream(device, "prepare") if new_stream is not None else torch.cuda.Stream(device=device)
+        st = new_stream(device, "prepare") if new_stream is not None else torch.cuda.Stream(device=device)
+        from nerf_downstream_amd.memory import _RESERVED, reserve_on
+
+        if _RESERVED:  # (a process that reserved a segment for its compute stream -- bench.py, train.py -- gets one here too)
+            reserve_on(st)
+        return st
 
     @staticmethod
     def finish_input(field):
