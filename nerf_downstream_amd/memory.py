@@ -39,10 +39,11 @@ def reserve_on(stream, gigabytes=None):
     built on the prepare stream (one arena of a few hundred MB per batch, several alive at once when the host runs ahead) never
     come out of the segment `reserve` took on the default stream -- they grew the pool by 14 GB over the first hundreds of
     steps, 8-9 `hipMalloc`s inside a bench window of twenty.  Default: $MINK_RESERVE_SIDE_GB, else 16 GB (never more than an
-    eighth of the free memory; 0 = do nothing).  Idempotent per stream."""
+    eighth of the free memory; 0 = do nothing).  ONE such segment per device and process: the first prepare stream gets it (a trainer
+    has one model; a test process that builds many models must not reserve 16 GB for each)."""
     if stream is None or stream.device.type != "cuda":
         return 0
-    key = ("stream", stream.device.index, stream.cuda_stream)
+    key = ("stream", stream.device.index)
     if key in _RESERVED:
         return _RESERVED[key]
     if gigabytes is None:
