@@ -591,5 +591,19 @@ def test_reserved_segment_serves_later_allocations():
     assert torch.cuda.memory_reserved(dev) == before  # carved out of the segment: no new hipMalloc
     del blocks
     assert memory.reserve(torch.device("cpu")) == 0
+    # the allocator's free blocks belong to a stream: what is allocated under another stream grows the pool, unless that stream
+    # has a segment of its own (memory.reserve_on; one per device)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        b0 = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    grown = torch.cuda.memory_reserved(dev)
+    assert grown > before  # (not served by the first segment)
+    del b0
+    assert memory.reserve_on(side, gigabytes=0.5) == 1 << 29 and memory.reserve_on(torch.cuda.Stream(device=dev), gigabytes=4.0) == 1 << 29
+    at = torch.cuda.memory_reserved(dev)
+    with torch.cuda.stream(side):
+        blocks = [torch.empty(s << 20, dtype=torch.uint8, device=dev) for s in (100, 200, 90)]
+    assert torch.cuda.memory_reserved(dev) == at
+    del blocks
     memory._RESERVED.clear()
     torch.cuda.empty_cache()
