@@ -21,7 +21,7 @@ def test_arena_takes_are_aligned_typed_views_of_a_few_chunks():
         assert t1.shape == (3, 5) and t1.dtype == torch.int32 and t2.shape == (7,) and t2.dtype == torch.int64
         assert t3.shape == (2, 3, 4) and t4.numel() == 0 and t5.shape == (100,)
         base = a.chunks[0].data_ptr()
-        ptrs = [t.data_ptr() - base for t in (t1, t2, t3, t4, t5)]
+        ptrs = [t.data_ptr() - base for t in (t1, t2, t3, t5)]  # (an empty view has no address)
         assert all(p % 256 == 0 for p in ptrs) and ptrs == sorted(set(ptrs))  # 256-byte steps from the chunk's start, no two takes share one
         t1.fill_(1), t2.fill_(2), t3.fill_(3.0), t5.fill_(5)
         assert int(t1.sum()) == 15 and int(t2.sum()) == 14 and float(t3.sum()) == 72.0 and int(t5.sum()) == 500  # no overlap
