@@ -32,14 +32,11 @@ if os.environ.get("BENCH_DEVICE") is not None and int(os.environ.get("WORLD_SIZE
     # about one process per GPU -- but it makes the rehearsal useless, so it runs the conservative schedule.
     os.environ.setdefault("MINK_DP_MULTISTREAM", "0")
 elif int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BENCH_FORCE_REDUCER") == "1":
-    # Data parallelism: one rank drives the compute, map-preparation and weight-gradient streams plus the two streams of
-    # the RCCL process group.  HIP multiplexes streams over GPU_MAX_HW_QUEUES (default 4) hardware queues and two busy
-    # streams on one queue serialise (measured with a one-rank group: 5.5 ms/step against 4.85 with a queue for each).
-    # The HIP runtime reads it when it is loaded -- before `import torch`.  SEVEN, not eight: with the bucket-launch stream of
-    # round 4 a rank has five busy streams, and at eight hardware queues the step falls off a cliff (one-rank RCCL group,
-    # ResNet14 B=16: 4 queues 4.27 ms, 5: 4.11, 6: 3.95, 7: 3.81, 8: 5.7-6.0; ResNet34 B=4: 7: 4.3-4.6, 8: 12.6).
-    # Round 5: the cliff was a FIFTH busy hardware queue (the stream the collectives were issued from); they now go out from inside
-    # the backward call on the weight-gradient stream -- nerf_downstream_amd/hwqueues.py has the measurements and the rule.
+    # Data parallelism: one rank drives four busy streams -- compute, map preparation, weight gradients (+ shortcut branch; the bucket
+    # collectives are issued from this stream inside the backward call) and the RCCL process group's own.  HIP multiplexes streams
+    # over GPU_MAX_HW_QUEUES (default 4) hardware queues and two busy streams on one queue serialise; the device serves four queues
+    # side by side and time-slices a fifth.  The HIP runtime reads the variable when it is loaded -- before `import torch`;
+    # nerf_downstream_amd/hwqueues.py has the measurements and the rule.
     from nerf_downstream_amd.hwqueues import configure as _configure_hw_queues
 
     _configure_hw_queues(data_parallel=True)
@@ -224,6 +221,187 @@ def roofline_from_timings(timings, pair_table):
     }
 
 
+def _reserved_total(dev):
+    from nerf_downstream_amd import memory
+
+    return memory.reserved_bytes(dev)
+
+
+class Job:
+    """One configuration's training step as the timed region queues it: model + flat gradient buffer (the backward kernels' sink,
+    all-reduced in buckets when there is more than one rank) + SGD over the flat buffers + two alternating resident batches, and the
+    software pipeline of a step (the coordinate pyramid of batch i+1 launched on the prepare stream before forward i, its tables
+    after backward i is queued)."""
+
+    def __init__(self, args, dev, rank, force_reducer=False, prepare_stream=None):
+        from nerf_downstream_amd.co3d_3d.src.models import get_model
+        from nerf_downstream_amd.co3d_3d.src.modules.classification_training import cross_entropy
+        from nerf_downstream_amd.parallel import BucketedGradAllReduce
+
+        self.args, self.dev, self.cross_entropy = args, dev, cross_entropy
+        torch.manual_seed(777)  # same initial weights on every rank (reference: pl.seed_everything)
+        self.model = model = get_model(args.model, args.in_channel, args.num_classes).to(dev)
+        if prepare_stream is not None:  # (a second configuration in one process: the same four streams, not a fifth)
+            model._side = prepare_stream
+        self.state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        # one flat gradient buffer the backward kernels write into; with N > 1 ranks its buckets are all-reduced (overlapped
+        # with backward), with one rank that is all it is -- the step is the same program at every N
+        self.reducer = BucketedGradAllReduce(model, bucket_bytes=int(os.environ.get("BENCH_BUCKET_BYTES", 32 << 20)), force=force_reducer)
+        # SGD with momentum and weight decay (configs/co3d_cls.gin) as one kernel over the flat buffers (parallel.FlatSGD;
+        # BENCH_TORCH_SGD=1: torch's fused multi-tensor SGD, the same update)
+        if dev.type == "cuda" and os.environ.get("BENCH_TORCH_SGD", "0") == "0":
+            from nerf_downstream_amd.parallel import FlatSGD
+
+            self.opt = FlatSGD(self.reducer, lr=0.1, momentum=0.9, weight_decay=1e-4)
+        else:
+            self.opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=dev.type == "cuda")
+        self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=200000)
+        batches = make_batches(2, args.batch, rank, args.num_classes, args.grid, args.in_channel)
+        self.batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+        self.vox_per_step = [int(b["coordinates"].shape[0]) for b in self.batches]
+        self.labels_dev = [b["labels"].long() for b in self.batches]
+        if os.environ.get("BENCH_PREPARE_ON_COMPUTE") == "1" and dev.type == "cuda":  # (timing experiment: the map build in line with the step)
+            model._side = torch.cuda.current_stream()
+        self.state = {"tf": model.process_input(self.batches[0])}
+        self.reuse_maps, self.tf_cache = os.environ.get("BENCH_ABLATE_MAPS", "0") == "1", {}
+
+    def step_body(self, i):
+        # software pipeline: the TensorField (+ coordinate/kernel maps, built on a side stream) of
+        # batch i+1 is prepared while batch i computes; every step builds exactly one set.  The
+        # coordinate pyramid is launched first, its row counts are read back (and the kernel maps
+        # launched) after forward+backward have been queued, so the host never waits for them.
+        from nerf_downstream_amd.minkowski import functional as Fn
+
+        model, reducer, opt, state, batches = self.model, self.reducer, self.opt, self.state, self.batches
+        tf = state["tf"]
+        side = getattr(model, "_side", None)
+        Fn.log_phase("step_begin", torch.cuda.current_stream())
+        Fn.log_phase("pyramid_begin", side)
+        nb = (i + 1) % len(batches)
+        if self.reuse_maps and nb in self.tf_cache:  # (timing-only ablation: what a step costs WITHOUT building the next batch's maps)
+            nxt = None
+        else:
+            nxt = model.process_input(batches[nb], defer=True)
+        Fn.log_phase("pyramid_end", side)
+        reducer.zero_grad()
+        Fn.log_phase("grads_cleared", torch.cuda.current_stream())
+        out = model(tf)
+        Fn.log_phase("forward_queued", torch.cuda.current_stream())
+        loss = self.cross_entropy(out, self.labels_dev[i % len(batches)])  # the trainer's own loss call (classification_training.py)
+        loss.backward()
+        Fn.log_phase("backward_queued", torch.cuda.current_stream())
+        Fn.log_phase("maps_begin", side)
+        if nxt is None:
+            state["tf"] = self.tf_cache[nb]
+        else:
+            state["tf"] = model.finish_input(nxt)
+            if self.reuse_maps:
+                self.tf_cache[nb] = state["tf"]
+        Fn.log_phase("maps_end", side)
+        reducer.finish()
+        opt.step()
+        Fn.log_phase("step_end", torch.cuda.current_stream())
+        self.sched.step()
+        return loss
+
+    def forward_only_ms(self, steps=10):
+        """The network forward on an already prepared batch, training-mode batch norm, no autograd graph (north_star: "fraction of
+        HBM roofline on the sparse-conv forward")."""
+        with torch.no_grad():
+            self.model(self.state["tf"])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                self.model(self.state["tf"])
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / steps * 1e3
+
+
+def layer_table_from(warm, pair_table=None):
+    """(N_in, N_out, P, Cin, Cout) per layer from the event-timed launches, so the roofline can be recomputed."""
+    table = []
+    for t, v in warm.items():
+        m = v["meta"]
+        if m["pairs"] is None or not v["ms"]:
+            continue
+        if pair_table is not None:
+            pair_table[t] = m["pairs"]
+        table.append({
+            "op": t, "n_in": m["n_in"], "n_out": m["n_out"], "pairs": m["pairs"], "cin": m["cin"],
+            "cout": m["cout"], "avg_ms_hip_events_on_a_contended_stream": round(sum(v["ms"]) / len(v["ms"]), 4),
+            "gflop": round(2e-9 * m["pairs"] * m["cin"] * m["cout"], 3),
+            "algorithmic_mb": round(_conv_bytes(m, m["pairs"]) / 1e6, 2),
+        })
+    return table
+
+
+def forward_bytes(layer_table, storage):
+    """Algorithmic bytes of the forward convolutions of ONE batch at the storage type the configuration keeps them in.
+    The table holds one row per (kernel, row count): the two alternating batches are two rows of every layer, so rows are
+    averaged per kernel identity (until round 5 they were SUMMED, which counted every layer twice: the forward's
+    `hbm_frac_at_algorithmic_bytes` of BENCH_r02..r05 is 2x too high -- 0.116 there is 0.058)."""
+    per_kernel = {}
+    for r in layer_table:
+        if r["op"].startswith("fwd"):
+            per_kernel.setdefault(_parse_kernel(r["op"]), []).append(r["algorithmic_mb"])
+    fwd_bytes = sum(sum(v) / len(v) for v in per_kernel.values()) * 1e6
+    stem_w = [r for r in layer_table if r["op"].startswith("wgrad") and r["cin"] <= 32 and r["op"].split("x")[1].startswith("27")]
+    if storage == "bf16" and stem_w and not any(r["op"].startswith("fwd") and r["cin"] <= 32 for r in layer_table):
+        # the bf16-storage stem forward (stem16.hip) is not one of the instrumented gather-GEMM calls: its algorithmic
+        # bytes with 2-byte rows in and out (SURVEY 8d with the storage type: x, y, fp32 weights, table)
+        r = stem_w[0]
+        fwd_bytes += 2.0 * (r["n_in"] * r["cin"] + r["n_out"] * r["cout"]) + 4.0 * 27 * r["cin"] * r["cout"] + 8.0 * r["pairs"]
+    return fwd_bytes
+
+
+def run_other_config(base_args, dev, prepare_stream, model, batch, math, storage, steps, warmup):
+    """BASELINE configs #3 (per-GPU shape) and #4 beside the headline, in the same process: a fresh model, optimizer, map plan and
+    batches, the same step program, `warmup` untimed steps, then `steps` timed ones between two device synchronisations.  The
+    kernel event timing is on for the first warm-up steps only (it yields the per-layer pair counts the forward's algorithmic
+    bytes are computed from) and off in the timed region."""
+    import copy
+
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    a = copy.copy(base_args)
+    a.model, a.batch, a.math, a.storage = model, batch, math, storage
+    old_math, old_storage = Fn.set_conv_math(math), Fn.set_conv_storage(storage)
+    try:
+        job = Job(a, dev, 0, prepare_stream=prepare_stream)
+        Fn.enable_kernel_timing(True)
+        n_timed = min(3, warmup)
+        for i in range(n_timed):
+            job.step_body(i)
+        table = layer_table_from(Fn.kernel_timings())
+        Fn.enable_kernel_timing(False)
+        for i in range(n_timed, warmup):
+            job.step_body(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = job.step_body(warmup + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        vox = sum(job.vox_per_step[(warmup + i) % 2] for i in range(steps))
+        loss_val = float(loss.item())
+        if not (loss_val == loss_val and abs(loss_val) < 1e30):
+            raise SystemExit(f"non-finite loss {loss_val} in {model} B={batch} {math}: invalid run")
+        fwd_ms = job.forward_only_ms()
+        fb = forward_bytes(table, storage)
+        return {
+            "workload": f"Mink-{model}, batch={batch}/GPU, {a.grid}^3, {math} math, {storage} storage of the full-resolution stage, "
+                        "fwd+bwd+SGD step incl. coordinate/kernel map build",
+            "ms_per_step": dt / steps * 1e3, "voxels_per_s": vox / dt, "steps": steps, "warmup": warmup,
+            "voxels_per_step": job.vox_per_step[0], "final_loss": loss_val,
+            "forward_ms": fwd_ms, "forward_voxels_per_s": job.vox_per_step[0] / (fwd_ms * 1e-3),
+            "forward_conv_algorithmic_bytes": fb,
+            "hbm_frac_at_" + ("bf16" if storage == "bf16" else "fp32") + "_bytes": fb / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fb else None,
+        }
+    finally:
+        Fn.enable_kernel_timing(False)
+        Fn.set_conv_math(old_math), Fn.set_conv_storage(old_storage)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,6 +421,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only (CPU test): rendezvous over gloo, one all-reduce, print ranks_seen; no compute, no number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` leg (BASELINE configs #4 and #3's per-GPU shape, K steps each after the headline)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timeline", action="store_true", help="after the timed region: print where the phases of a step "
                     "fall on the GPU clock of every stream and when the host queued them (diagnostic)")
@@ -343,34 +523,16 @@ def main():
         from nerf_downstream_amd.memory import reserve
 
         reserve(dev)
-    torch.manual_seed(777)  # same initial weights on every rank (reference: pl.seed_everything)
-    model = get_model(args.model, args.in_channel, args.num_classes).to(dev)
-    state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    # one flat gradient buffer the backward kernels write into; with N > 1 ranks its buckets are all-reduced (overlapped
-    # with backward), with one rank that is all it is -- the step is the same program at every N
-    reducer = BucketedGradAllReduce(model, bucket_bytes=int(os.environ.get("BENCH_BUCKET_BYTES", 32 << 20)), force=force_reducer)
-    # SGD with momentum and weight decay (configs/co3d_cls.gin) as one kernel over the flat buffers (parallel.FlatSGD;
-    # BENCH_TORCH_SGD=1: torch's fused multi-tensor SGD, the same update)
-    if dev.type == "cuda" and os.environ.get("BENCH_TORCH_SGD", "0") == "0":
-        from nerf_downstream_amd.parallel import FlatSGD
-
-        opt = FlatSGD(reducer, lr=0.1, momentum=0.9, weight_decay=1e-4)
-    else:
-        opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=dev.type == "cuda")
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=200000)
-
-    batches = make_batches(2, args.batch, rank, args.num_classes, args.grid, args.in_channel)
-    batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
-    vox_per_step = [int(b["coordinates"].shape[0]) for b in batches]
-    labels_dev = [b["labels"].long() for b in batches]
-    from nerf_downstream_amd.co3d_3d.src.modules.classification_training import cross_entropy
-
+    job = Job(args, dev, rank, force_reducer=force_reducer)
+    model, reducer, state, batches, vox_per_step, state0 = job.model, job.reducer, job.state, job.batches, job.vox_per_step, job.state0
+    step_body = job.step_body
+    if dev.type == "cuda":
+        # the two up-front reservations (24 GB under the compute stream, 16 GB under the prepare stream, which the first
+        # process_input has just created) were each ONE allocation, freed at once: without this reset they ARE `max_memory_allocated`
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
     if "BENCH_WGRAD_OVERLAP" in os.environ:
         Fn.set_wgrad_overlap(os.environ["BENCH_WGRAD_OVERLAP"] != "0")
-    if os.environ.get("BENCH_PREPARE_ON_COMPUTE") == "1" and dev.type == "cuda":  # (timing experiment: the map build in line with the step)
-        model._side = torch.cuda.current_stream()
-    state = {"tf": model.process_input(batches[0])}
-    reuse_maps, tf_cache = os.environ.get("BENCH_ABLATE_MAPS", "0") == "1", {}
 
     host_phase = collections.defaultdict(float) if os.environ.get("BENCH_HOST_PHASES") else None  # (diagnostic: host ms per phase)
 
@@ -390,46 +552,6 @@ def main():
             host_phase["-> " + name] += t - t_
             t_ = t
         host_phase["steps"] += 1
-        return loss
-
-    def step_body(i):
-        # software pipeline: the TensorField (+ coordinate/kernel maps, built on a side stream) of
-        # batch i+1 is prepared while batch i computes; every step builds exactly one set.  The
-        # coordinate pyramid is launched first, its row counts are read back (and the kernel maps
-        # launched) after forward+backward have been queued, so the host never waits for them.
-        tf = state["tf"]
-        side = getattr(model, "_side", None)
-        Fn.log_phase("step_begin", torch.cuda.current_stream())
-        Fn.log_phase("pyramid_begin", side)
-        nb = (i + 1) % len(batches)
-        if reuse_maps and nb in tf_cache:  # (timing-only ablation: what a step costs WITHOUT building the next batch's maps)
-            nxt = None
-        else:
-            nxt = model.process_input(batches[nb], defer=True)
-        Fn.log_phase("pyramid_end", side)
-        if reducer is not None:
-            reducer.zero_grad()
-        else:
-            opt.zero_grad(set_to_none=True)
-        Fn.log_phase("grads_cleared", torch.cuda.current_stream())
-        out = model(tf)
-        Fn.log_phase("forward_queued", torch.cuda.current_stream())
-        loss = cross_entropy(out, labels_dev[i % len(batches)])  # the trainer's own loss call (classification_training.py)
-        loss.backward()
-        Fn.log_phase("backward_queued", torch.cuda.current_stream())
-        Fn.log_phase("maps_begin", side)
-        if nxt is None:
-            state["tf"] = tf_cache[nb]
-        else:
-            state["tf"] = model.finish_input(nxt)
-            if reuse_maps:
-                tf_cache[nb] = state["tf"]
-        Fn.log_phase("maps_end", side)
-        if reducer is not None:
-            reducer.finish()
-        opt.step()
-        Fn.log_phase("step_end", torch.cuda.current_stream())
-        sched.step()
         return loss
 
     def fence():
@@ -453,17 +575,7 @@ def main():
     layer_table, pair_table = [], {}
     if not args.no_kernel_timing:
         warm = Fn.kernel_timings()  # (synchronises on the recorded events)
-        for t, v in warm.items():  # (N_in, N_out, P, Cin, Cout) per layer so the roofline can be recomputed
-            m = v["meta"]
-            if m["pairs"] is None or not v["ms"]:
-                continue
-            pair_table[t] = m["pairs"]
-            layer_table.append({
-                "op": t, "n_in": m["n_in"], "n_out": m["n_out"], "pairs": m["pairs"], "cin": m["cin"],
-                "cout": m["cout"], "avg_ms": round(sum(v["ms"]) / len(v["ms"]), 4),
-                "gflop": round(2e-9 * m["pairs"] * m["cin"] * m["cout"], 3),
-                "algorithmic_mb": round(_conv_bytes(m, m["pairs"]) / 1e6, 2),
-            })
+        layer_table = layer_table_from(warm, pair_table)
         if warm:
             # the kernel with the longest typical launch (median over the launches of one kernel identity -- kind, K, cin, cout;
             # the two alternating batches are two tags of it: the first launches of a process run long, and a tag may have
@@ -677,38 +789,39 @@ def main():
                 "ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
                 "collective": collective_desc,
                 "final_loss": loss_val,
+                # allocated = the working set (peak of live tensors since the model was built: weights, flat gradient / momentum
+                # buffers, activations, the maps of the batches prepared ahead); pool = what the caching allocator holds from the
+                # driver, of which `reserved_up_front` are the two segments taken before the first step (memory.py)
                 "peak_memory_gb": ({"allocated": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
-                                    "reserved": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2)} if dev.type == "cuda" else None),
+                                    "pool": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
+                                    "reserved_up_front": round(_reserved_total(dev) / 2 ** 30, 2)} if dev.type == "cuda" else None),
             },
         }
         if timings:
             res["roofline"] = roofline_from_timings(timings, pair_table)
         if world == 1:
-            # forward only (north_star: "fraction of HBM roofline on the sparse-conv forward"): the network
-            # forward on an already prepared batch, training-mode batch norm, no autograd graph
-            fwd_steps = 10
-            with torch.no_grad():
-                model(state["tf"])
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(fwd_steps):
-                    model(state["tf"])
-                torch.cuda.synchronize()
-                fwd_ms = (time.perf_counter() - t1) / fwd_steps * 1e3
-            fwd_bytes = sum(r["algorithmic_mb"] for r in layer_table if r["op"].startswith("fwd")) * 1e6
-            stem_w = [r for r in layer_table if r["op"].startswith("wgrad") and r["cin"] <= 32 and r["op"].split("x")[1].startswith("27")]
-            if args.storage == "bf16" and stem_w and not any(r["op"].startswith("fwd") and r["cin"] <= 32 for r in layer_table):
-                # the bf16-storage stem forward (stem16.hip) is not one of the instrumented gather-GEMM calls: its algorithmic
-                # bytes with 2-byte rows in and out (SURVEY 8d with the storage type: x, y, fp32 weights, table)
-                r = stem_w[0]
-                fwd_bytes += 2.0 * (r["n_in"] * r["cin"] + r["n_out"] * r["cout"]) + 4.0 * 27 * r["cin"] * r["cout"] + 8.0 * r["pairs"]
+            # forward only (north_star: "fraction of HBM roofline on the sparse-conv forward")
+            fwd_ms = job.forward_only_ms()
+            fwd_bytes = forward_bytes(layer_table, args.storage)
             res.setdefault("roofline", {})["forward_only"] = {
                 "voxels_per_s": vox_per_step[0] / (fwd_ms * 1e-3), "ms": fwd_ms,
                 "conv_algorithmic_bytes": fwd_bytes,
                 "hbm_frac_at_algorithmic_bytes": fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fwd_bytes else None,
             }
         if layer_table:
-            print("[bench] per-layer conv kernels (warm-up, HIP events): " + json.dumps(layer_table), file=sys.stderr)
+            # (avg_ms here: HIP events around launches on streams that other streams' kernels contend with -- a weight-gradient
+            #  kernel reads long when it shares the CUs with the data-gradient chain; per-kernel durations come from the rocprofv3
+            #  kernel trace under profiles/, not from this table)
+            print("[bench] per-layer conv kernels (warm-up; durations are HIP events on contended streams, see profiles/*_trace_summary.txt "
+                  "for per-kernel times): " + json.dumps(layer_table), file=sys.stderr)
+        if world == 1 and not args.no_other_configs and (args.model, args.batch, args.math) == ("ResNet14", 16, "fp32"):
+            # BASELINE configs #4 and #3 (per-GPU shape) on the driver's record, measured after the headline in the same process;
+            # the headline fields above are final by now
+            k_o, w_o = min(args.steps, 20), min(max(args.warmup, 5), 10)
+            res["other_configs"] = {
+                "bf16_b16": run_other_config(args, dev, model._side, "ResNet14", 16, "bf16", "bf16", k_o, w_o),
+                "resnet34_b4": run_other_config(args, dev, model._side, "ResNet34", 4, "fp32", "fp32", k_o, w_o),
+            }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.model, args.in_channel, args.num_classes, args.grid, state0)
         print(json.dumps(res))

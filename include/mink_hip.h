@@ -154,12 +154,19 @@ typedef struct MinkKernelMapDesc {
   int32_t *blk_base;        /* [blk_cap] */
   int32_t *blk_slot;        /* [n_in] scratch: block slot of every input row */
   int32_t *blk_rowids;      /* [max(n_in, 8)] */
-  int32_t *blk_counter;     /* [1]: set non-zero by the build if blk_cap was too small (rows of blocks that found no slot are then
-                               missing from the tables: the caller's error, reported instead of a hang) */
+  int32_t *blk_counter;     /* [1]: the build fills it with 0xFFFFFFFF (= every block found a slot) and writes 0 if blk_cap was too
+                               small (rows of blocks that found no slot are then missing from the tables: the caller's error,
+                               reported instead of a hang; see also mink_set_overflow_sink) */
   int64_t blk_cap;          /* power of two >= 2 * the number of occupied blocks (<= n_in; the blocks of the map at tensor stride ts
                                are the cells of the map at 4 ts, so a caller that holds that map knows the number) */
 } MinkKernelMapDesc;
 int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *descs, void *stream);
+
+/* Process-wide overflow sink of the block-index builds: a 32-bit word in PINNED host memory (device-mapped; NULL = none), zero
+ * initialised by the caller.  A build whose blk_cap was too small writes 1 into it (besides clearing its own blk_counter) and
+ * nobody ever refills it, so a caller that looks at the word before queuing its next batch learns of a violated capacity
+ * promise without a device synchronisation or a copy -- one batch late at most, instead of silently missing neighbours. */
+int mink_set_overflow_sink(int32_t *host_word);
 
 /* ME-format rulebook from a neighbour table: per offset k the (in,out) pairs ordered
  * by output row, built with wave64 ballot + prefix sums.

@@ -101,6 +101,7 @@ SIGNATURES = {
     "mink_coords_build_levels": (ctypes.c_int, [_p, ctypes.c_int, _i64, _i32, _p, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
     "mink_kernel_map": (ctypes.c_int, [_p, _p, _i64, _p, _i64, _p, _i32, _p, _p, _p]),
     "mink_kernel_map_batch": (ctypes.c_int, [_i32, _p, _p]),
+    "mink_set_overflow_sink": (ctypes.c_int, [_p]),
     "mink_rulebook_workspace_bytes": (_i64, [_i64, _i32]),
     "mink_rulebook": (ctypes.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),
     "mink_class_partition_rows": (_i64, [_i64, _i32]),

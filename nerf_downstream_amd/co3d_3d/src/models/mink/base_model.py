@@ -99,9 +99,9 @@ class MinkowskiBaseModel(_HIP_ME.MinkowskiNetwork, InputInterface):
         import torch
 
         st = new_stream(device, "prepare") if new_stream is not None else torch.cuda.Stream(device=device)
-        from nerf_downstream_amd.memory import _RESERVED, reserve_on
+        from nerf_downstream_amd.memory import reserve_on, reserved
 
-        if _RESERVED:  # (a process that reserved a segment for its compute stream -- bench.py, train.py -- gets one here too)
+        if reserved(device):  # (a process that reserved a segment for its compute stream -- bench.py, train.py -- gets one here too)
             reserve_on(st)
         return st
 

@@ -341,7 +341,7 @@ __device__ __forceinline__ uint64_t blk_hash(uint64_t key) {
 // (A table given too few slots for the blocks -- blk_cap is the caller's promise -- must not hang the card: probing stops after
 //  one trip round the table, the row is left out (slot -1: the later passes skip it) and *overflow is cleared from its 0xFF fill.)
 __device__ __forceinline__ void blk_insert_body(const int *__restrict__ coords, int64_t n, int ts, unsigned long long *table,
-                                                uint64_t mask, int *__restrict__ slot_of_row, int *overflow) {
+                                                uint64_t mask, int *__restrict__ slot_of_row, int *overflow, int *sticky) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < n;  // (callers drop whole idle workgroups; every lane of a live wave reaches the shuffles)
   const int lane = threadIdx.x & 63;
@@ -383,6 +383,7 @@ __device__ __forceinline__ void blk_insert_body(const int *__restrict__ coords, 
         s32 = (int)s;
       } else {
         *overflow = 0;
+        if (sticky) *sticky = 1;  // (mink_set_overflow_sink: a host-visible word nobody refills -- the caller's next batch sees it)
         s32 = -1;
       }
     }
@@ -457,6 +458,7 @@ __device__ __forceinline__ void blk_fill_body(const int *__restrict__ coords, in
 
 // The block indices of ALL input maps of a batch's plan are built by four launches, not four per map (blockIdx.y = map):
 // the builds are independent of each other, and a prepared batch has six of them.
+static int *g_overflow_sink = nullptr;  // mink_set_overflow_sink
 constexpr int kMaxBatch = 8;
 struct BlkBuild {
   const int *coords;
@@ -468,11 +470,12 @@ struct BlkBuild {
 };
 struct BlkBuildBatch {
   BlkBuild e[kMaxBatch];
+  int *sticky;  // process-wide overflow sink (device-visible host word), or nullptr
 };
 __global__ __launch_bounds__(kBlock) void blk_insert_kernel(BlkBuildBatch b) {
   const BlkBuild &e = b.e[blockIdx.y];
   if ((int64_t)blockIdx.x * kBlock >= e.n) return;
-  blk_insert_body(e.coords, e.n, e.ts, e.table, e.mask, e.slot, e.overflow);
+  blk_insert_body(e.coords, e.n, e.ts, e.table, e.mask, e.slot, e.overflow, b.sticky);
 }
 template <bool ASSIGN>
 __global__ __launch_bounds__(kBlock) void blk_leader_kernel(BlkBuildBatch b) {
@@ -1066,6 +1069,18 @@ int mink_kernel_map(const uint64_t *in_table_keys, const int32_t *in_table_vals,
   return MINK_OK;
 }
 
+int mink_set_overflow_sink(int32_t *host_word) {
+  if (!host_word) {
+    g_overflow_sink = nullptr;
+    return MINK_OK;
+  }
+  void *dp = nullptr;
+  MINK_REQUIRE(hipHostGetDevicePointer(&dp, host_word, 0) == hipSuccess && dp,
+               "set_overflow_sink: the word must live in pinned (device-mapped) host memory");
+  g_overflow_sink = (int *)dp;
+  return MINK_OK;
+}
+
 int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
   MINK_REQUIRE(n >= 0 && (n == 0 || d), "kernel_map_batch: bad arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -1121,6 +1136,7 @@ int mink_kernel_map_batch(int32_t n, const MinkKernelMapDesc *d, void *stream) {
   // ---- pass 1: block indices (insert, two leader passes, fill)
   for (int i0 = 0; i0 < n;) {
     BlkBuildBatch bb;
+    bb.sticky = g_overflow_sink;
     int nb = 0;
     int64_t nmax = 0;
     int i = i0;

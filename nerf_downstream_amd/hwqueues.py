@@ -29,16 +29,23 @@ def busy_streams(data_parallel):
 
 
 def configure(data_parallel=True):
-    """Set GPU_MAX_HW_QUEUES for this process; returns the value in force.  An inherited value is kept unless it is known to be on
-    the wrong side (five busy streams and room for each to get a queue of its own)."""
-    if "torch" in sys.modules and os.environ.get("GPU_MAX_HW_QUEUES") is None:
+    """Set GPU_MAX_HW_QUEUES for this process; returns the value in force, or None when the runtime was loaded before this call
+    with nothing inherited (its default then applies and the environment is left alone).  An inherited value is kept unless it
+    is known to be on the wrong side (five busy streams and room for each to get a queue of its own)."""
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is not None:
+        try:
+            cur_n = int(cur)
+        except ValueError:
+            raise ValueError(f"GPU_MAX_HW_QUEUES={cur!r} is not an integer") from None
+    if "torch" in sys.modules and cur is None:
         # (the runtime has read its environment already: say so rather than pretend)
         print("[hwqueues] torch was imported before hwqueues.configure(): GPU_MAX_HW_QUEUES is not applied", file=sys.stderr)
-    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+        return None
     n_busy = busy_streams(data_parallel)
     if cur is None:
         os.environ["GPU_MAX_HW_QUEUES"] = str(SAFE)
-    elif n_busy > 4 and int(cur) > SAFE and os.environ.get("MINK_HWQUEUES_KEEP") != "1":  # (KEEP: measurement runs of the cliff itself)
+    elif n_busy > 4 and cur_n > SAFE and os.environ.get("MINK_HWQUEUES_KEEP") != "1":  # (KEEP: measurement runs of the cliff itself)
         print(f"[hwqueues] GPU_MAX_HW_QUEUES={cur} with {n_busy} busy streams puts a fifth queue to work (1.5-3x per step): using {SAFE}",
               file=sys.stderr)
         os.environ["GPU_MAX_HW_QUEUES"] = str(SAFE)

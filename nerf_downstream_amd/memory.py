@@ -7,6 +7,7 @@ megabytes, paid in the middle of a step (measured: ResNet34 at four scenes, one 
 still growing; a bench.py run of twenty steps that catches one reads 4.2-4.6 ms per step instead of 3.7).  An MI355X has 288 GB:
 take one segment up front and hand it to the pool; every later request of >= 1 MB is a split of it.
 """
+import logging
 import os
 
 import torch
@@ -31,6 +32,7 @@ def reserve(device, gigabytes=None):
         block = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
         del block  # (back to the allocator's pool of free LARGE blocks: split on demand, never returned to the driver)
     _RESERVED[idx] = nbytes
+    logging.getLogger(__name__).info("reserved %.1f GB for the caching allocator on cuda:%d", nbytes / 2 ** 30, idx)
     return nbytes
 
 
@@ -55,4 +57,20 @@ def reserve_on(stream, gigabytes=None):
             block = torch.empty(nbytes, dtype=torch.uint8, device=stream.device)
             del block
     _RESERVED[key] = nbytes
+    logging.getLogger(__name__).info("reserved %.1f GB for allocations under the prepare stream of cuda:%d", nbytes / 2 ** 30,
+                                     stream.device.index)
     return nbytes
+
+
+def reserved(device):
+    """True once `reserve` has taken (or been asked for) a segment on `device` in this process."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else None)
+    return idx in _RESERVED
+
+
+def reserved_bytes(device):
+    """Bytes of the segments taken up front on `device` (compute stream + prepare stream)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return int(_RESERVED.get(idx, 0)) + int(_RESERVED.get(("stream", idx), 0))

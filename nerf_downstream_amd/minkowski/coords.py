@@ -37,6 +37,30 @@ def _as_int(v):
 
 _OFFSET_CACHE = {}
 
+# Process-wide overflow sink of the block-index builds (include/mink_hip.h: mink_set_overflow_sink): a pinned host word the insert
+# kernel sets when a table was given fewer slots than its map has blocks -- rows are then MISSING from the neighbour tables.  The
+# capacities asked for here are exact when the pyramid holds the level at four times the stride, so this only fires on a broken
+# invariant; it is looked at before every batch's table build (a numpy read of host memory: no copy, no synchronisation).
+_OVERFLOW = {"word": None, "view": None}
+
+
+def _overflow_sink():
+    if _OVERFLOW["word"] is None:
+        w = torch.zeros(1, dtype=torch.int32).pin_memory()
+        check(lib().mink_set_overflow_sink(w.data_ptr()))
+        _OVERFLOW["word"], _OVERFLOW["view"] = w, w.numpy()
+    return _OVERFLOW["view"]
+
+
+def check_block_index_overflow():
+    """Raise if any block-index build of this process (so far executed on the device) ran out of slots."""
+    v = _overflow_sink()
+    if v[0] != 0:
+        v[0] = 0
+        raise RuntimeError(
+            "a block index was built with fewer slots than its map has 4^3-cell blocks: rows are missing from the neighbour tables "
+            "of an earlier batch (MinkKernelMapDesc.blk_cap must be mink_table_capacity(number of occupied blocks))")
+
 
 
 
@@ -252,6 +276,7 @@ class CoordinateManager:
                 todo.append((ts_in, ts_out, ks, dil, transposed))
         if not todo:
             return
+        check_block_index_overflow()  # (an earlier batch's builds; arms the sink on first use)
         sizes = []
         for ts_in, ts_out, ks, dil, transposed in todo:
             K = ks ** 3
@@ -302,7 +327,10 @@ class CoordinateManager:
     def block_index_ok(self):
         """True when every block index built so far found a slot for every block (one host synchronisation; for tests and
         tools -- the capacities this manager asks for are exact, see `_build_tables_batched`)."""
-        return all(int(f.item()) == -1 for f in self._blk_flags.values())
+        ok = all(int(f.item()) == -1 for f in self._blk_flags.values())
+        if not ok:
+            _overflow_sink()[0] = 0  # (reported here: the process-wide sink need not raise for it again)
+        return ok
 
     def _take(self, shape, dtype):
         if self._arena is None:

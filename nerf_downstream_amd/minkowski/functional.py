@@ -346,6 +346,10 @@ def _parse_gate(v):
     """"f<i>" / "b<i>": before block i of the native trunk's forward / backward pass; "b-1": before the stem's backward; "0": off."""
     if not v or v == "0":
         return None
+    import re
+
+    if not re.fullmatch(r"[fb]-?\d+", v):
+        raise ValueError(f"MINK_PREPARE_GATE={v!r}: expected 'f<i>' or 'b<i>' (block index; 'b-1' = before the stem's backward) or '0'")
     return (1 if v[0] == "b" else 0, int(v[1:]))
 
 

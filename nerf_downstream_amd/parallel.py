@@ -261,7 +261,7 @@ class BucketedGradAllReduce:
         self._ready[b] += 1
         if self._ready[b] == self.buckets[b][2]:
             self._bucket_event[b] = self.stage_event
-            if not self.defer:
+            if not self.defer or self.stage_stream is not None:  # (in-call launch: as ready_many)
                 self._drain()
 
     def _drain(self):

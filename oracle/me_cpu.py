@@ -215,12 +215,26 @@ class TensorField:
 
 
 # --------------------------------------------------------------------------------- functions
+# Test hook: when set, _ConvFn passes every GEMM operand through OPERAND_HOOK(tensor, role, shape) before it is multiplied, with
+# role in {"fwd_x", "fwd_w", "fwd_y", "dgrad_g", "dgrad_w", "wgrad_x", "wgrad_g"} ("fwd_y": the finished output, identity gradient)
+# and shape = (K, cin, cout, n_in, n_out).  tests/test_gpu_parity_full.py uses it to run the oracle in float64 on operands ROUNDED TO
+# bf16 exactly where the implementation under test rounds them (BASELINE config #4): what a bf16-operand / fp32-accumulate kernel is
+# asked to compute, tensor by tensor, instead of a cosine against the fp32 network.
+OPERAND_HOOK = None
+
+
+def _op(t, role, shape):
+    return t if OPERAND_HOOK is None else OPERAND_HOOK(t, role, shape)
+
+
 class _ConvFn(torch.autograd.Function):
     """A6: out[o_list] += in[i_list] @ kernel[k], k ascending; and its backward."""
 
     @staticmethod
     def forward(ctx, x, kernel, nbr):
         nbr_t = torch.from_numpy(nbr.astype(np.int64))
+        shape = (kernel.shape[0], kernel.shape[1], kernel.shape[2], x.shape[0], nbr.shape[0])
+        xf, kf = _op(x, "fwd_x", shape), _op(kernel, "fwd_w", shape)
         out = x.new_zeros(nbr.shape[0], kernel.shape[2])
         lists = []
         for k in range(nbr.shape[1]):
@@ -230,25 +244,31 @@ class _ConvFn(torch.autograd.Function):
                 continue
             i = nbr_t[o, k]
             lists.append((i, o))
-            out[o] += x[i] @ kernel[k]
+            out[o] += xf[i] @ kf[k]
         ctx.save_for_backward(x, kernel)
         ctx.lists = lists
-        return out
+        ctx.shape = shape
+        return _op(out, "fwd_y", shape)
 
     @staticmethod
     def backward(ctx, gout):
         x, kernel = ctx.saved_tensors
         gout = gout.contiguous()
+        shape = ctx.shape
         gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
         gk = torch.zeros_like(kernel)
+        if OPERAND_HOOK is not None:
+            gd, kd = _op(gout, "dgrad_g", shape), _op(kernel, "dgrad_w", shape)
+            x, gw = _op(x, "wgrad_x", shape), _op(gout, "wgrad_g", shape)
+        else:
+            gd, kd, gw = gout, kernel, gout
         for k, io in enumerate(ctx.lists):
             if io is None:
                 continue
             i, o = io
-            g = gout[o]
             if gx is not None:
-                gx[i] += g @ kernel[k].t()
-            gk[k] = x[i].t() @ g
+                gx[i] += gd[o] @ kd[k].t()
+            gk[k] = x[i].t() @ gw[o]
         return gx, gk, None
 
 

@@ -146,9 +146,20 @@ def test_block_index_capacity_is_the_block_count_and_a_short_table_is_reported(o
     nbr, _ = m.kernel_table(k1, k1, 3)
     torch.cuda.synchronize()
     monkeypatch.undo()
+    # the violated promise is LOUD: the next batch's table build of this process raises (mink_set_overflow_sink: a pinned host
+    # word the insert kernel sets, read without a synchronisation), once
+    from nerf_downstream_amd.minkowski.coords import check_block_index_overflow
+
+    m2 = field()
+    with pytest.raises(RuntimeError, match="fewer slots"):
+        m2.kernel_table(k1, k1, 3)
+    check_block_index_overflow()  # (reported once: the word is cleared)
+    nbr2, _ = m2.kernel_table(k1, k1, 3)
+    assert np.array_equal(nbr2.cpu().numpy(), ref) and m2.block_index_ok()
     assert not m.block_index_ok()
     got = nbr.cpu().numpy()
     assert got.min() >= -1 and got.max() < len(c1)  # rows are missing, nothing points outside the map
+    check_block_index_overflow()
 
 
 def test_full_size_properties():

@@ -149,6 +149,51 @@ def test_resnet18_matches_plain_torch_resnet18():
     assert torch.allclose(hip.model.bn1.running_mean.cpu(), ref.model.bn1.running_mean, atol=1e-5)
 
 
+@pytest.mark.long
+@pytest.mark.timeout(90)
+def test_resnet18_at_the_baseline_shape_matches_plain_torch():
+    """BASELINE config #5 at its OWN shape (reference co3d_2d/train.py:49,95 -- 224 x 224 renders, batch 32 -- and
+    co3d_2d/src/model/models.py:9-34): forward + backward of the HIP ResNet18 in fp32 against the plain-torch ResNet18 with the same
+    state dict ON THE SAME CARD (torch's fp32 convolutions, TF32 off): logits within north_star's 1e-3, and the gradient of EVERY
+    parameter tensor in relative L2.  Both sides are fp32 with different summation orders over up to 32 x 112 x 112 = 401 k positions,
+    and a ReLU / max-pool tie broken the other way moves a gradient by one element's share -- so the per-tensor bound is the one the
+    small-shape test above uses (5e-3), with the whole-gradient relative L2 at 2e-3; a dropped tap, a mis-strided window or a wrong
+    shortcut is O(1)."""
+    hip, ref = _pair()
+    ref = ref.cuda()
+    old_tf32 = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cudnn.allow_tf32 = torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        x = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(11)).cuda()
+        labels = ((torch.arange(32) * 7 + 3) % 51).cuda()
+        out, outr = hip(x), ref(x)
+        assert out.shape == (32, 51)
+        err = float((out.detach() - outr.detach()).abs().max())
+        F.cross_entropy(out, labels, label_smoothing=0.005).backward()
+        F.cross_entropy(outr, labels, label_smoothing=0.005).backward()
+        torch.cuda.synchronize()
+    finally:
+        torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = old_tf32
+    print(f"[co3d_2d ResNet18 224^2 B=32 fp32] max |logit error| vs torch on the card {err:.3e}")
+    assert err < 1e-3, err
+    hp, rp = dict(hip.named_parameters()), dict(ref.named_parameters())
+    assert hp.keys() == rp.keys()
+    worst, bad = ("", 0.0), []
+    for k in rp:
+        rel = float((hp[k].grad.double() - rp[k].grad.double()).norm() / rp[k].grad.double().norm().clamp_min(1e-300))
+        if rel > worst[1]:
+            worst = (k, rel)
+        if not rel < 5e-3:
+            bad.append((k, rel))
+    g = torch.cat([hp[k].grad.double().flatten() for k in rp])
+    og = torch.cat([rp[k].grad.double().flatten() for k in rp])
+    tot = float((g - og).norm() / og.norm())
+    print(f"[co3d_2d ResNet18 224^2 B=32 fp32] {len(rp)} parameter tensors: worst relative L2 {worst[1]:.2e} ({worst[0]}), all parameters {tot:.2e}")
+    assert not bad, bad
+    assert tot < 2e-3, tot
+    assert torch.allclose(hip.model.bn1.running_mean, ref.model.bn1.running_mean, atol=1e-5)
+
+
 def test_resnet18_bf16_matrix_cores_and_eval_mode():
     """run.precision = 16: bf16 MFMA operands, fp32 accumulate -- logits within 3e-2 of the fp32 torch network (two
     8-bit roundings per product over 20 convolution layers); eval mode (running statistics) matches torch's."""
