@@ -236,6 +236,12 @@ int mink_batch_offsets(const int32_t *coords, int64_t n, int32_t B, int32_t *bat
  * plain workgroup order in the streaming weight gradient, bit 30 / 31 = the dense gather-GEMM instead of the row-compacted
  * kernel for the mid layers / the strided data gradients (the tests compare the two).  Returns the previous low byte. */
 int mink_conv_set_stagger(int units);
+
+/* Which software pipeline the row-compacted mid-layer kernel (compact_gemm_kernel) runs: bit 0 = the stride-1 forward / data
+ * gradient launches, bit 1 = the class-permuted strided data gradients on the THREE-STAGE form (three LDS stages of the gathered-row
+ * tile, MFMA operands read one item ahead; three workgroups per CU), 0 = the two-stage form (four workgroups per CU).  Results are
+ * bit-identical either way.  Returns the previous mode. */
+int mink_conv_set_pipeline(int mode);
 /* Matrix-core arithmetic of mink_conv_gather_gemm (forward / input gradient):
  *   0 = exact fp32 MFMA (default), 1 = bf16 operands with fp32 accumulation (BASELINE config
  *   "bf16 mixed precision"), 3 = split-bf16 (hi/lo, three products; ~1e-5 relative).

@@ -115,6 +115,7 @@ SIGNATURES = {
         [_p, _i32, _p, _i64, _i32, _i64, _p, _i32, _p, _p, ctypes.c_uint64, _p, _p, _p, _i64, _p, _p, _i64, _p],
     ),
     "mink_conv_set_stagger": (ctypes.c_int, [ctypes.c_int]),
+    "mink_conv_set_pipeline": (ctypes.c_int, [ctypes.c_int]),
     "mink_conv_get_math": (ctypes.c_int, []),
     "mink_conv_set_math": (ctypes.c_int, [ctypes.c_int]),
     "mink_conv_plan_ksplit": (ctypes.c_int, [_i64, _i32, _i32, _i32]),
@@ -244,6 +245,8 @@ def lib():
             L.mink_bn_set_fold(int(os.environ["MINK_BN_FOLD"]))
         if os.environ.get("MINK_BN_SMALL"):
             L.mink_bn_set_small(int(os.environ["MINK_BN_SMALL"]))
+        if os.environ.get("MINK_CONV_PIPELINE"):  # (A/B runs: 0 = two-stage mid-layer kernel, 1 / 2 / 3 = three-stage, see mink_hip.h)
+            L.mink_conv_set_pipeline(int(os.environ["MINK_CONV_PIPELINE"]))
         _lib = L
     return _lib
 

@@ -250,6 +250,15 @@ def train(
         logger.info(f"loaded {path} (step {step})")
 
     train_loader, val_loader = data.train_dataloader(), data.val_dataloader()
+    # training batches reach the device through pinned staging buffers and a copy stream of their own (data/staging.py):
+    # a helper thread packs every collated batch into pinned memory, the loop below uploads it with ONE asynchronous copy
+    # whose event the model's prepare stream waits for.  MINK_STAGING=0: a pageable copy per tensor on the compute stream
+    # (what the reference's Lightning loop does with pin_memory=False).
+    stager = None
+    if device.type == "cuda" and ME is None and os.environ.get("MINK_STAGING", "1") != "0":
+        from nerf_downstream_amd.co3d_3d.src.data.staging import PinnedStager, StagedLoader
+
+        stager = PinnedStager(device)
     total_steps = max_steps + (warmup_steps if warmup_steps > 0 else 0)
     history = []
     model.train()
@@ -268,22 +277,29 @@ def train(
                 break
             batch_in_epoch += 1
         skip_batches = 0
-        batch = next(it, None)
+        if stager is not None:
+            staged = StagedLoader(it, stager)
+            next_batch = staged.next
+        else:
+            def next_batch(it=it):
+                b = next(it, None)
+                return _to_device(b, device) if b is not None else None
+        batch = next_batch()
         if batch is not None:
-            batch = _to_device(batch, device)
             field = model.process_input(batch)
         while batch is not None:
             # prepare the next batch on the side stream under this one's compute: its coordinate
             # pyramid is launched now, the row counts are read back and the kernel maps launched
             # once forward+backward are queued, so the host never waits for the device here
-            nxt_batch = next(it, None)
+            nxt_batch = next_batch()
             if nxt_batch is not None:
-                nxt_batch = _to_device(nxt_batch, device)
                 nxt_field = model.process_input(nxt_batch, defer=True)
             if reducer is not None:
                 reducer.zero_grad()
             else:
                 optimizer.zero_grad(set_to_none=True)
+            if stager is not None:  # (the labels and features of a staged batch were written by the copy stream)
+                torch.cuda.current_stream(device).wait_event(batch["h2d_event"])
             loss, out = module.training_step(batch, field)
             loss.backward()
             cur_batch = batch
@@ -316,6 +332,8 @@ def train(
                     csv_logger.log_dict(m, step)
                 if rank == 0:
                     logger.info(f"step {step}: " + " ".join(f"{k}={v:.4g}" for k, v in m.items()))
+            if stager is not None:
+                stager.release(cur_batch)  # its device buffer may be overwritten behind everything queued for it so far
             if step % val_every_n_steps == 0 or step >= total_steps:
                 vm = validate(module, val_loader, device, world)
                 history.append({"global_step": step, **vm})

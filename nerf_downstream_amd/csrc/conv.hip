@@ -851,7 +851,7 @@ constexpr int CD = 3;                // ring of global-load register sets (an it
 #endif
 constexpr bool CSWZ = MINK_CSWZ, CPF = MINK_CPF, CCIN = MINK_CCIN;
 constexpr int CLDA = CSWZ ? BK : MINK_CLDA;
-constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * CLDA + CKP * CM + 32) * 4 + CKP * CM + 4 * CM; }
+constexpr int compact_smem(int CM, bool P3 = false) { return ((CM + 1) * CLDC + (P3 ? 3 : 2) * CM * CLDA + CKP * CM + 32) * 4 + CKP * CM + 4 * CM; }
 
 // CM: rows per tile.  64: 39 KB of LDS, four workgroups (16 waves) per CU -- the latency of an item's chain (barrier,
 // LDS stores, operand reads, scatter) is hidden by the other workgroups; 128: half the weight traffic.
@@ -879,8 +879,17 @@ constexpr int compact_smem(int CM) { return ((CM + 1) * CLDC + 2 * CM * CLDA + C
 // the fp32 form issues eight 16x16x4 -- the item's weight fragment and a block's gathered operands are rounded to bf16 in registers
 // (eight cvt_pk per block and item), LDS and global traffic unchanged: the kernel then runs at its "no matrix work" time, which for the
 // strided data gradients is far under what the dense bf16 kernel takes (the table there is two thirds empty per offset).
-template <bool W_T, int CM, bool PERM = false, bool ABL = false, int NWV = 4, int MATH = 0>
-__global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_gemm_kernel(GemmParams p) {
+// P3 (round 6: the structural answer to the convoy of section 4's PMC reading): THREE stages of the gathered-row tile in LDS and the
+// MFMA operands of an item read one step AHEAD, into a second register set, under the previous item's MFMAs -- a wave leaves the
+// barrier with its operands already in registers and starts multiplying at once; what is left in front of a burst is instruction
+// issue (two LDS stores, two gather requests, the eight reads for the next item), not an LDS round trip.  The classic form reads an
+// item's operands behind the barrier that published them: every wave of the workgroup -- one per SIMD -- then waits out the same
+// LDS round trip at the same moment, and the four workgroups of a CU fall into step (57 % of a wave's life waiting to issue).
+// Costs: 8 KB more LDS (45 KB: three workgroups per CU instead of four) and 32 more VGPRs (within the 170 of three waves per SIMD);
+// the gather stage runs four items ahead of the multiplying stage, the weight stage three (two iterators).  Same arithmetic in the
+// same order: bit-identical to the classic form (tests/test_gpu_ops.py).
+template <bool W_T, int CM, bool PERM = false, bool ABL = false, int NWV = 4, int MATH = 0, bool P3 = false>
+__global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void compact_gemm_kernel(GemmParams p) {
   const int abl = ABL ? p.stagger : 0;
   constexpr bool CCIN = mink::CCIN && (W_T || !PERM);  // (the forward-layout class-permuted form -- tests only -- has no registers to spare)
   constexpr int T = 64 * NWV, SPW = 4 / NWV;  // threads, column strips per wave
@@ -888,8 +897,9 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
   constexpr int NU = ((PERM ? 27 : CKP) + NWV - 1) / NWV;  // offsets of the slice a wave looks at (cs, cs + NWV, ...)
   extern __shared__ __attribute__((aligned(16))) unsigned char c_smem[];
   float *sC = reinterpret_cast<float *>(c_smem);             // [CM + 1][CLDC]; row CM takes the padding lanes
-  float *sA = sC + (CM + 1) * CLDC;                          // [2][CM][CLDA] compacted gathered rows
-  int *s_src = reinterpret_cast<int *>(sA + 2 * CM * CLDA);   // [CKP][CM] input row of the p-th compacted row (padding: row 0)
+  constexpr int NST = P3 ? 3 : 2;                            // stages of the gathered-row tile
+  float *sA = sC + (CM + 1) * CLDC;                          // [NST][CM][CLDA] compacted gathered rows
+  int *s_src = reinterpret_cast<int *>(sA + NST * CM * CLDA);  // [CKP][CM] input row of the p-th compacted row (padding: row 0)
   int *s_cnt = s_src + CKP * CM;                             // [32] compacted rows per offset of the slice
   unsigned char *s_lrow = reinterpret_cast<unsigned char *>(s_cnt + 32);  // [CKP][CM] tile row of the p-th compacted row
   int *s_orow = reinterpret_cast<int *>(s_lrow + CKP * CM);  // PERM: [CM] output row of a tile row (-1: padding)
@@ -1131,7 +1141,7 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ga[slot][i]) : "v"(src));
       }
     };
-    auto gload_w = [&](int slot) __attribute__((always_inline)) {
+    auto gload_w = [&](int slot, bool advance = true) __attribute__((always_inline)) {
       const int so = g_wo;
       if constexpr (!W_T) {
         if constexpr (PERM) {  // (the compiler does not hold the item's offset in a scalar register there: it goes into the lane offset)
@@ -1159,12 +1169,38 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(gwt[slot][q][h]) : "v"(vo), "s"(rw));
           }
       }
+      if (!advance) return;  // (P3 prologue: the weight loads of the step before the first item exists -- same count, no move)
       if (g_left > 0) {  // uniform
-        --g_left, g_wo += g_wstep, g_xo += 4u * BK;
+        --g_left, g_wo += g_wstep;
+        if constexpr (!P3) g_xo += 4u * BK;
         if (++g_cc == ncc) {
           g_cc = 0, ++g_ka;
-          g_wo = wbase_of(g_ka), g_xo = 4u * (unsigned)(cbeg * BK);
-          if constexpr (CPF) load_src();  // (used by the NEXT step's gload_a: the read has the barrier wait to arrive)
+          g_wo = wbase_of(g_ka);
+          if constexpr (!P3) {
+            g_xo = 4u * (unsigned)(cbeg * BK);
+            if constexpr (CPF) load_src();  // (used by the NEXT step's gload_a: the read has the barrier wait to arrive)
+          }
+        }
+      }
+    };
+    // P3: the gather stage has an iterator of its own (it runs one item further ahead than the weight stage)
+    static_assert(!P3 || CPF, "the three-stage form gathers through the per-offset lane offsets");
+    int r_ka = 0, r_cc = 0, r_left = n_items - 1;
+    unsigned r_xo = 4u * (unsigned)(cbeg * BK);
+    auto load_src3 = [&]() __attribute__((always_inline)) {
+      const int j = nib(act_lo, act_hi, r_ka);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) sv[i] = (unsigned)s_src[j * CM + a_r + ARP * i] * (4u * (unsigned)p.ldx) + 16u * (unsigned)a_cc;
+    };
+    auto gload_a3 = [&](int slot) __attribute__((always_inline)) {
+      const unsigned long long xb = (unsigned long long)p.x + r_xo;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ga[slot][i]) : "v"(sv[i]), "s"(xb));
+      if (r_left > 0) {  // uniform; past the end the last item is re-read
+        --r_left, r_xo += 4u * BK;
+        if (++r_cc == ncc) {
+          r_cc = 0, ++r_ka, r_xo = 4u * (unsigned)(cbeg * BK);
+          load_src3();  // (used by the NEXT step's gather request)
         }
       }
     };
@@ -1214,6 +1250,27 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
     // every load the COMPILER tracks (table entries, row permutation) is complete before the ring starts: a pending score
     // on a register the ring re-uses would make it insert s_waitcnt vmcnt(0) at the loop header -- a full drain every pass
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    float4 u[P3 ? 2 : 1][NBLK][2];  // MFMA operands of an item (P3: of the item being multiplied and of the next one)
+    auto xr_at = [&](const float *a, int blk, int half) __attribute__((always_inline)) {
+      return *reinterpret_cast<const float4 *>(a + blk * 16 * CLDA + (half ? r_sw1 : r_sw0));
+    };
+    if constexpr (P3) {
+      if (n_items > 0) {  // uniform
+        // the steps "before the first": every step issues [rows of item s + 4][weights of item s + 3] -- the same NA + NW loads in the
+        // same order as a real one, so the hand-counted waits hold from the first real step on (weights of item -1: item 0's again)
+        load_src3();
+        gload_a3(0), gload_w(2, false);                  // s = -4
+        gload_a3(1), gload_w(0);                         // s = -3
+        wait_rows(0), sts(0, 0), gload_a3(2), gload_w(1);  // s = -2: item 0 -> stage 0
+        wait_rows(1), sts(1, 1), gload_a3(0), gload_w(2);  // s = -1: item 1 -> stage 1
+      }
+      MINK_LDS_BARRIER();
+      if (n_items > 0) {
+        const float *a0 = sA + n * CLDA;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) u[0][b][0] = xr_at(a0, b, 0), u[0][b][1] = xr_at(a0, b, 1);
+      }
+    } else {
     if (n_items > 0) {  // uniform
       if constexpr (CPF) load_src();
       gload_a(0), gload_w(0), gload_a(1), gload_w(1), gload_a(2), gload_w(2);
@@ -1222,6 +1279,7 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
       sts(0, 0);
     }
     MINK_LDS_BARRIER();
+    }
     // CCIN: float index (row * CLDC) of the tile row behind each block of the offset being multiplied, for this lane's n
     int crow[NBLK];
     auto crows = [&](int j) __attribute__((always_inline)) {
@@ -1256,18 +1314,33 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
     }
     int ka = 0, cc = 0;
     int c_j = nib(act_lo, act_hi, 0), c_nb = nib(nbs_lo, nbs_hi, 0);  // rulebook slot and block count of the offset being multiplied
-    auto step = [&](int it, auto slot_c, auto nslot_c) __attribute__((always_inline)) {
+    auto step = [&](int it, auto slot_c, auto nslot_c, auto par_c) __attribute__((always_inline)) {
       constexpr int slot = decltype(slot_c)::value;
       const int j = c_j, nb = c_nb;  // nb >= 1
       constexpr int nslot = decltype(nslot_c)::value;
+      constexpr int par = P3 ? decltype(par_c)::value : 0;
+      if constexpr (P3) {
+        // ring slot / LDS stage of item i: i % 3.  Item it + 2 has arrived: into its stage (free since the barrier of step it - 2,
+        // behind which nobody reads item it - 1 any more); item it + 4 is requested into the registers of item it + 1 (stored
+        // at step it - 1); the operands of item it + 1 (published by the barrier of step it - 1) go into the other register set
+        constexpr int s2 = (slot + 2) % 3;
+        wait_rows(s2);
+        sts(s2, s2);
+        gload_a3(nslot);
+        const float *an = sA + nslot * CM * CLDA + n * CLDA;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) u[par ^ 1][b][0] = xr_at(an, b, 0), u[par ^ 1][b][1] = xr_at(an, b, 1);
+        __builtin_amdgcn_sched_barrier(0);  // (the reads stay in front of the burst: they have its length to arrive)
+      } else {
       wait_rows(nslot);
       sts(nslot, (it + 1) & 1);  // item it + 1 (after the last item: a re-read copy nobody multiplies)
+      }
       const float *a = sA + (it & 1) * CM * CLDA + n * CLDA;
       // item it + CD takes the registers of item it NOW, not after the MFMAs: the compiler's s_waitcnt before the next
       // step's LDS stores is vmcnt(0..9) where the ring would allow 18 (it merges the loop-carried load scores
       // conservatively), so a load issued at the end of a step was waited for a few hundred cycles later; issued here
       // it has this step's MFMAs to arrive
-      gload_a(slot);
+      if constexpr (!P3) gload_a(slot);
       wait_weights(slot);
       auto mfma8 = [&](auto q_c, f32x4 &c, const float4 &u0, const float4 &u1) __attribute__((always_inline)) {
         constexpr int q = decltype(q_c)::value;  // strip of this wave
@@ -1293,21 +1366,22 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 6>{}), u1.z, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf(integral_constant<int, 7>{}), u1.w, c, 0, 0, 0);
       };
-      auto xr = [&](int blk, int half) __attribute__((always_inline)) { return *reinterpret_cast<const float4 *>(a + blk * 16 * CLDA + (half ? r_sw1 : r_sw0)); };
+      auto xr = [&](int blk, int half) __attribute__((always_inline)) { return xr_at(a, blk, half); };
       // The operands of every block are read up front (rows past the compacted count hold stale data that is read but
       // never multiplied), then one accumulation chain per block that exists.  Each accumulator is written in ONE
       // place per item: the paired form (two blocks' MFMAs alternating, a single-block tail) made the compiler keep
       // the merged accumulators in other registers and copy them back -- 32 v_mov_b64 per item beside 24 MFMAs, on a
       // part where every vector-ALU instruction is a slot the matrix pipe loses; the 8-cycle gap between dependent
       // 16x16x4 MFMAs of one chain is filled by the other three waves of the SIMD.
-      float4 u[NBLK][2];
+      if constexpr (!P3) {
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) u[b][0] = xr((abl & 128) ? 0 : b, 0), u[b][1] = xr((abl & 128) ? 0 : b, 1);  // (bit 7, timing only: one block's operands)
+        for (int b = 0; b < NBLK; ++b) u[0][b][0] = xr((abl & 128) ? 0 : b, 0), u[0][b][1] = xr((abl & 128) ? 0 : b, 1);  // (bit 7, timing only: one block's operands)
+      }
 #pragma unroll
       for (int b = 0; b < NBLK; ++b)
         if ((b == 0 || b < nb) && !(abl & 32)) {  // uniform; an item has at least one block (bit 5, timing only: no matrix work)
-          mfma8(std::integral_constant<int, 0>{}, acc[0][b], u[b][0], u[b][1]);
-          if constexpr (SPW > 1) mfma8(std::integral_constant<int, 1>{}, acc[SPW - 1][b], u[b][0], u[b][1]);
+          mfma8(std::integral_constant<int, 0>{}, acc[0][b], u[par][b][0], u[par][b][1]);
+          if constexpr (SPW > 1) mfma8(std::integral_constant<int, 1>{}, acc[SPW - 1][b], u[par][b][0], u[par][b][1]);
         }
       if (++cc == ncc) {  // the offset is complete: add the blocks into the tile rows they belong to (padding -> row CM)
         cc = 0, ++ka;
@@ -1357,10 +1431,21 @@ __global__ __launch_bounds__(64 * NWV, CM == 64 ? NWV : NWV / 2) void compact_ge
       gload_w(slot);
       MINK_LDS_BARRIER();
     };
-    for (int base = 0; base < n_items; base += CD) {
-      step(base, S0{}, S1{});
-      if (base + 1 < n_items) step(base + 1, S1{}, S2{});
-      if (base + 2 < n_items) step(base + 2, S2{}, S0{});
+    if constexpr (P3) {  // (ring slot = item % 3, operand set = item % 2: six step bodies)
+      for (int base = 0; base < n_items; base += 6) {
+        step(base, S0{}, S1{}, S0{});
+        if (base + 1 < n_items) step(base + 1, S1{}, S2{}, S1{});
+        if (base + 2 < n_items) step(base + 2, S2{}, S0{}, S0{});
+        if (base + 3 < n_items) step(base + 3, S0{}, S1{}, S1{});
+        if (base + 4 < n_items) step(base + 4, S1{}, S2{}, S0{});
+        if (base + 5 < n_items) step(base + 5, S2{}, S0{}, S1{});
+      }
+    } else {
+      for (int base = 0; base < n_items; base += CD) {
+        step(base, S0{}, S1{}, S0{});
+        if (base + 1 < n_items) step(base + 1, S1{}, S2{}, S0{});
+        if (base + 2 < n_items) step(base + 2, S2{}, S0{}, S0{});
+      }
     }
     if (n_items > 0) drain(0), drain(1), drain(2);  // (uniform) the ring's last re-read loads
     if (!PERM) break;
@@ -2578,6 +2663,16 @@ struct ScopedTimer {  // records an event pair around the launches of one convol
 
 static int g_stagger = 0;
 static int g_flat = 1;
+template <bool W_T, bool PERM, int MATH>
+static int launch_compact_p3(const GemmParams &p, dim3 grid, hipStream_t st) {
+  constexpr int smem = compact_smem(64, true);
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<W_T, 64, PERM, false, 4, MATH, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
+  MINK_REQUIRE(ok, "gather_gemm: %d bytes of LDS per workgroup refused", smem);
+  compact_gemm_kernel<W_T, 64, PERM, false, 4, MATH, true><<<grid, 256, smem, st>>>(p);
+  return MINK_OK;
+}
+
 static int g_math = 0;  // 0 fp32, 1 bf16 MFMA, 3 split-bf16
 static int g_wgrad_bf16 = 1;  // bf16 math: stem weight gradient on the bf16 MFMA too (set_stagger bit 28 switches it off: A/B tests)
 static int g_wgrad_bf16_off = 0;
@@ -2586,6 +2681,7 @@ static int g_compact = 1;  // fp32 mid layers on compact_gemm_kernel (set_stagge
 static int g_compact_perm16 = 1;  // --math bf16: the class-permuted data gradients on compact_gemm_kernel<.., MATH = 1> (set_stagger bit 27 = off: the dense bf16 kernel, A/B)
 static int g_compact_cin32 = 0;  // set_stagger bit 8 (measurement only, scripts/kbench.py stemc): the class-permuted form also takes cin = 32
 static int g_compact_perm = 1;  // ... and the class-permuted strided data gradients (bit 31)
+static int g_compact_p3 = 0;    // mink_conv_set_pipeline: the three-stage form of compact_gemm_kernel (1: stride-1 layers, 2: class-permuted too, 3: both)
 static int g_wgrad_xcd = 1;  // streaming wgrad: groups of a row split share an XCD (stream_slot; bit 29: plain order)
 
 extern "C" {
@@ -2603,6 +2699,12 @@ int mink_conv_set_stagger(int units) {
   g_compact = !((units >> 30) & 1);      // bit 30: mid layers back on gather_gemm2_kernel (A/B)
   g_compact_perm = !(((unsigned)units >> 31) & 1u);  // bit 31: class-permuted strided data gradients back on gather_gemm2_kernel (A/B)
   g_wgrad_force = (units >> 12) & 0x7FFF;  // bits 12-15: force G (1, 3, 9), bits 16-26: force the row split count
+  return old;
+}
+
+int mink_conv_set_pipeline(int mode) {
+  const int old = g_compact_p3;
+  if (mode >= 0 && mode <= 7) g_compact_p3 = mode;  // (bit 2, measurement only: the two-stage form with the LDS footprint -- hence the occupancy -- of the three-stage one)
   return old;
 }
 
@@ -2802,7 +2904,10 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
     const int zc = (int)cdiv(ncc, p.kper);
     dim3 cgrid((unsigned)cdiv(n_virtual, CMT), grid.y, (unsigned)zc);
     compact_swizzle(p, cgrid, cin, cout, K);
-    if (w_transposed && (g_stagger & 0xFC)) {  // timing-only switches (kbench cabp): the instantiation that carries them
+    if (w_transposed && (g_compact_p3 & 2) && !(g_stagger & 0xFC)) {
+      const int rc = g_math == 1 ? launch_compact_p3<true, true, 1>(p, cgrid, st) : launch_compact_p3<true, true, 0>(p, cgrid, st);
+      if (rc) return rc;
+    } else if (w_transposed && (g_stagger & 0xFC)) {  // timing-only switches (kbench cabp): the instantiation that carries them
       static const bool abl_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<true, CMT, true, true>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
       MINK_REQUIRE(abl_ok, "gather_gemm: %d bytes of LDS per workgroup refused", smem);
@@ -2843,7 +2948,18 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
     dim3 cgrid((unsigned)cdiv(n_out, CMT), grid.y, grid.z);
     tiles_x = cgrid.x;
     compact_swizzle(p, cgrid, cin, cout, K);
-    if (w_transposed) compact_gemm_kernel<true, CMT><<<cgrid, 256, smem, st>>>(p);
+    if (g_compact_p3 & 4) {  // (measurement only: two stages at three workgroups per CU)
+      constexpr int smem3 = compact_smem(CMT, true);
+      static const bool ok3 = hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<false, CMT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem3) == hipSuccess &&
+                              hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<true, CMT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem3) == hipSuccess;
+      MINK_REQUIRE(ok3, "gather_gemm: %d bytes of LDS per workgroup refused", smem3);
+      if (w_transposed) compact_gemm_kernel<true, CMT><<<cgrid, 256, smem3, st>>>(p);
+      else compact_gemm_kernel<false, CMT><<<cgrid, 256, smem3, st>>>(p);
+    } else
+    if ((g_compact_p3 & 1) && !(g_stagger & 0xFC)) {
+      const int rc = w_transposed ? launch_compact_p3<true, false, 0>(p, cgrid, st) : launch_compact_p3<false, false, 0>(p, cgrid, st);
+      if (rc) return rc;
+    } else if (w_transposed) compact_gemm_kernel<true, CMT><<<cgrid, 256, smem, st>>>(p);
     else if (g_stagger & 0xFC) {  // timing-only switches (kbench cab): the instantiation that carries them
       static const bool abl_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<false, CMT, false, true>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;

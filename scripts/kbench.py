@@ -324,6 +324,38 @@ if which == "perm":  # data gradient of the strided convolutions: row-compacted 
         Fn._PLAN_CACHE.clear()
         print("   max |compact - dense|", float((outs[0] - outs[1]).abs().max()), "max |dense|", float(outs[1].abs().max()),
               "bitwise repeatable:", bool(torch.equal(outs[0], outs[2])))
+if which == "p3":  # round 6: the three-stage form of compact_gemm_kernel (mink_conv_set_pipeline) against the two-stage one, bit for bit
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    tot = {0: 0.0, 3: 0.0, 4: 0.0}
+    for ts in (2, 4, 8, 16):
+        cin, cout = chans[ts], chans[ts * 2]
+        nbr1, nbr1_t = m.kernel_table(keys[ts], keys[ts * 2], 3, 1, transposed=True)
+        nbr2, _ = m.kernel_table(keys[ts * 2], keys[ts * 2], 3, 1)
+        perm = m.class_perm(keys[ts])
+        w1 = torch.randn(27, cin, cout, device=dev) * 0.05
+        w2 = torch.randn(27, cout, cout, device=dev) * 0.05
+        x2 = torch.randn(nbr2.shape[0], cout, device=dev)
+        gy = torch.randn(nbr2.shape[0], cout, device=dev)
+        cases = [
+            (f"l@{ts*2}.c2 fwd        rows={nbr2.shape[0]:6d} {cout}->{cout}", lambda: Fn.gather_gemm(x2, w2, nbr2, cout)),
+            (f"l@{ts*2}.c2 dgrad      rows={nbr2.shape[0]:6d} {cout}->{cout}", lambda: Fn.gather_gemm(gy, w2, nbr2, cout, w_transposed=True, flip_k=True)),
+            (f"l@{ts}.c1 dgrad(perm) rows={nbr1_t.shape[0]:6d} {cout}->{cin}", lambda: Fn.gather_gemm(gy, w1, nbr1_t, cin, w_transposed=True, row_perm=perm)),
+        ]
+        for name, fn in cases:
+            tt, out = {}, {}
+            for mode in (0, 3, 4, 0, 3, 4):  # (4: the two-stage form held to three workgroups per CU -- occupancy alone)
+                lib().mink_conv_set_pipeline(mode)
+                t = timeit(fn, reps) * 1e3
+                tt[mode] = min(tt.get(mode, 1e9), t)
+                out[mode] = fn()
+            lib().mink_conv_set_pipeline(0)
+            tot[0] += tt[0]; tot[3] += tt[3]; tot[4] += tt[4]
+            print(f"{name}: two-stage {tt[0]:7.1f} us, three-stage {tt[3]:7.1f} us ({(tt[3] / tt[0] - 1) * 100:+5.1f} %), two-stage at 3 WG/CU {tt[4]:7.1f} us, bitwise equal: {bool(torch.equal(out[0], out[3]))}")
+    print(f"sum: two-stage {tot[0]:.1f} us, three-stage {tot[3]:.1f} us, two-stage at three workgroups per CU {tot[4]:.1f} us")
 if which in ("stem", "all"):
     bench_layer("stem", x.F.contiguous(), k1, k1, 3, 28, 64, 1)
 if which in ("l1", "l4", "all"):

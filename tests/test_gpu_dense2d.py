@@ -76,6 +76,24 @@ def test_dense_maxpool_and_batchnorm_match_torch():
     assert torch.allclose(bn.running_var.cpu(), bnr.running_var, atol=1e-5) and int(bn.num_batches_tracked) == 1
 
 
+# ReLU branch decisions imposed on the plain-torch network (None: it decides itself): a list of boolean masks in rows layout
+# [B * H * W, C], consumed in call order -- the order of the HIP network's relu=True batch norms (stem, then norm1 / norm2 of every
+# block).  _RELU_FLIPS collects (elements decided differently, their largest |z| / sd(z)) per call.
+_RELU_MASKS, _RELU_FLIPS = None, []
+
+
+def _relu(z):
+    if _RELU_MASKS is None:
+        return torch.relu(z)
+    m = _RELU_MASKS.pop(0)
+    B, C, H, W = z.shape
+    m = m.view(B, H, W, C).permute(0, 3, 1, 2)
+    diff = (z > 0) != m
+    n = int(diff.sum())
+    _RELU_FLIPS.append((n, float(z.detach()[diff].abs().max() / z.detach().std()) if n else 0.0))
+    return z * m.to(z.dtype)
+
+
 class _TorchBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
@@ -87,7 +105,7 @@ class _TorchBlock(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        return torch.relu(self.bn2(self.conv2(torch.relu(self.bn1(self.conv1(x))))) + idt)
+        return _relu(self.bn2(self.conv2(_relu(self.bn1(self.conv1(x))))) + idt)
 
 
 class _TorchResNet18(nn.Module):
@@ -109,7 +127,7 @@ class _TorchResNet18(nn.Module):
 
     def forward(self, x):
         m = self.model
-        x = F.max_pool2d(torch.relu(m.bn1(m.conv1(x))), 3, 2, 1)
+        x = F.max_pool2d(_relu(m.bn1(m.conv1(x))), 3, 2, 1)
         x = m.layer4(m.layer3(m.layer2(m.layer1(x))))
         return self.fc(self.dropout(x.mean((2, 3))))
 
@@ -154,44 +172,80 @@ def test_resnet18_matches_plain_torch_resnet18():
 def test_resnet18_at_the_baseline_shape_matches_plain_torch():
     """BASELINE config #5 at its OWN shape (reference co3d_2d/train.py:49,95 -- 224 x 224 renders, batch 32 -- and
     co3d_2d/src/model/models.py:9-34): forward + backward of the HIP ResNet18 in fp32 against the plain-torch ResNet18 with the same
-    state dict ON THE SAME CARD (torch's fp32 convolutions, TF32 off): logits within north_star's 1e-3, and the gradient of EVERY
-    parameter tensor in relative L2.  Both sides are fp32 with different summation orders over up to 32 x 112 x 112 = 401 k positions,
-    and a ReLU / max-pool tie broken the other way moves a gradient by one element's share -- so the per-tensor bound is the one the
-    small-shape test above uses (5e-3), with the whole-gradient relative L2 at 2e-3; a dropped tap, a mis-strided window or a wrong
-    shortcut is O(1)."""
+    state dict ON THE SAME CARD: logits within north_star's 1e-3 of torch's fp32 network (TF32 off), and the gradient of EVERY
+    parameter tensor in relative L2 against a FLOAT64 run of the plain-torch network.
+
+    The criterion is the 3-D path's (tests/test_gpu_parity_full.py::_assert_gradients_match_float64).  (1) Among the tens of
+    millions of ReLU inputs of a batch some are zero to rounding, two fp32 implementations take different branches there, and one
+    such element moves a gradient tensor by its share (un-imposed, first measurement of this test: logits 1.2e-6, gradients up to
+    4.4e-3 per tensor): the float64 network runs under the HIP run's branch decisions (every relu=True batch norm's output > 0,
+    captured by forward hooks), and every decision that differs from its own must have |z| <= 1e-4 sd (zero to fp32 rounding).
+    (2) The yardstick has to be float64, not torch's fp32: the stem's weight gradient sums x * dx over 401 k positions whose terms
+    cancel like a random walk, while an error in the batch-norm backward's two MEANS is a constant over those positions and adds up
+    coherently -- a 1e-6 difference between two fp32 batch-norm backwards reads 8e-4 in model.conv1.weight (second measurement:
+    HIP against torch fp32 8.3e-4 on that tensor, every other tensor < 1e-4; the weight-gradient kernels themselves sit 6e-7 from
+    a float64 sum of the same products, scripts/diag_dense_stem_wgrad.py).  Bound: 1e-4 per tensor; torch's own fp32 distance to
+    the float64 run is printed beside HIP's."""
+    import copy
+
+    from nerf_downstream_amd.co3d_2d.src.model import dense
+
+    global _RELU_MASKS
     hip, ref = _pair()
     ref = ref.cuda()
+    ref64 = copy.deepcopy(ref).double()
+    masks, hooks = [], []
+    for mod in hip.modules():
+        if isinstance(mod, dense.BatchNorm2d):
+            hooks.append(mod.register_forward_hook(
+                lambda m_, a_, kw_, out_: masks.append(out_.detach() > 0) if kw_.get("relu") else None, with_kwargs=True))
     old_tf32 = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
     torch.backends.cudnn.allow_tf32 = torch.backends.cuda.matmul.allow_tf32 = False
     try:
         x = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(11)).cuda()
         labels = ((torch.arange(32) * 7 + 3) % 51).cuda()
-        out, outr = hip(x), ref(x)
-        assert out.shape == (32, 51)
-        err = float((out.detach() - outr.detach()).abs().max())
+        out = hip(x)
+        for h in hooks:
+            h.remove()
+        assert out.shape == (32, 51) and len(masks) == 17  # the stem's ReLU + two per block
         F.cross_entropy(out, labels, label_smoothing=0.005).backward()
+        outr = ref(x)  # torch fp32 deciding for itself: the logits
+        err = float((out.detach() - outr.detach()).abs().max())
+        rm0 = ref.model.bn1.running_mean.clone()
         F.cross_entropy(outr, labels, label_smoothing=0.005).backward()
+        _RELU_MASKS, _RELU_FLIPS[:] = list(masks), []
+        out64 = ref64(x.double())
+        assert not _RELU_MASKS
+        F.cross_entropy(out64, labels, label_smoothing=0.005).backward()
         torch.cuda.synchronize()
     finally:
+        _RELU_MASKS = None
         torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = old_tf32
-    print(f"[co3d_2d ResNet18 224^2 B=32 fp32] max |logit error| vs torch on the card {err:.3e}")
+    nflip, zmax = sum(f[0] for f in _RELU_FLIPS), max(f[1] for f in _RELU_FLIPS)
+    print(f"[co3d_2d ResNet18 224^2 B=32 fp32] max |logit error| vs torch fp32 on the card {err:.3e}, vs the float64 network "
+          f"{float((out.detach().double() - out64.detach()).abs().max()):.3e}; ReLU branches of the HIP run that differ from the float64 "
+          f"run's own: {nflip} element(s) in {sum(1 for f in _RELU_FLIPS if f[0])} of 17 layers, largest |z|/sd there {zmax:.1e}")
     assert err < 1e-3, err
-    hp, rp = dict(hip.named_parameters()), dict(ref.named_parameters())
-    assert hp.keys() == rp.keys()
-    worst, bad = ("", 0.0), []
-    for k in rp:
-        rel = float((hp[k].grad.double() - rp[k].grad.double()).norm() / rp[k].grad.double().norm().clamp_min(1e-300))
-        if rel > worst[1]:
-            worst = (k, rel)
-        if not rel < 5e-3:
-            bad.append((k, rel))
-    g = torch.cat([hp[k].grad.double().flatten() for k in rp])
-    og = torch.cat([rp[k].grad.double().flatten() for k in rp])
+    assert zmax <= 1e-4, _RELU_FLIPS
+    assert float((out.detach().double() - out64.detach()).abs().max()) < 1e-3
+    hp, rp, r64 = dict(hip.named_parameters()), dict(ref.named_parameters()), dict(ref64.named_parameters())
+    assert hp.keys() == rp.keys() == r64.keys()
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm().clamp_min(1e-300))  # noqa: E731
+    worst, worst_t, bad = ("", 0.0), ("", 0.0), []
+    for k in r64:
+        e, et = rel(hp[k].grad, r64[k].grad), rel(rp[k].grad, r64[k].grad)
+        worst = (k, e) if e > worst[1] else worst
+        worst_t = (k, et) if et > worst_t[1] else worst_t
+        if not e < 1e-4:
+            bad.append((k, e))
+    g = torch.cat([hp[k].grad.double().flatten() for k in r64])
+    og = torch.cat([r64[k].grad.flatten() for k in r64])
     tot = float((g - og).norm() / og.norm())
-    print(f"[co3d_2d ResNet18 224^2 B=32 fp32] {len(rp)} parameter tensors: worst relative L2 {worst[1]:.2e} ({worst[0]}), all parameters {tot:.2e}")
+    print(f"[co3d_2d ResNet18 224^2 B=32 fp32] {len(r64)} parameter tensors against the float64 network under the HIP run's ReLU branches: "
+          f"worst relative L2 {worst[1]:.2e} ({worst[0]}), all parameters {tot:.2e}; torch fp32 (its own branches) against the same: worst "
+          f"{worst_t[1]:.2e} ({worst_t[0]})")
     assert not bad, bad
-    assert tot < 2e-3, tot
-    assert torch.allclose(hip.model.bn1.running_mean, ref.model.bn1.running_mean, atol=1e-5)
+    assert torch.allclose(hip.model.bn1.running_mean, rm0, atol=1e-5)
 
 
 def test_resnet18_bf16_matrix_cores_and_eval_mode():

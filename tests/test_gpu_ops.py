@@ -816,6 +816,63 @@ def test_permuted_rows_kernel_on_the_bf16_matrix_cores(n_out, K, cin, cout, pure
         ME.set_conv_math(old)
 
 
+@pytest.mark.parametrize("n_out,K,cin,cout,perm_rows", [(130, 27, 64, 64, False), (1000, 27, 128, 128, False), (517, 27, 256, 64, False),
+                                                         (64, 27, 64, 64, False), (700, 27, 128, 64, True), (300, 9, 512, 64, True),
+                                                         (2100, 27, 64, 64, True)])
+def test_three_stage_pipeline_of_the_mid_layer_kernel_is_bitwise_the_two_stage_one(n_out, K, cin, cout, perm_rows):
+    """Round 6's structural variant of compact_gemm_kernel (csrc/conv.hip, template parameter P3; mink_conv_set_pipeline): three LDS
+    stages of the gathered-row tile, the MFMA operands of an item read one step ahead into a second register set, gather stage four
+    and weight stage three items ahead on two iterators, three workgroups per CU.  Same products added in the same order: forward,
+    same-map data gradient (weights read transposed in place, offsets flipped) and the class-permuted strided data gradient must
+    equal the two-stage form BIT FOR BIT, un-split and split, on ragged tables (rows without neighbours, offsets without rows,
+    a tile of exactly 64 rows, item counts that are not multiples of the six unrolled step bodies).  It measured 4-17 % slower
+    (profiles/r06_three_stage_negative.txt) and stays off; this test is what keeps the measurement honest."""
+    from nerf_downstream_amd._lib import lib
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(n_out * 3 + K + cin + cout)
+    n_in = max(4, n_out // 2 + 3)
+    nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
+    nbr[torch.rand(n_out, K, generator=g) < 0.45] = -1
+    nbr[:, K // 2 + 1] = -1  # an offset nobody has
+    nbr[n_out // 3] = -1     # a row without neighbours
+    x = (torch.randn(n_in, cin, generator=g)).to(dev)
+    w = (torch.randn(K, cin, cout, generator=g) * 0.1).to(dev)
+    nd = nbr.to(dev)
+    cases = []
+    if perm_rows:
+        cls = torch.randint(0, 8, (n_out,), generator=g)
+        segs = []
+        for c in range(8):
+            rows = torch.nonzero(cls == c).flatten().to(torch.int32)
+            segs += [rows, torch.full(((-len(rows)) % 128,), -1, dtype=torch.int32)]
+        pd = torch.cat(segs).to(dev)
+        wk = w.transpose(1, 2).contiguous()
+        cases.append(("perm", lambda: Fn.gather_gemm(x, wk, nd, cout, w_transposed=True, row_perm=pd)))
+    else:
+        cases.append(("fwd", lambda: Fn.gather_gemm(x, w, nd, cout)))
+        gy = torch.randn(n_out, cout, generator=g).to(dev)
+        nd2 = torch.randint(0, n_out, (n_out, K), generator=g, dtype=torch.int32)
+        nd2[torch.rand(n_out, K, generator=g) < 0.5] = -1
+        nd2 = nd2.to(dev)
+        cases.append(("dgrad", lambda: Fn.gather_gemm(gy, w, nd2, cin, w_transposed=True, flip_k=True)))
+    L = lib()
+    try:
+        for zs in (0, 1, 3):
+            Fn._FORCE_KSPLIT = zs
+            for name, fn in cases:
+                L.mink_conv_set_pipeline(0)
+                a = fn()
+                L.mink_conv_set_pipeline(3)
+                b = fn()
+                assert torch.equal(a, b), (name, zs, float((a - b).abs().max()))
+                assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+    finally:
+        Fn._FORCE_KSPLIT = 0
+        L.mink_conv_set_pipeline(0)
+
+
 @pytest.mark.parametrize("B,C,ncls,rows", [(16, 512, 51, 33), (3, 2048, 40, 5), (5, 64, 7, 1), (2, 96, 130, 40)])
 def test_classifier_head_matches_torch(B, C, ncls, rows):
     """mink_head_forward/backward (global average pooling + the kernel-volume-1 `final` convolution with bias, reference
