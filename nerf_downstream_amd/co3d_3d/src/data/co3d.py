@@ -32,12 +32,10 @@ assert len(CLASSES) == 51
 _NPY_HEADER = None
 
 
-def _read_npz(path):
-    """{name: array} of a `data.npz`.  The reference writes its scenes with `np.savez` (scripts/preprocess.py:49): STORED zip members,
-    each a .npy file.  `np.load` spends ~1 ms per member parsing the header through `ast.literal_eval` and copies (and CRC-checks)
-    every byte -- 4 ms per scene, 64 ms per batch of 16 in a DataLoader worker, which is the trainer's bound at a 3.4 ms step.
-    Stored members are instead MAPPED where they lie in the file (header parsed with one regular expression, no copy; the bytes are
-    read by whoever concatenates the batch); anything else -- a compressed member, an unusual header -- goes through `np.load`."""
+def npz_members(path):
+    """({name: (byte offset of the array data in `path`, dtype, shape)}, [names that are not plain stored .npy members]).
+    The reference writes its scenes with `np.savez` (scripts/preprocess.py:49): STORED zip members, each a .npy file, so an array
+    can be read -- or mapped -- where it lies in the file; the header is parsed with one regular expression."""
     import re
     import struct
     import zipfile
@@ -71,15 +69,27 @@ def _read_npz(path):
                 slow.append(name)
                 continue
             shape = tuple(int(v) for v in m.group(3).replace(b" ", b"").split(b",") if v)
-            dtype = np.dtype(m.group(1).decode())
-            count = int(np.prod(shape)) if shape else 1
-            if count == 0:
-                out[name] = np.zeros(shape, dtype)
-            elif count * dtype.itemsize < 4096:  # (scalars, the two SH constants: read, not mapped)
-                f.seek(start + skip + hlen)
+            out[name] = (start + skip + hlen, np.dtype(m.group(1).decode()), shape)
+    return out, slow
+
+
+def _read_npz(path):
+    """{name: array} of a `data.npz`.  `np.load` spends ~1 ms per member parsing the header through `ast.literal_eval` and copies
+    (and CRC-checks) every byte -- 4 ms per scene, 64 ms per batch of 16 in a DataLoader worker, which is the trainer's bound at a
+    3.4 ms step.  Stored members are instead MAPPED where they lie in the file (`npz_members`; no copy: the bytes are read by whoever
+    concatenates the batch); anything else -- a compressed member, an unusual header -- goes through `np.load`."""
+    members, slow = npz_members(path)
+    out = {}
+    for name, (off, dtype, shape) in members.items():
+        count = int(np.prod(shape)) if shape else 1
+        if count == 0:
+            out[name] = np.zeros(shape, dtype)
+        elif count * dtype.itemsize < 4096:  # (scalars, the two SH constants: read, not mapped)
+            with open(path, "rb") as f:
+                f.seek(off)
                 out[name] = np.frombuffer(f.read(count * dtype.itemsize), dtype=dtype).reshape(shape).copy()
-            else:
-                out[name] = np.memmap(path, dtype=dtype, mode="c", offset=start + skip + hlen, shape=shape)  # (copy-on-write: private, never written back)
+        else:
+            out[name] = np.memmap(path, dtype=dtype, mode="c", offset=off, shape=shape)  # (copy-on-write: private, never written back)
     if slow:
         z = np.load(path)
         for name in slow:
@@ -153,7 +163,7 @@ class Co3DDatasetBase(Dataset):
         links, density, sh_q, scale, mn, reso = self._load_raw(inst_id)
         bc = lambda a: np.broadcast_to(np.asarray(a, np.float32).reshape(-1), (27,)).copy()  # noqa: E731
         return {"links": torch.from_numpy(links), "density": torch.from_numpy(density),
-                "sh_q": torch.from_numpy(sh_q.reshape(len(links), -1)), "sh_scale": torch.from_numpy(bc(scale)),
+                "sh_q": torch.from_numpy(sh_q.reshape(len(links), sh_q.size // len(links) if len(links) else 27)), "sh_scale": torch.from_numpy(bc(scale)),
                 "sh_min": torch.from_numpy(bc(mn)), "reso": tuple(reso)}
 
     def __getitem__(self, index):

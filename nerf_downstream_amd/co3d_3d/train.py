@@ -256,7 +256,7 @@ def train(
     # (what the reference's Lightning loop does with pin_memory=False).
     stager = None
     if device.type == "cuda" and ME is None and os.environ.get("MINK_STAGING", "1") != "0":
-        from nerf_downstream_amd.co3d_3d.src.data.staging import PinnedStager, StagedLoader
+        from nerf_downstream_amd.co3d_3d.src.data.staging import DirectCompactLoader, PinnedStager, StagedLoader
 
         stager = PinnedStager(device)
     total_steps = max_steps + (warmup_steps if warmup_steps > 0 else 0)
@@ -271,13 +271,29 @@ def train(
         if skip_batches and hasattr(train_loader.sampler, "skip"):  # resumed inside this epoch: drop what was trained on, by index
             train_loader.sampler.skip(skip_batches * train_loader.batch_size)
             batch_in_epoch, skip_batches = skip_batches, 0
-        it = iter(train_loader)
+        direct = (stager is not None and os.environ.get("MINK_DIRECT_LOADER", "1") != "0" and train_loader.sampler is not None
+                  and DirectCompactLoader.usable(train_loader.dataset))
+        if direct:
+            # compact scenes on disk: read straight into the pinned staging buffers by a few threads of this process (data/staging.py)
+            idx = iter(train_loader.sampler)
+            for _ in range(skip_batches * train_loader.batch_size):  # (samplers without skip(): the indices are drawn and dropped)
+                if next(idx, None) is None:
+                    break
+            batch_in_epoch += skip_batches
+            skip_batches = 0
+            next_batch = DirectCompactLoader(train_loader.dataset, idx, train_loader.batch_size, stager,
+                                             threads=max(2, min(8, train_num_workers or 2))).next
+            it = None
+        else:
+            it = iter(train_loader)
         for _ in range(skip_batches):  # (samplers without skip(): the batches are drawn and dropped)
             if next(it, None) is None:
                 break
             batch_in_epoch += 1
         skip_batches = 0
-        if stager is not None:
+        if direct:
+            pass
+        elif stager is not None:
             staged = StagedLoader(it, stager)
             next_batch = staged.next
         else:

@@ -39,6 +39,7 @@ struct GemmParams {
   int accumulate;  // y += result instead of y = result (un-split launches whose rows are visited at most once)
   float *stats;  // optional [row tiles][2][cout]: per-tile column (sum, sum of squares) of y (un-split launches only)
   int swz_x, swz_y, swz_z;  // compact_gemm_kernel: > 0 = XCD-aware one-dimensional launch over (row tiles, column tiles, slices)
+  unsigned long long *trace;  // measurement only (mink_conv_trace; ABL instantiation): [workgroup][5] = clock at start / loop / epilogue / end, HW id
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float *p, int valid, bool vec) {
@@ -941,6 +942,10 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
     else if (pr == 2) __builtin_amdgcn_s_setprio(2);
     else if (pr == 3) __builtin_amdgcn_s_setprio(3);
   }
+  unsigned long long t_start = 0, t_loop = 0, t_epi = 0;
+  if constexpr (ABL) {
+    if (p.trace) t_start = __builtin_readcyclecounter();
+  }
   const int64_t o0 = (int64_t)bx * CM;
   const int n0 = by * BN;
   const int K = p.K;
@@ -1312,6 +1317,9 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
         if (nb0 > 2) cget(S2{}, std::integral_constant<int, 4>{}, nb0);
       }
     }
+    if constexpr (ABL) {
+      if (p.trace && t_loop == 0) t_loop = __builtin_readcyclecounter();
+    }
     int ka = 0, cc = 0;
     int c_j = nib(act_lo, act_hi, 0), c_nb = nib(nbs_lo, nbs_hi, 0);  // rulebook slot and block count of the offset being multiplied
     auto step = [&](int it, auto slot_c, auto nslot_c, auto par_c) __attribute__((always_inline)) {
@@ -1451,6 +1459,9 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
     if (!PERM) break;
   }
 
+  if constexpr (ABL) {
+    if (p.trace) t_epi = __builtin_readcyclecounter();
+  }
   // ---- epilogue: y / slab = C (+ bias), column statistics of the tile for the batch norm that follows
   const bool direct = gz == 1;
   float *dst = direct ? p.y : p.ws + (int64_t)bz * p.n_out * p.cout;
@@ -1482,6 +1493,17 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
       float t = 0.f;
       for (int g = 0; g < RG; ++g) t += red[(g * 2 + which) * BN + c];
       p.stats[((int64_t)bx * 2 + which) * p.cout + n0 + c] = t;
+    }
+  }
+  if constexpr (ABL) {
+    if (p.trace) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tile's stores have left: what the slot waits for before it is handed on)
+      if (tid == 0) {
+        const unsigned long long lin = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z);
+        unsigned long long *t = p.trace + 5 * lin;
+        t[0] = t_start, t[1] = t_loop, t[2] = t_epi, t[3] = __builtin_readcyclecounter();
+        t[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // HW_ID, XCC_ID
+      }
     }
   }
 }
@@ -2681,6 +2703,8 @@ static int g_compact = 1;  // fp32 mid layers on compact_gemm_kernel (set_stagge
 static int g_compact_perm16 = 1;  // --math bf16: the class-permuted data gradients on compact_gemm_kernel<.., MATH = 1> (set_stagger bit 27 = off: the dense bf16 kernel, A/B)
 static int g_compact_cin32 = 0;  // set_stagger bit 8 (measurement only, scripts/kbench.py stemc): the class-permuted form also takes cin = 32
 static int g_compact_perm = 1;  // ... and the class-permuted strided data gradients (bit 31)
+static unsigned long long *g_trace_buf = nullptr;  // mink_conv_trace
+static int64_t g_trace_cap = 0;
 static int g_compact_p3 = 0;    // mink_conv_set_pipeline: the three-stage form of compact_gemm_kernel (1: stride-1 layers, 2: class-permuted too, 3: both)
 static int g_wgrad_xcd = 1;  // streaming wgrad: groups of a row split share an XCD (stream_slot; bit 29: plain order)
 
@@ -2700,6 +2724,11 @@ int mink_conv_set_stagger(int units) {
   g_compact_perm = !(((unsigned)units >> 31) & 1u);  // bit 31: class-permuted strided data gradients back on gather_gemm2_kernel (A/B)
   g_wgrad_force = (units >> 12) & 0x7FFF;  // bits 12-15: force G (1, 3, 9), bits 16-26: force the row split count
   return old;
+}
+
+int mink_conv_trace(void *buf, int64_t capacity_workgroups) {
+  g_trace_buf = (unsigned long long *)buf, g_trace_cap = buf ? capacity_workgroups : 0;
+  return MINK_OK;
 }
 
 int mink_conv_set_pipeline(int mode) {

@@ -362,13 +362,18 @@ def _write_co3d_scenes(root, n_scenes=16):
 @pytest.mark.timeout(120)
 def test_train_on_co3d_format_compact_equals_decoded(tmp_path, monkeypatch):
     """train() on a tiny tree in the reference's on-disk format, DataLoader workers included: the
-    compact path (GPU-side decode) and the ordinary path (CPU decode) give the same loss history."""
+    compact path (GPU-side decode) and the ordinary path (CPU decode) give the same loss history -- and so do the three ways a
+    batch reaches the device (round 6): pageable copies on the compute stream, pinned staging + a copy stream, and the direct
+    reader that fills the pinned buffers from the scene files without a DataLoader."""
     from nerf_downstream_amd.co3d_3d.train import train
 
     _write_co3d_scenes(tmp_path)
     monkeypatch.chdir(tmp_path)
     hist = {}
-    for compact in (False, True):
+    # (compact form, MINK_STAGING, MINK_DIRECT_LOADER): the reference-style loop (pageable copies on the compute stream), the DataLoader
+    # through pinned staging + copy stream, and the direct reader of the scene files into the pinned buffers (data/staging.py)
+    for compact, staging, direct in ((False, "0", "0"), (False, "1", "0"), (True, "1", "0"), (True, "1", "1"), (True, "0", "0")):
+        monkeypatch.setenv("MINK_STAGING", staging), monkeypatch.setenv("MINK_DIRECT_LOADER", direct)
         gin.clear_config()
         gin.parse_config_files_and_bindings(
             [f"{CFG}/co3d_cls.gin", f"{CFG}/resnet14.gin"],
@@ -377,11 +382,12 @@ def test_train_on_co3d_format_compact_equals_decoded(tmp_path, monkeypatch):
              f"Co3DDatasetBase.compact={compact}", "get_model.in_channel=28", "train.batch_size=4", "train.val_batch_size=4",
              "train.lr=0.003", "train.train_num_workers=2", "train.val_num_workers=0"],
         )
-        res = train(save_path=str(tmp_path / f"run{int(compact)}"), resume_training=False, run_name="r", run_name_postfix=None, seed=9)
+        res = train(save_path=str(tmp_path / f"run{int(compact)}{staging}{direct}"), resume_training=False, run_name="r", run_name_postfix=None, seed=9)
         gin.clear_config()
-        hist[compact] = [h["train/loss"] for h in res["history"] if "train/loss" in h]
+        hist[(compact, staging, direct)] = [h["train/loss"] for h in res["history"] if "train/loss" in h]
         assert [h for h in res["history"] if "val/acc1" in h]
-    assert len(hist[True]) == 6 and hist[True] == hist[False]
+    first = hist[(False, "0", "0")]
+    assert len(first) == 6 and all(h == first for h in hist.values()), hist
 
 
 def test_flat_sgd_is_torch_sgd(tmp_path):

@@ -1,0 +1,110 @@
+"""Host side of the trainer's input path (nerf_downstream_amd/co3d_3d/src/data/staging.py, co3d.py) on the CPU: the mapped reader of
+stored npz members against np.load, and the direct reader of compact scenes (scene files -> one staging buffer, no DataLoader) against
+`collate_mink` of the same samples, key by key and byte by byte.  (The pinned / device rings need a GPU: tests/test_gpu_train.py.)"""
+import numpy as np
+import pytest
+import torch
+
+from nerf_downstream_amd.co3d_3d.src.data import staging
+from nerf_downstream_amd.co3d_3d.src.data.co3d import Co3DDataset, _read_npz, npz_members
+from nerf_downstream_amd.co3d_3d.src.data.utils import collate_mink
+
+
+def _write_scenes(root, n_scenes=10, seed=5):
+    rng = np.random.default_rng(seed)
+    (root / "filelist").mkdir(parents=True)
+    lines = []
+    for j in range(n_scenes):
+        n = int(rng.integers(0 if j == 3 else 40, 400)) if j != 3 else 0  # scene 3 is EMPTY
+        links = np.sort(rng.choice(128 ** 3, n, replace=False)).astype(np.int32)
+        d = root / "data" / f"plenoxel_co3d_s{j}"
+        d.mkdir(parents=True)
+        np.savez(d / "data.npz", links=links, density=rng.random((n, 1)).astype(np.float32), sh=rng.integers(0, 256, (n, 27)).astype(np.uint8),
+                 sh_min=np.float32(-1.0 - 0.1 * j), sh_scale=np.float32(0.008 + 0.001 * j))
+        lines.append(f"{('cup', 'apple', 'vase')[j % 3]} s{j}")
+    for phase in ("train", "test"):
+        (root / "filelist" / f"{phase}.txt").write_text("\n".join(lines) + "\n")
+
+
+class _HostStager:
+    """acquire_host / upload of PinnedStager without a GPU: plain host buffers, `upload` returns views of them."""
+
+    def __init__(self):
+        self.bufs = []
+
+    def acquire_host(self, nbytes):
+        self.bufs.append(torch.zeros(max(nbytes, 1), dtype=torch.uint8))
+        return len(self.bufs) - 1, self.bufs[-1]
+
+    def upload(self, packed):
+        buf = self.bufs[packed.slot]
+        out = dict(packed.extras)
+        for k, o, nb, dt, shape in packed.layout:
+            out[k] = buf[o : o + nb].view(dt).view(shape) if nb else torch.empty(shape, dtype=dt)
+        return out
+
+
+def test_mapped_npz_reader_is_np_load(tmp_path):
+    _write_scenes(tmp_path)
+    p = tmp_path / "data" / "plenoxel_co3d_s5" / "data.npz"
+    a, b = _read_npz(str(p)), np.load(p)
+    assert sorted(a) == sorted(b.files)
+    for k in b.files:
+        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+    mem, slow = npz_members(str(p))
+    assert not slow and mem["sh"][1] == np.uint8 and mem["sh"][2] == b["sh"].shape
+    np.savez_compressed(tmp_path / "c.npz", **{k: b[k] for k in b.files})  # a compressed member: the np.load path, same arrays
+    c = _read_npz(str(tmp_path / "c.npz"))
+    assert all(np.array_equal(c[k], b[k]) for k in b.files)
+    assert npz_members(str(tmp_path / "c.npz"))[1]  # (and it says so)
+
+
+@pytest.mark.parametrize("aug", [False, True])
+def test_direct_compact_loader_is_collate_mink(tmp_path, monkeypatch, aug):
+    _write_scenes(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    ds = Co3DDataset("train", data_root=str(tmp_path / "data"), features=("density", "sh"), compact=True,
+                     train_transformations=("RandomRotation", "CoordinateJitter") if aug else ())
+    assert staging.DirectCompactLoader.usable(ds)
+    order = [7, 3, 0, 9, 2, 5, 1, 8, 4, 6]
+    staging.DirectCompactLoader._LAYOUTS.clear()
+    ld = staging.DirectCompactLoader(ds, iter(order), 4, _HostStager(), threads=3, drop_last=False)
+    got = []
+    while True:
+        b = ld.next()
+        if b is None:
+            break
+        got.append(b)
+    assert [int(b["labels"].shape[0]) for b in got] == [4, 4, 2]
+    for bi, b in enumerate(got):
+        want = collate_mink([ds[i] for i in order[4 * bi : 4 * bi + 4]])
+        skip = {"aug_params", "aug_streams", "aug_seed"}  # (random draws: shapes and types below)
+        assert set(b) == set(want), (sorted(b), sorted(want))
+        for k, v in want.items():
+            if k in skip:
+                continue
+            if torch.is_tensor(v):
+                assert b[k].dtype == v.dtype and b[k].shape == v.shape and torch.equal(b[k], v), (bi, k)
+            else:
+                assert tuple(b[k]) == tuple(v) if isinstance(v, (tuple, list)) else b[k] == v, (bi, k)
+        if aug:
+            assert b["aug_params"].shape == want["aug_params"].shape and b["aug_params"].dtype == want["aug_params"].dtype
+            assert b["aug_streams"].shape == want["aug_streams"].shape and b["aug_streams"].dtype == torch.int32
+            assert isinstance(b["aug_seed"], int)
+
+
+def test_direct_loader_declines_what_it_cannot_serve(tmp_path, monkeypatch):
+    _write_scenes(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    plain = Co3DDataset("train", data_root=str(tmp_path / "data"), features=("sh",), compact=False)
+    assert not staging.DirectCompactLoader.usable(plain)
+    filt = Co3DDataset("train", data_root=str(tmp_path / "data"), features=("sh",), compact=True, train_transformations=("DensityBasedSample",))
+    assert not staging.DirectCompactLoader.usable(filt)  # a per-scene row filter needs the density values on the host
+    # a scene whose members are compressed is refused loudly, naming the switch
+    z = np.load(tmp_path / "data" / "plenoxel_co3d_s1" / "data.npz")
+    np.savez_compressed(tmp_path / "data" / "plenoxel_co3d_s1" / "data.npz", **{k: z[k] for k in z.files})
+    ds = Co3DDataset("train", data_root=str(tmp_path / "data"), features=("sh",), compact=True)
+    staging.DirectCompactLoader._LAYOUTS.clear()
+    ld = staging.DirectCompactLoader(ds, iter([0, 1]), 2, _HostStager(), threads=2)
+    with pytest.raises(RuntimeError, match="MINK_DIRECT_LOADER=0"):
+        ld.next()
