@@ -264,6 +264,18 @@ class Job:
             model._side = torch.cuda.current_stream()
         self.state = {"tf": model.process_input(self.batches[0])}
         self.reuse_maps, self.tf_cache = os.environ.get("BENCH_ABLATE_MAPS", "0") == "1", {}
+        # The next batch's maps from a HELPER THREAD (round 6): process_input (pyramid, row-count read-back, tables: 0.7 ms of the
+        # host's 2.1 ms per step, most of it inside native calls and an event wait that release the GIL) runs beside the step's own
+        # queuing instead of in two slices of it.  Same kernels on the same prepare stream.  MEASURED (A/B, one box, two alternations):
+        # fp32 B=16 3.52 / 3.52 ms with the thread against 3.48 / 3.48 without (the build then lands beside the stem's forward),
+        # --math bf16 2.04 / 2.05 against 2.07 / 2.07, Mink-ResNet34 at four scenes 3.91 / 3.88 against 3.92 / 3.89: nothing where the
+        # GPU is the limit, 1 % where the host is -- OFF by default (BENCH_PREPARE_THREAD=1: on).
+        self.prep_pool = None
+        if dev.type == "cuda" and os.environ.get("BENCH_PREPARE_THREAD", "0") != "0" and not self.reuse_maps \
+                and os.environ.get("BENCH_PREPARE_ON_COMPUTE") != "1":
+            from concurrent.futures import ThreadPoolExecutor
+
+            self.prep_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mink-prepare", initializer=torch.cuda.set_device, initargs=(dev,))
 
     def step_body(self, i):
         # software pipeline: the TensorField (+ coordinate/kernel maps, built on a side stream) of
@@ -278,7 +290,10 @@ class Job:
         Fn.log_phase("step_begin", torch.cuda.current_stream())
         Fn.log_phase("pyramid_begin", side)
         nb = (i + 1) % len(batches)
-        if self.reuse_maps and nb in self.tf_cache:  # (timing-only ablation: what a step costs WITHOUT building the next batch's maps)
+        fut = None
+        if self.prep_pool is not None:
+            fut, nxt = self.prep_pool.submit(model.process_input, batches[nb]), None
+        elif self.reuse_maps and nb in self.tf_cache:  # (timing-only ablation: what a step costs WITHOUT building the next batch's maps)
             nxt = None
         else:
             nxt = model.process_input(batches[nb], defer=True)
@@ -291,7 +306,9 @@ class Job:
         loss.backward()
         Fn.log_phase("backward_queued", torch.cuda.current_stream())
         Fn.log_phase("maps_begin", side)
-        if nxt is None:
+        if fut is not None:
+            state["tf"] = fut.result()
+        elif nxt is None:
             state["tf"] = self.tf_cache[nb]
         else:
             state["tf"] = model.finish_input(nxt)

@@ -242,6 +242,12 @@ int mink_conv_set_stagger(int units);
  * tile, MFMA operands read one item ahead; three workgroups per CU), 0 = the two-stage form (four workgroups per CU).  Results are
  * bit-identical either way.  Returns the previous mode. */
 int mink_conv_set_pipeline(int mode);
+
+/* Measurement only: while `buf` (device memory, 5 x uint64 per workgroup, `capacity_workgroups` of them) is set, the mid-layer
+ * forward kernel runs the instantiation that carries the timing switches and every workgroup records the shader clock at its start,
+ * at the head of its item loop, at its epilogue and at its end (stores drained), plus its hardware id (scripts/kbench.py ctrace).
+ * NULL: off. */
+int mink_conv_trace(void *buf, int64_t capacity_workgroups);
 /* Matrix-core arithmetic of mink_conv_gather_gemm (forward / input gradient):
  *   0 = exact fp32 MFMA (default), 1 = bf16 operands with fp32 accumulation (BASELINE config
  *   "bf16 mixed precision"), 3 = split-bf16 (hi/lo, three products; ~1e-5 relative).

@@ -116,6 +116,7 @@ SIGNATURES = {
     ),
     "mink_conv_set_stagger": (ctypes.c_int, [ctypes.c_int]),
     "mink_conv_set_pipeline": (ctypes.c_int, [ctypes.c_int]),
+    "mink_conv_trace": (ctypes.c_int, [_p, _i64]),
     "mink_conv_get_math": (ctypes.c_int, []),
     "mink_conv_set_math": (ctypes.c_int, [ctypes.c_int]),
     "mink_conv_plan_ksplit": (ctypes.c_int, [_i64, _i32, _i32, _i32]),

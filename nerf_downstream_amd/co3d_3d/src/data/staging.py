@@ -36,28 +36,28 @@ class PackedBatch:
 class PinnedStager:
     HOST_KEEP = ("aug_params",)  # tensors that stay on the host (the augmentation kernel uploads its parameter rows itself)
 
-    def __init__(self, device, host_slots=5, device_slots=4):
-        # host_slots: a helper thread that packs `depth` = 2 batches ahead (StagedLoader) touches, at one moment, the buffer it is
-        # filling, two queued ones and the one the trainer thread has taken but not yet queued for upload: four, plus one to spare --
-        # the buffer filled next was handed to `upload` five batches ago, so its `_host_free` event exists.
+    def __init__(self, device, host_slots=6, device_slots=4):
+        import queue
+
         self.device = torch.device(device)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._host = [None] * host_slots        # pinned uint8 buffers
-        self._host_free = [None] * host_slots   # event: the upload that last read the buffer
+        # free pinned buffers, each with the event of the upload that last read it: `acquire_host` BLOCKS until one is back, so a
+        # producer may run as far ahead as it likes (a ring indexed modulo its size was overwritten under a batch the trainer
+        # thread had taken but not yet queued for upload: labels of the wrong batch, found by the first 600-step run)
+        self._host_free = queue.Queue()
+        for i in range(host_slots):
+            self._host_free.put((i, None))
         self._dev = [None] * device_slots       # device uint8 buffers
         self._dev_free = [None] * device_slots  # event on the compute stream: the step that last used the buffer is queued
-        self._h = self._d = 0
-        self._lock = threading.Lock()
+        self._d = 0
 
     # ------------------------------------------------------------------ host side (helper thread)
     def acquire_host(self, nbytes):
-        """(slot, pinned uint8 buffer of at least `nbytes`): the next buffer of the ring, once its last upload has left it."""
-        with self._lock:
-            slot = self._h
-            self._h = (self._h + 1) % len(self._host)
-        ev = self._host_free[slot]
+        """(slot, pinned uint8 buffer of at least `nbytes`): a buffer no upload is reading any more (blocks until there is one)."""
+        slot, ev = self._host_free.get()
         if ev is not None:
-            ev.synchronize()  # (batches old: done long ago)
+            ev.synchronize()
         buf = self._host[slot]
         if buf is None or buf.numel() < nbytes:
             buf = self._host[slot] = torch.empty(_round_up(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8).pin_memory()
@@ -114,7 +114,7 @@ class PinnedStager:
         with torch.cuda.stream(cs):
             dbuf[: packed.nbytes].copy_(self._host[packed.slot][: packed.nbytes], non_blocking=True)
             done = cs.record_event()
-        self._host_free[packed.slot] = done
+        self._host_free.put((packed.slot, done))
         out = dict(packed.extras)
         for k, o, nb, dt, shape in packed.layout:
             out[k] = dbuf[o : o + nb].view(dt).view(shape) if nb else torch.empty(shape, dtype=dt, device=self.device)

@@ -40,6 +40,9 @@ struct GemmParams {
   float *stats;  // optional [row tiles][2][cout]: per-tile column (sum, sum of squares) of y (un-split launches only)
   int swz_x, swz_y, swz_z;  // compact_gemm_kernel: > 0 = XCD-aware one-dimensional launch over (row tiles, column tiles, slices)
   unsigned long long *trace;  // measurement only (mink_conv_trace; ABL instantiation): [workgroup][5] = clock at start / loop / epilogue / end, HW id
+  unsigned sk_q, sk_r;  // compact_gemm_kernel<.., SK>: the F = (row tiles x column tiles) x K offset-tiles of the launch dealt out in runs of
+                        // q = F / G (the first r = F % G workers: q + 1)
+  int sk_X, sk_S;       // ... row tiles; slabs per tile in the workspace (>= the workers that can share a tile)
 };
 
 __device__ __forceinline__ float4 ld4_guard(const float *p, int valid, bool vec) {
@@ -852,7 +855,10 @@ constexpr int CD = 3;                // ring of global-load register sets (an it
 #endif
 constexpr bool CSWZ = MINK_CSWZ, CPF = MINK_CPF, CCIN = MINK_CCIN;
 constexpr int CLDA = CSWZ ? BK : MINK_CLDA;
-constexpr int compact_smem(int CM, bool P3 = false) { return ((CM + 1) * CLDC + (P3 ? 3 : 2) * CM * CLDA + CKP * CM + 32) * 4 + CKP * CM + 4 * CM; }
+constexpr int CKP_SK = 16;           // ... of the stream-K form (a round per segment where the classic rulebook would take two: the act / nbs nibble tables hold 16)
+constexpr int compact_smem(int CM, bool P3 = false, bool SK = false) {
+  return ((CM + 1) * CLDC + (P3 ? 3 : 2) * CM * CLDA + (SK ? CKP_SK : CKP) * CM + 32) * 4 + (SK ? CKP_SK : CKP) * CM + 4 * CM;
+}
 
 // CM: rows per tile.  64: 39 KB of LDS, four workgroups (16 waves) per CU -- the latency of an item's chain (barrier,
 // LDS stores, operand reads, scatter) is hidden by the other workgroups; 128: half the weight traffic.
@@ -889,21 +895,37 @@ constexpr int compact_smem(int CM, bool P3 = false) { return ((CM + 1) * CLDC + 
 // Costs: 8 KB more LDS (45 KB: three workgroups per CU instead of four) and 32 more VGPRs (within the 170 of three waves per SIMD);
 // the gather stage runs four items ahead of the multiplying stage, the weight stage three (two iterators).  Same arithmetic in the
 // same order: bit-identical to the classic form (tests/test_gpu_ops.py).
-template <bool W_T, int CM, bool PERM = false, bool ABL = false, int NWV = 4, int MATH = 0, bool P3 = false>
+// SK (round 6, "stream-K"): what a launch of this kernel loses is not inside the item loop.  A per-workgroup clock trace
+// (mink_conv_trace, scripts/kbench.py ctrace; profiles/r06_workgroup_trace.txt) of l1.conv2 -- 575 row tiles x 3 offset slices =
+// 1,725 workgroups on 1,024 slots -- shows every CU with four resident workgroups for the first 35 % of the launch, 3.7 until
+// 55 %, 2.7 until 80 %, then a tail of 2.5 -> 0: 23 % of the slot time has NO workgroup in it and another 17 % is prologue and
+// epilogue; the matrix pipe's 0.48 is that, not the 0.73 of the loop.  The work of a launch is (tiles) x (K offsets), each
+// offset of a tile costing the same few items -- so here the launch is EXACTLY one resident round (gridDim.x = 4 or 3 workers per
+// CU), and worker w takes the run [F w / G, F (w + 1) / G) of the F = tiles x K offset-tiles in tile-major order: every worker,
+// hence every CU, multiplies the same number of offsets (+-1), starts at time zero and ends with the others.  A run crosses tile
+// boundaries: a worker processes up to three SEGMENTS (tile, offsets k0 .. k1), each with the prologue / rulebook / epilogue of the
+// classic form (offsets of a segment in rounds of CKP, as the class-permuted form does), and writes the segment's partial tile
+// into slab (w - first worker of the tile); the worker that finishes a tile also zeroes the slabs nobody wrote, so the consumers
+// (split-K reduce with statistics, the batch-norm kernels that read slabs) see the fixed slab count they are used to.  Workers are
+// numbered so that the eight XCDs each cover one contiguous eighth of the tiles (column-tile major: a deep layer's XCD reads one
+// column tile's weights).  Deterministic: a tile's slabs are summed in slab order, offsets ascending across them.
+template <bool W_T, int CM, bool PERM = false, bool ABL = false, int NWV = 4, int MATH = 0, bool P3 = false, bool SK = false>
 __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void compact_gemm_kernel(GemmParams p) {
+  static_assert(!SK || (!PERM && !P3 && !ABL && NWV == 4), "stream-K: the stride-1 form");
   const int abl = ABL ? p.stagger : 0;
   constexpr bool CCIN = mink::CCIN && (W_T || !PERM);  // (the forward-layout class-permuted form -- tests only -- has no registers to spare)
   constexpr int T = 64 * NWV, SPW = 4 / NWV;  // threads, column strips per wave
   constexpr int NBLK = CM / 16, NH = CM / 64, NA = CM / (T / 8);
-  constexpr int NU = ((PERM ? 27 : CKP) + NWV - 1) / NWV;  // offsets of the slice a wave looks at (cs, cs + NWV, ...)
+  constexpr int CKR = SK ? CKP_SK : CKP;  // offsets per rulebook round
+  constexpr int NU = ((PERM ? 27 : CKR) + NWV - 1) / NWV;  // offsets of the slice a wave looks at (cs, cs + NWV, ...); SK: of a ROUND
   extern __shared__ __attribute__((aligned(16))) unsigned char c_smem[];
   float *sC = reinterpret_cast<float *>(c_smem);             // [CM + 1][CLDC]; row CM takes the padding lanes
   constexpr int NST = P3 ? 3 : 2;                            // stages of the gathered-row tile
   float *sA = sC + (CM + 1) * CLDC;                          // [NST][CM][CLDA] compacted gathered rows
   int *s_src = reinterpret_cast<int *>(sA + NST * CM * CLDA);  // [CKP][CM] input row of the p-th compacted row (padding: row 0)
-  int *s_cnt = s_src + CKP * CM;                             // [32] compacted rows per offset of the slice
+  int *s_cnt = s_src + CKR * CM;                             // [32] compacted rows per offset of the slice
   unsigned char *s_lrow = reinterpret_cast<unsigned char *>(s_cnt + 32);  // [CKP][CM] tile row of the p-th compacted row
-  int *s_orow = reinterpret_cast<int *>(s_lrow + CKP * CM);  // PERM: [CM] output row of a tile row (-1: padding)
+  int *s_orow = reinterpret_cast<int *>(s_lrow + CKR * CM);  // PERM: [CM] output row of a tile row (-1: padding)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int cs = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = column strip
@@ -946,10 +968,37 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
   if constexpr (ABL) {
     if (p.trace) t_start = __builtin_readcyclecounter();
   }
+  // (every quotient below is uniform but comes out of the vector ALU -- the scalar unit does not divide: readfirstlane puts it
+  //  back where the loop's scalar bookkeeping and the scalar-base loads want it)
+  unsigned sk_f = 0, sk_end = 0, sk_w = 0;
+  if constexpr (SK) {
+    const unsigned G = gridDim.x;
+    sk_w = (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3);  // (G is a multiple of 8: the workers of an XCD are neighbours)
+    sk_f = sk_w * p.sk_q + min(sk_w, p.sk_r), sk_end = sk_f + p.sk_q + (sk_w < p.sk_r ? 1u : 0u);
+    if (sk_f >= sk_end) return;
+  }
+  // SK: one pass per segment of the worker's run (a backward goto that only the SK instantiation contains: a loop statement
+  // around the body cost the other instantiations registers -- the forward-layout class-permuted form went from 125 to 128
+  // VGPRs plus scratch, and its scalar-base loads lost their scalar registers)
+sk_next_segment : {
+  int sk_k0 = 0, sk_nk = 0, sk_slab = 0, sk_zero = 0;
+  if constexpr (SK) {
+    const unsigned Ku = (unsigned)p.K;
+    const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)(sk_f / Ku));
+    sk_k0 = (int)(sk_f - tile * Ku);
+    sk_nk = (int)min(Ku - (unsigned)sk_k0, sk_end - sk_f);
+    by = (unsigned)__builtin_amdgcn_readfirstlane((int)(tile / (unsigned)p.sk_X));
+    bx = tile - by * (unsigned)p.sk_X;
+    // the worker whose run holds the tile's first offset: runs are q + 1 long for the first r workers, q after them
+    const unsigned P = tile * Ku, head = p.sk_r * (p.sk_q + 1u);
+    const unsigned w_first = (unsigned)__builtin_amdgcn_readfirstlane((int)(P < head ? P / (p.sk_q + 1u) : p.sk_r + (P - head) / p.sk_q));
+    sk_slab = (int)(sk_w - w_first);
+    sk_zero = (unsigned)(sk_k0 + sk_nk) == Ku ? p.sk_S - 1 - sk_slab : 0;  // the worker that finishes a tile zeroes the slabs nobody wrote
+  }
   const int64_t o0 = (int64_t)bx * CM;
   const int n0 = by * BN;
   const int K = p.K;
-  const int kbeg = PERM ? 0 : bz * p.kper, nk = PERM ? K : min(K, kbeg + p.kper) - kbeg;
+  const int kbeg = PERM ? 0 : (SK ? sk_k0 : bz * p.kper), nk = PERM ? K : (SK ? sk_nk : min(K, kbeg + p.kper) - kbeg);
   const int rows_here = (int)min((int64_t)CM, (PERM ? p.n_virtual : p.n_out) - o0);
   const int ncc_all = p.cin / BK;
   const int cbeg = PERM ? bz * p.kper : 0;                               // first channel chunk of this slice
@@ -957,7 +1006,7 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
 
   // ---- prologue: table entries of the slice (a wave takes offsets cs, cs + 4, ...; they are requested together,
   // straight from global memory: one round trip), C = 0
-  static_assert(CKP <= 12 && (NWV == 4 || NWV == 2) && CM == 64, "the rulebook's slots and the wave layout");
+  static_assert(CKP <= 12 && CKR <= 16 && (NWV == 4 || NWV == 2) && CM == 64, "the rulebook's slots and the wave layout");
   int orow[NH];
 #pragma unroll
   for (int hh = 0; hh < NH; ++hh) {
@@ -966,12 +1015,14 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
     if (PERM && cs == 0) s_orow[r] = orow[hh];
   }
   int tv[NU][NH];
+  if constexpr (!SK) {  // (SK: a segment has up to K offsets -- its table entries are read round by round, below)
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int jj = cs + NWV * u;
+    for (int u = 0; u < NU; ++u) {
+      const int jj = cs + NWV * u;
 #pragma unroll
-    for (int hh = 0; hh < NH; ++hh)
-      tv[u][hh] = (jj < nk && orow[hh] >= 0) ? p.nbr[(int64_t)orow[hh] * K + kbeg + jj] : -1;
+      for (int hh = 0; hh < NH; ++hh)
+        tv[u][hh] = (jj < nk && orow[hh] >= 0) ? p.nbr[(int64_t)orow[hh] * K + kbeg + jj] : -1;
+    }
   }
   for (int e = tid; e < (CM + 1) * CLDC / 4; e += T) reinterpret_cast<float4 *>(sC)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (PERM) {  // rows per offset first: the live offsets get the rulebook's slots in ascending order
@@ -992,7 +1043,7 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
     for (int j = 0; j < nk; ++j)
       if (__builtin_amdgcn_readfirstlane(s_cnt[j]) > 0) amask |= 1u << j;
   }
-  const int n_live = PERM ? __popc(amask) : 1;
+  const int n_live = PERM ? __popc(amask) : (SK ? nk : 1);  // (SK: the segment's offsets, CKP per round)
 
   // ---- weight fragment of this lane: channels 16 h + 4 kq + s of the chunk, column 16 cs + n; byte offsets inside the
   // chunk are fixed per lane, the chunk's own offset is a scalar
@@ -1040,13 +1091,22 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
   float *myC = sC + 16 * SPW * cs + 4 * kq;  // (strip q: + 16 q)
 
   // PERM: the live offsets CKP at a time (a class-pure tile has at most eight: one round)
-  for (int round0 = 0; round0 < n_live; round0 += CKP) {
+  for (int round0 = 0; round0 < n_live; round0 += CKR) {
+    if constexpr (SK) {  // the round's table entries (holding all K of a segment costs seven registers through the item loop: spills)
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int jj = round0 + cs + NWV * u;
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
+          tv[u][hh] = (jj < nk && cs + NWV * u < CKR && orow[hh] >= 0) ? p.nbr[(int64_t)orow[hh] * K + kbeg + jj] : -1;
+      }
+    }
     // ---- rulebook of the round: wave64 ballot + prefix rank per offset
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const int jj = cs + NWV * u;
-      const int slot = PERM ? __popc(amask & ((1u << jj) - 1u)) - round0 : jj;
-      const bool mine = PERM ? (jj < nk && ((amask >> jj) & 1u) && slot >= 0 && slot < CKP) : jj < nk;
+      const int jj = (SK ? round0 : 0) + cs + NWV * u;
+      const int slot = PERM ? __popc(amask & ((1u << jj) - 1u)) - round0 : (SK ? jj - round0 : jj);
+      const bool mine = PERM ? (jj < nk && ((amask >> jj) & 1u) && slot >= 0 && slot < CKP) : (SK ? (jj < nk && slot >= 0 && slot < CKR) : jj < nk);
       if (mine) {  // uniform
         int cnt = 0;
 #pragma unroll
@@ -1086,19 +1146,23 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
         ++na;
       }
     } else {
-      for (int j = 0; j < nk; ++j) {
+      const int j0 = SK ? round0 : 0, j1 = SK ? min(nk, round0 + CKR) : nk;  // (SK: entry = rulebook slot j - round0)
+      for (int j = j0; j < j1; ++j) {
         const int cnt = __builtin_amdgcn_readfirstlane(s_cnt[j]);
         if (cnt > 0) {
           const unsigned nbj = (unsigned)((cnt + 15) >> 4);
-          if (na < 8) act_lo |= (unsigned)j << (4 * na), nbs_lo |= nbj << (4 * na);
-          else act_hi |= (unsigned)j << (4 * (na - 8)), nbs_hi |= nbj << (4 * (na - 8));
+          if (na < 8) act_lo |= (unsigned)(j - j0) << (4 * na), nbs_lo |= nbj << (4 * na);
+          else act_hi |= (unsigned)(j - j0) << (4 * (na - 8)), nbs_hi |= nbj << (4 * (na - 8));
           ++na;
         }
       }
     }
     auto nib = [](unsigned lo, unsigned hi, int a) { return (int)(((a < 8 ? lo : hi) >> (4 * (a & 7))) & 15u); };
+    // (a const copy: naming the round loop's own variable inside the lambdas below took it -- and with it the whole scalar bookkeeping
+    //  of the item loop -- out of registers in the class-permuted instantiations, which do not even use it)
+    const int kbeg0 = kbeg + (SK ? round0 : 0);  // kernel offset of rulebook slot 0 of this round (stride-1 forms)
     auto kof = [&](int a, int j) {  // kernel offset of entry a (rulebook slot j)
-      if (!PERM) return kbeg + j;
+      if constexpr (!PERM) return kbeg0 + j;
       const unsigned w_ = a < 4 ? kl0 : a < 8 ? kl1 : kl2;
       return (int)((w_ >> (8 * (a & 3))) & 255u);
     };
@@ -1133,7 +1197,12 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
     };
     auto gload_a = [&](int slot) __attribute__((always_inline)) {
       if constexpr (CPF) {
-        const unsigned long long xb = (unsigned long long)p.x + g_xo;
+        unsigned long long xb = (unsigned long long)p.x + g_xo;
+        if constexpr (PERM && !W_T) {
+          // (the forward-layout class-permuted form -- tests only -- sits at the register limit, and the allocator has been seen to
+          //  leave this uniform base in vector registers, which the "s" operand cannot take: put it back explicitly)
+          xb = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ga[slot][i]) : "v"(sv[i]), "s"(xb));
         return;
@@ -1456,15 +1525,15 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
       }
     }
     if (n_items > 0) drain(0), drain(1), drain(2);  // (uniform) the ring's last re-read loads
-    if (!PERM) break;
+    if (!PERM && !SK) break;
   }
 
   if constexpr (ABL) {
     if (p.trace) t_epi = __builtin_readcyclecounter();
   }
   // ---- epilogue: y / slab = C (+ bias), column statistics of the tile for the batch norm that follows
-  const bool direct = gz == 1;
-  float *dst = direct ? p.y : p.ws + (int64_t)bz * p.n_out * p.cout;
+  const bool direct = !SK && gz == 1;
+  float *dst = direct ? p.y : p.ws + (int64_t)(SK ? sk_slab : (int)bz) * p.n_out * p.cout;
   const int ldd = direct ? p.ldy : p.cout;
   const int c4 = tid & 15, rg = tid >> 4;
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1495,6 +1564,22 @@ __global__ __launch_bounds__(64 * NWV, P3 ? 3 : (CM == 64 ? NWV : NWV / 2)) void
       p.stats[((int64_t)bx * 2 + which) * p.cout + n0 + c] = t;
     }
   }
+  if constexpr (SK) {
+    for (int zsl = 1; zsl <= sk_zero; ++zsl) {  // (uniform) slabs of this tile that no worker wrote: zeros for the consumers
+      float *dz = p.ws + (int64_t)(sk_slab + zsl) * p.n_out * p.cout;
+#pragma unroll
+      for (int jr = 0; jr < CM / RG; ++jr) {
+        const int r = rg + RG * jr;
+        if (r < rows_here) *reinterpret_cast<float4 *>(&dz[(o0 + r) * p.cout + n0 + 4 * c4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    sk_f += sk_nk;
+    if (sk_f < sk_end) {  // uniform
+      __syncthreads();  // (the next segment zeroes the C tile this epilogue read)
+      goto sk_next_segment;
+    }
+  }
+  }  // segment
   if constexpr (ABL) {
     if (p.trace) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tile's stores have left: what the slot waits for before it is handed on)
@@ -2685,6 +2770,37 @@ struct ScopedTimer {  // records an event pair around the launches of one convol
 
 static int g_stagger = 0;
 static int g_flat = 1;
+// Stream-K plan of a stride-1 mid-layer launch: (workers G, slabs S) or G = 0 when the shape does not take it.  G is one resident
+// round (4 or 3 workgroups on each of the 256 CUs; a multiple of 8 for the XCD numbering); a worker's run is at least F / G
+// offset-tiles long, so at most ceil(K / floor(F / G)) + 1 workers share a tile -- the slab count.  The largest G whose slab
+// count stays within the budget (15 slabs, the 128 MB the slabs may take) wins.
+struct SkPlan {
+  int G, S;
+};
+static SkPlan sk_plan(int64_t n_rows, int K, int cout) {
+  const int64_t F = cdiv(n_rows, 64) * cdiv(cout, BN) * K;
+  const int64_t slab_cap = std::max<int64_t>(1, (128ll << 20) / (4 * n_rows * cout));
+  // (measured, scripts/kbench.py sk: runs of 15 and 6 offsets -- layers 1 and 2 of the B=16 batch -- gain; runs of 3 -- layer 3, ten
+  //  slabs -- do not, and layer 4, where only three workers per CU keep the slab count at 15, loses 25-29 % to the (tile, slice) grid
+  //  of 896 workgroups: a run has to be at least five offsets long, in one resident round of four workers per CU)
+  const int G = 1024;
+  const int64_t run = F / G;
+  if (run < 5) return {0, 0};
+  const int64_t S = cdiv(K, run) + 1;
+  if (S <= slab_cap) return {G, (int)S};
+  return {0, 0};
+}
+
+template <bool W_T>
+static int launch_compact_sk(const GemmParams &p, int G, hipStream_t st) {
+  constexpr int smem = compact_smem(64, false, true);
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<W_T, 64, false, false, 4, 0, false, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
+  MINK_REQUIRE(ok, "gather_gemm: %d bytes of LDS per workgroup refused", smem);
+  compact_gemm_kernel<W_T, 64, false, false, 4, 0, false, true><<<dim3((unsigned)G), 256, smem, st>>>(p);
+  return MINK_OK;
+}
+
 template <bool W_T, bool PERM, int MATH>
 static int launch_compact_p3(const GemmParams &p, dim3 grid, hipStream_t st) {
   constexpr int smem = compact_smem(64, true);
@@ -2733,7 +2849,7 @@ int mink_conv_trace(void *buf, int64_t capacity_workgroups) {
 
 int mink_conv_set_pipeline(int mode) {
   const int old = g_compact_p3;
-  if (mode >= 0 && mode <= 7) g_compact_p3 = mode;  // (bit 2, measurement only: the two-stage form with the LDS footprint -- hence the occupancy -- of the three-stage one)
+  if (mode >= 0 && mode <= 15) g_compact_p3 = mode;  // (bit 2, measurement only: the two-stage form with the LDS footprint -- hence the occupancy -- of the three-stage one)
   return old;
 }
 
@@ -2806,6 +2922,7 @@ int mink_conv_plan_ksplit(int64_t n_out, int32_t K, int32_t cout, int32_t row_cl
 // (column tile, slice) pairs.  Turns the three-dimensional grid into the padded one-dimensional one the kernel decodes.
 static void compact_swizzle(GemmParams &p, dim3 &grid, int cin, int cout, int K) {
   p.swz_x = p.swz_y = p.swz_z = 0;
+  p.trace = nullptr;
   const int64_t wbytes = 4ll * K * cin * cout;
   const unsigned slices = grid.y * grid.z;
   if (wbytes <= (2ll << 20) || grid.x > 64 || slices < 16) return;
@@ -2823,6 +2940,10 @@ static bool compact_shape(int64_t n_rows, int K, int cin, int cout, int row_clas
   return zmin == 1 || zmin * 4 * n_rows * cout <= (128ll << 20);
 }
 static int compact_plan(int64_t n_rows, int K, int cout) {
+  if (g_compact_p3 & 8) {  // stream-K: the slab count of its plan
+    const SkPlan sk = sk_plan(n_rows, K, cout);
+    if (sk.G) return sk.S;
+  }
   constexpr int wg_cap = 2048;
   const int64_t tiles = cdiv(n_rows, 64) * cdiv(cout, BN);
   const int64_t slab_cap = std::max<int64_t>(1, (128ll << 20) / (4 * n_rows * cout));
@@ -2902,7 +3023,15 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
   p.kper = (int)cdiv(K, ksplit);
   p.stats = nullptr;
   p.swz_x = p.swz_y = p.swz_z = 0;
-  const int zs = (int)cdiv(K, p.kper);
+  p.trace = nullptr;
+  p.sk_q = p.sk_r = 0, p.sk_X = 0, p.sk_S = 0;
+  // stream-K (compact_gemm_kernel<.., SK>): a split stride-1 launch whose caller planned at least the slabs the plan needs
+  SkPlan sk = {0, 0};
+  if ((g_compact_p3 & 8) && ksplit > 1 && !row_perm && !(g_stagger & 0xFC) && !g_trace_buf && compact_shape(n_out, K, cin, cout, 0)) {
+    sk = sk_plan(n_out, K, cout);
+    if (sk.G == 0 || sk.S > ksplit) sk = {0, 0};
+  }
+  const int zs = sk.G ? ksplit : (int)cdiv(K, p.kper);  // (stream-K: exactly the slabs the caller planned; the spare ones are zeroed)
   const dim3 grid((unsigned)cdiv(n_virtual, BM), (unsigned)cdiv(cout, BN), (unsigned)zs);
   hipStream_t st = (hipStream_t)stream;
   const bool al = (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && (ldx & 3) == 0 && (cin & 3) == 0;
@@ -2961,7 +3090,7 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
   unsigned tiles_x = grid.x;  // row tiles that wrote statistics partials
   // (--math bf16 keeps the stride-1 mid layers on the dense bf16 kernel: the row-compacted form with one bf16 MFMA per block and item,
   //  measured round 5, is no faster there -- l1.conv2 57 / 60 us against 56 / 56 forward / data gradient, l3 48 / 58 against 44 / 46)
-  const bool compact = g_compact && g_math == 0 && vec && !row_perm && !p.accumulate && K >= 8 && p.kper <= CKP && cin >= 64 &&
+  const bool compact = g_compact && g_math == 0 && vec && !row_perm && !p.accumulate && K >= 8 && (p.kper <= CKP || sk.G) && cin >= 64 &&
                        cin % BK == 0 && cout % BN == 0 && (ldy & 3) == 0 && 4ll * K * cin * cout < (1ll << 31) &&
                        4ll * n_in * ldx < (1ll << 32) && (((uintptr_t)y | (uintptr_t)workspace | (uintptr_t)bias) & 15) == 0;
   if (compact) {  // row-compacted offsets, C tile in LDS (compact_gemm_kernel)
@@ -2977,7 +3106,13 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
     dim3 cgrid((unsigned)cdiv(n_out, CMT), grid.y, grid.z);
     tiles_x = cgrid.x;
     compact_swizzle(p, cgrid, cin, cout, K);
-    if (g_compact_p3 & 4) {  // (measurement only: two stages at three workgroups per CU)
+    if (sk.G) {
+      p.swz_x = 0;
+      const int64_t F = (int64_t)cdiv(n_out, CMT) * grid.y * K;
+      p.sk_q = (unsigned)(F / sk.G), p.sk_r = (unsigned)(F % sk.G), p.sk_X = (int)cdiv(n_out, CMT), p.sk_S = zs;
+      const int rc = w_transposed ? launch_compact_sk<true>(p, sk.G, st) : launch_compact_sk<false>(p, sk.G, st);
+      if (rc) return rc;
+    } else if (g_compact_p3 & 4) {  // (measurement only: two stages at three workgroups per CU)
       constexpr int smem3 = compact_smem(CMT, true);
       static const bool ok3 = hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<false, CMT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem3) == hipSuccess &&
                               hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<true, CMT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem3) == hipSuccess;
@@ -2989,7 +3124,8 @@ static int gather_gemm_impl(const float *x, int64_t n_in, int32_t ldx, int32_t c
       const int rc = w_transposed ? launch_compact_p3<true, false, 0>(p, cgrid, st) : launch_compact_p3<false, false, 0>(p, cgrid, st);
       if (rc) return rc;
     } else if (w_transposed) compact_gemm_kernel<true, CMT><<<cgrid, 256, smem, st>>>(p);
-    else if (g_stagger & 0xFC) {  // timing-only switches (kbench cab): the instantiation that carries them
+    else if ((g_stagger & 0xFC) || g_trace_buf) {  // timing-only switches (kbench cab) / phase trace (kbench ctrace): the instantiation that carries them
+      p.trace = (int64_t)cgrid.x * cgrid.y * cgrid.z <= g_trace_cap ? g_trace_buf : nullptr;
       static const bool abl_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&compact_gemm_kernel<false, CMT, false, true>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess;
       MINK_REQUIRE(abl_ok, "gather_gemm: %d bytes of LDS per workgroup refused", smem);

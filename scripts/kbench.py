@@ -324,6 +324,101 @@ if which == "perm":  # data gradient of the strided convolutions: row-compacted 
         Fn._PLAN_CACHE.clear()
         print("   max |compact - dense|", float((outs[0] - outs[1]).abs().max()), "max |dense|", float(outs[1].abs().max()),
               "bitwise repeatable:", bool(torch.equal(outs[0], outs[2])))
+if which == "ctrace":  # round 6: where a mid-layer forward launch's time goes, workgroup by workgroup (mink_conv_trace)
+    import ctypes
+    import numpy as np
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    for ts in (4, 8, 16, 32):
+        c = chans[ts]
+        nbr, _ = m.kernel_table(keys[ts], keys[ts], 3, 1)
+        xin = torch.randn(nbr.shape[0], c, device=dev)
+        w = torch.randn(27, c, c, device=dev) * 0.05
+        fn = lambda: Fn.gather_gemm(xin, w, nbr, c)
+        t_plain = timeit(fn, reps) * 1e3
+        cap = 8192
+        buf = torch.zeros(cap * 5, dtype=torch.int64, device=dev)
+        lib().mink_conv_trace(ctypes.c_void_p(buf.data_ptr()), cap)
+        t_traced = timeit(fn, reps) * 1e3
+        buf.zero_(); torch.cuda.synchronize()
+        fn(); torch.cuda.synchronize()
+        lib().mink_conv_trace(None, 0)
+        t = buf.cpu().numpy().reshape(cap, 5)
+        t = t[(t[:, 3] != 0) & (t[:, 0] != 0)]
+        t0, t1, t2, t3 = (t[:, i].astype(np.float64) for i in range(4))
+        hw, xcc = t[:, 4] & 0xFFFFFFFF, (t[:, 4] >> 32) & 0xF
+        cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
+        for cid in np.unique(cu):  # (the clock counters are not aligned across the chip: every CU from its own first start)
+            sel = cu == cid
+            base = t0[sel].min()
+            for a in (t0, t1, t2, t3):
+                a[sel] -= base
+        span = t3.max() - t0.min()
+        pro, loop, epi = t1 - t0, t2 - t1, t3 - t2
+        ncu = len(np.unique(cu))
+        q = lambda a: " / ".join(f"{np.percentile(a, p) / span * 100:5.1f}" for p in (10, 50, 90))
+        # per CU: the share of the launch's span during which at least one / on average how many of its workgroups are inside their item loop
+        any_loop, avg_loop, first_start, last_end = [], [], [], []
+        for cid in np.unique(cu):
+            sel = cu == cid
+            ev = sorted([(a, 1) for a in t1[sel]] + [(b, -1) for b in t2[sel]])
+            depth, last, busy, area = 0, t0.min(), 0.0, 0.0
+            for tt, d in ev:
+                if depth > 0:
+                    busy += tt - last
+                area += depth * (tt - last)
+                depth, last = depth + d, tt
+            any_loop.append(busy / span), avg_loop.append(area / span)
+            first_start.append((t1[sel].min() - t0.min()) / span), last_end.append((t3.max() - t2[sel].max()) / span)
+        print(f"l@{ts}.c2 fwd rows={nbr.shape[0]} {c}->{c}: {len(t)} workgroups on {ncu} CUs ({len(t) / ncu:.2f} per CU), conv + reduce {t_plain:.1f} us "
+              f"({t_traced:.1f} traced); clock span of the conv launch {span:.0f} ticks")
+        print(f"    per workgroup, % of the launch's span (10th / median / 90th percentile): prologue {q(pro)}   item loop {q(loop)}   epilogue + store drain {q(epi)}")
+        print(f"    per CU: some workgroup inside its item loop {np.mean(any_loop) * 100:.1f} % of the span, workgroups inside their loops on average "
+              f"{np.mean(avg_loop):.2f} (of 4 slots); first loop starts {np.mean(first_start) * 100:.1f} % in, last loop ends {np.mean(last_end) * 100:.1f} % before the end")
+        print(f"    sum of all (prologue, loop, epilogue) / (4 slots x CUs x span): {pro.sum() / (4 * ncu * span):.3f} {loop.sum() / (4 * ncu * span):.3f} {epi.sum() / (4 * ncu * span):.3f}"
+              f" -- the rest of the slot time has no workgroup in it; span {span:.0f} ticks = {span / 2.4e3:.1f} us at 2.4 GHz; median workgroup {np.median(t3 - t0) / 2.4e3:.1f} us")
+        # how the launch fills: resident workgroups per CU at 5 % steps of the span
+        grid_t = np.linspace(0, span, 21)
+        res = [(np.sum((t0 <= g) & (t3 > g)) / ncu) for g in grid_t]
+        print("    resident workgroups per CU at 0, 5, ... 100 % of the span: " + " ".join(f"{r:.1f}" for r in res))
+        starts = np.sort(t0)
+        print(f"    workgroup starts: the first {min(1024, len(starts))} within {starts[min(1024, len(starts)) - 1] / 2.4e3:.1f} us; the last start at {starts[-1] / 2.4e3:.1f} us")
+if which == "sk":  # round 6: stream-K launches of the stride-1 mid-layer kernel (mink_conv_set_pipeline bit 3) against the (row tile, slice) grid
+    from nerf_downstream_amd._lib import lib
+    keys = {1: k1}
+    for ts in (2, 4, 8, 16, 32):
+        keys[ts] = m.stride(keys[ts // 2], 2)
+    chans = {2: 64, 4: 64, 8: 128, 16: 256, 32: 512}
+    tot = {0: 0.0, 8: 0.0}
+    for ts in (4, 8, 16, 32):
+        c = chans[ts]
+        nbr, _ = m.kernel_table(keys[ts], keys[ts], 3, 1)
+        w = torch.randn(27, c, c, device=dev) * 0.05
+        x2 = torch.randn(nbr.shape[0], c, device=dev)
+        gy = torch.randn(nbr.shape[0], c, device=dev)
+        ref = None
+        for name, fn in ((f"l@{ts}.c2 fwd   rows={nbr.shape[0]:6d} {c}->{c}", lambda: Fn.gather_gemm(x2, w, nbr, c)),
+                         (f"l@{ts}.c2 dgrad rows={nbr.shape[0]:6d} {c}->{c}", lambda: Fn.gather_gemm(gy, w, nbr, c, w_transposed=True, flip_k=True))):
+            tt, out, ks = {}, {}, {}
+            for mode in (0, 8, 0, 8):
+                lib().mink_conv_set_pipeline(mode)
+                Fn._PLAN_CACHE.clear()
+                t = timeit(fn, reps) * 1e3
+                tt[mode] = min(tt.get(mode, 1e9), t)
+                o = fn()
+                if mode in out:
+                    assert torch.equal(o, out[mode]), "not repeatable"
+                out[mode] = o
+                ks[mode] = Fn._plan_ksplit(lib(), nbr.shape[0], 27, c, c, 0)
+            lib().mink_conv_set_pipeline(0)
+            Fn._PLAN_CACHE.clear()
+            err = float((out[0] - out[8]).abs().max() / out[0].abs().max())
+            tot[0] += tt[0]; tot[8] += tt[8]
+            print(f"{name}: grid {tt[0]:7.1f} us ({ks[0]} slabs), stream-K {tt[8]:7.1f} us ({ks[8]} slabs) ({(tt[8] / tt[0] - 1) * 100:+5.1f} %), max rel diff {err:.1e}")
+    print(f"sum: grid {tot[0]:.1f} us, stream-K {tot[8]:.1f} us")
 if which == "p3":  # round 6: the three-stage form of compact_gemm_kernel (mink_conv_set_pipeline) against the two-stage one, bit for bit
     from nerf_downstream_amd._lib import lib
     keys = {1: k1}

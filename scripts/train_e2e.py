@@ -131,7 +131,10 @@ def main():
         print(p.stdout[-4000:])
         raise SystemExit(f"trainer failed (rc {p.returncode})")
     tail = its[len(its) // 3:]
-    print(f"[e2e] co3d_3d.train CLI, ResNet14 B=16 fp32, {args.form} samples, staging={args.staging}, {args.workers} DataLoader workers, "
+    direct = args.form == "compact" and args.staging != "0" and os.environ.get("MINK_DIRECT_LOADER", "1") != "0"
+    feed = (f"direct reader ({max(2, min(8, args.workers))} threads: scene files -> pinned buffers)" if direct else
+            f"DataLoader, {args.workers} worker processes" + (", pinned staging + copy stream" if args.staging != "0" else ", pageable copies on the compute stream"))
+    print(f"[e2e] co3d_3d.train CLI, ResNet14 B=16 fp32, {args.form} samples, {feed}, "
           f"{args.steps} steps ({wall:.0f} s wall incl. start-up and the final validation): train/iter_time over windows of {log_every} steps (ms): "
           + " ".join(f"{t * 1e3:.2f}" for t in its) + f" | sustained (last two thirds): {np.mean(tail) * 1e3:.2f} ms per step", flush=True)
 

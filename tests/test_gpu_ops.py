@@ -816,6 +816,65 @@ def test_permuted_rows_kernel_on_the_bf16_matrix_cores(n_out, K, cin, cout, pure
         ME.set_conv_math(old)
 
 
+@pytest.mark.parametrize("n_out,cin,cout", [(36754, 64, 64), (8355, 128, 128), (20000, 64, 128), (16000, 128, 64)])
+def test_stream_k_launch_of_the_mid_layer_kernel(n_out, cin, cout):
+    """Round 6's second structural variant (compact_gemm_kernel<.., SK>, mink_conv_set_pipeline bit 3): ONE resident round of 1,024 workers,
+    each taking an equal run of the launch's (tile, offset) pairs in tile-major order -- a run crosses tile boundaries, so a worker
+    processes up to three segments (tile, offset range), writes each into the slab (worker - first worker of the tile), and the worker that
+    finishes a tile zeroes the slabs nobody wrote.  Checked here at the row counts where the plan takes it (a run of >= 5 offsets): against
+    a float64 sum of the same products (the bound of the grid form: one fp32 chain per output element and slab), against the grid form
+    (another partition of a tile's offsets into slabs: not bitwise), repeatable bit for bit, forward and same-map data gradient, on
+    a ragged table with an empty offset and rows without neighbours; and that the plan really switched (slab counts may differ).
+    It measured within 2 % of the grid form (profiles/r06_stream_k.txt) and stays off."""
+    from nerf_downstream_amd._lib import lib
+    from nerf_downstream_amd.minkowski import functional as Fn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(n_out + cin)
+    K = 27
+    n_in = n_out
+    nbr = torch.randint(0, n_in, (n_out, K), generator=g, dtype=torch.int32)
+    nbr[torch.rand(n_out, K, generator=g) < 0.48] = -1
+    nbr[:, 13] = -1
+    nbr[n_out // 5 : n_out // 5 + 70] = -1  # a whole tile and more without neighbours
+    x = torch.randn(n_in, cin, generator=g).to(dev)
+    w = (torch.randn(K, cin, cout, generator=g) * 0.1).to(dev)
+    gy = torch.randn(n_out, cout, generator=g).to(dev)
+    nd = nbr.to(dev)
+    L = lib()
+    cases = {"fwd": lambda: Fn.gather_gemm(x, w, nd, cout), "dgrad": lambda: Fn.gather_gemm(gy, w, nd, cin, w_transposed=True, flip_k=True)}
+    sel = torch.arange(0, n_out, max(1, n_out // 257))  # float64 on a sample of rows (every 64-row tile phase, both ends)
+    sel = torch.cat([sel, torch.tensor([0, 63, 64, n_out - 1])]).unique()
+    try:
+        for name, fn in cases.items():
+            out = {}
+            for mode in (0, 8):
+                L.mink_conv_set_pipeline(mode)
+                Fn._PLAN_CACHE.clear()
+                out[mode] = fn()
+                assert torch.equal(out[mode], fn()), (name, mode)
+            src, wk, co = (x, w, cout) if name == "fwd" else (gy, w.transpose(1, 2), cin)
+            ref = torch.zeros(len(sel), co, dtype=torch.float64, device=dev)
+            for k in range(K):
+                kk = k if name == "fwd" else K - 1 - k
+                col = nd[sel.to(dev), k].long()
+                ok = col >= 0
+                ref[ok] += src[col[ok]].double() @ wk[kk].double()
+            scale = float(ref.abs().max())
+            for mode in (0, 8):
+                err = float((out[mode][sel.to(dev)].double() - ref).abs().max()) / scale
+                assert err < 3e-6, (name, mode, err)
+            assert float((out[0] - out[8]).abs().max()) / scale < 3e-6, name
+            assert not torch.equal(out[0], out[8]) or True  # (equal only by accident: another summation order)
+        L.mink_conv_set_pipeline(8)
+        Fn._PLAN_CACHE.clear()
+        ks_sk = Fn._plan_ksplit(L, n_out, K, cin, cout, 0)
+        assert 2 <= ks_sk <= 8, ks_sk  # ceil(27 / run) + 1 with a run of >= 5 offsets
+    finally:
+        L.mink_conv_set_pipeline(0)
+        Fn._PLAN_CACHE.clear()
+
+
 @pytest.mark.parametrize("n_out,K,cin,cout,perm_rows", [(130, 27, 64, 64, False), (1000, 27, 128, 128, False), (517, 27, 256, 64, False),
                                                          (64, 27, 64, 64, False), (700, 27, 128, 64, True), (300, 9, 512, 64, True),
                                                          (2100, 27, 64, 64, True)])
