@@ -8,10 +8,10 @@ out=gpurun_out/$tag
 # (GIT_HEAD=<commit> in the environment is recorded next to the PMC summary: the box has no .git;
 #  BENCH_ARGS="--math bf16 --storage bf16" profiles another configuration of bench.py)
 mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/trace -o bench --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline $BENCH_ARGS > $out/trace.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d $out/trace -o bench --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs $BENCH_ARGS > $out/trace.log 2>&1 || exit 1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --pmc $pass -d $out/pmc_$name -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing $BENCH_ARGS > $out/pmc_$name.log 2>&1 || exit 1
+  rocprofv3 --pmc $pass -d $out/pmc_$name -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs --no-kernel-timing $BENCH_ARGS > $out/pmc_$name.log 2>&1 || exit 1
   echo "pass $name done"
 done
 python scripts/trace_summary.py $out/trace 0 60 > $out/trace_summary.txt
