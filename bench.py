@@ -144,8 +144,9 @@ def pmc_traffic(tag, meta):
 
     # a profile of the configuration that is running: profiles/<tag>_pmc.json for the default (fp32) bench,
     # profiles/<tag>_bf16s_pmc.json for --math bf16 --storage bf16 (scripts/profile_round.sh with BENCH_ARGS)
-    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))
-                    if f.endswith("_bf16s_pmc.json") == (PMC_CONFIG == "bf16s")), key=natural)
+    # (profiles of other configurations -- profiles/<tag>_r34b4_pmc.json: Mink-ResNet34 at four scenes -- are not this run's kernels)
+    want_name = re.compile(r"r\d+_v\d+_bf16s_pmc\.json$" if PMC_CONFIG == "bf16s" else r"r\d+_v\d+_pmc\.json$")
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")) if want_name.search(os.path.basename(f))), key=natural)
     if not files or PMC_CONFIG is None:
         return None, None
     source = {"profile": os.path.basename(files[-1]), "git_head_of_profile": "unknown"}
@@ -252,7 +253,13 @@ class Job:
         if dev.type == "cuda" and os.environ.get("BENCH_TORCH_SGD", "0") == "0":
             from nerf_downstream_amd.parallel import FlatSGD
 
-            self.opt = FlatSGD(self.reducer, lr=0.1, momentum=0.9, weight_decay=1e-4)
+            # (BENCH_SGD_IN_BACKWARD=1, one rank: the update of a bucket goes out from inside the backward call as soon as its gradients
+            #  are complete -- parallel.FlatSGD(in_backward=True).  MEASURED (A/B on one box, two alternations): 3.50 / 3.52 ms against
+            #  3.46 / 3.46 for the one kernel behind the backward pass, --math bf16 2.16 / 2.27 against 2.02 / 2.04, Mink-ResNet34 at
+            #  four scenes 4.05 against 3.87: what the per-block ordering of the weight-gradient stream behind the compute stream costs
+            #  is more than the 55 / 280 us of update it moves off the end of the step -- OFF by default.)
+            self.opt = FlatSGD(self.reducer, lr=0.1, momentum=0.9, weight_decay=1e-4,
+                               in_backward=os.environ.get("BENCH_SGD_IN_BACKWARD", "0") != "0")
         else:
             self.opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=dev.type == "cuda")
         self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=200000)

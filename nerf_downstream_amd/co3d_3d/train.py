@@ -231,7 +231,8 @@ def train(
         # the same update as torch.optim.SGD, as one kernel over the flat parameter / gradient / momentum buffers
         from nerf_downstream_amd.parallel import FlatSGD
 
-        optimizer = FlatSGD.like(optimizer, reducer)
+        # (MINK_SGD_IN_BACKWARD=1, one rank: a bucket's update is launched from inside the backward call; measured slower, bench.py)
+        optimizer = FlatSGD.like(optimizer, reducer, in_backward=world == 1 and os.environ.get("MINK_SGD_IN_BACKWARD", "0") != "0")
     scheduler = get_scheduler(scheduler_name, optimizer, warmup_steps)
     csv_logger = CSVLogger(save_path, run_name, resume=resume_training) if rank == 0 and "csv" in loggers else None
     for name in loggers:

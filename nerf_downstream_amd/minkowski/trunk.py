@@ -484,7 +484,7 @@ class TrunkFunction(torch.autograd.Function):
             sd.conv.dw = gw_pad.data_ptr() if pad else ptrs[0]
             sd.norm.dgamma, sd.norm.dbeta = ptrs[1], ptrs[2]
         g_buf = torch.empty(grad_floats, dtype=torch.float32, device=dev)
-        collect = views is not None and getattr(sink, "_collect", False)
+        collect = views is not None and (getattr(sink, "_collect", False) or getattr(sink, "_bucket_cb", None) is not None)
         evp, hook_err = None, []
         in_call = collect and _DP_LAUNCH_IN_CALL and hasattr(sink, "stage_stream")
         if in_call:
