@@ -105,6 +105,8 @@ def test_direct_loader_declines_what_it_cannot_serve(tmp_path, monkeypatch):
     np.savez_compressed(tmp_path / "data" / "plenoxel_co3d_s1" / "data.npz", **{k: z[k] for k in z.files})
     ds = Co3DDataset("train", data_root=str(tmp_path / "data"), features=("sh",), compact=True)
     staging.DirectCompactLoader._LAYOUTS.clear()
+    assert not staging.DirectCompactLoader.usable(ds, probe=10)  # the probe finds it: the trainer takes the DataLoader path for this tree
+    assert staging.DirectCompactLoader.usable(ds, probe=2)       # (first and last scene only: both fine)
     ld = staging.DirectCompactLoader(ds, iter([0, 1]), 2, _HostStager(), threads=2)
     with pytest.raises(RuntimeError, match="MINK_DIRECT_LOADER=0"):
         ld.next()
