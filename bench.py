@@ -294,7 +294,8 @@ class Job:
         model, reducer, opt, state, batches = self.model, self.reducer, self.opt, self.state, self.batches
         tf = state["tf"]
         side = getattr(model, "_side", None)
-        Fn.log_phase("step_begin", torch.cuda.current_stream())
+        cur = Fn.current_stream() if Fn._PHASE_LOG is not None else None  # (the phase marks are a diagnostic: no Stream object per mark otherwise)
+        Fn.log_phase("step_begin", cur)
         Fn.log_phase("pyramid_begin", side)
         nb = (i + 1) % len(batches)
         fut = None
@@ -306,12 +307,12 @@ class Job:
             nxt = model.process_input(batches[nb], defer=True)
         Fn.log_phase("pyramid_end", side)
         reducer.zero_grad()
-        Fn.log_phase("grads_cleared", torch.cuda.current_stream())
+        Fn.log_phase("grads_cleared", cur)
         out = model(tf)
-        Fn.log_phase("forward_queued", torch.cuda.current_stream())
+        Fn.log_phase("forward_queued", cur)
         loss = self.cross_entropy(out, self.labels_dev[i % len(batches)])  # the trainer's own loss call (classification_training.py)
         loss.backward()
-        Fn.log_phase("backward_queued", torch.cuda.current_stream())
+        Fn.log_phase("backward_queued", cur)
         Fn.log_phase("maps_begin", side)
         if fut is not None:
             state["tf"] = fut.result()
@@ -324,7 +325,7 @@ class Job:
         Fn.log_phase("maps_end", side)
         reducer.finish()
         opt.step()
-        Fn.log_phase("step_end", torch.cuda.current_stream())
+        Fn.log_phase("step_end", cur)
         self.sched.step()
         return loss
 

@@ -28,6 +28,12 @@ def _stream():
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
+def _Fn():  # (functional imports this module: resolved at call time)
+    from . import functional
+
+    return functional
+
+
 def _as_int(v):
     if isinstance(v, (list, tuple)):
         assert all(int(s) == int(v[0]) for s in v), "anisotropic strides/kernels are not supported"
@@ -427,7 +433,7 @@ class CoordinateManager:
         )
         meta_host = torch.empty(nlev + 2, dtype=torch.int32, pin_memory=True)
         meta_host.copy_(meta, non_blocking=True)
-        done = torch.cuda.current_stream(dev).record_event()
+        done = _Fn().current_stream(dev).record_event()
         self._pending_field = (n, ts_list, cap, tkeys, tvals, coords, index_a, index_b, meta_host, done, fc, ws)
         if not defer:
             self.finish_field()
@@ -482,14 +488,14 @@ class CoordinateManager:
     def _note_lazy(self, *tensors):
         if self._replaying or not torch.cuda.is_available():
             return
-        cur = torch.cuda.current_stream(self.device)
+        cur = _Fn().current_stream(self.device)
         self._lazy_marks.append((cur, cur.record_event(), [t for t in tensors if t is not None]))
         self._lazy_seen[cur] = len(self._lazy_marks)
 
     def _sync_lazy(self):
         if not self._lazy_marks:
             return
-        cur = torch.cuda.current_stream(self.device)
+        cur = _Fn().current_stream(self.device)
         seen = self._lazy_seen.get(cur, 0)
         for st, ev, tensors in self._lazy_marks[seen:]:
             if st != cur:

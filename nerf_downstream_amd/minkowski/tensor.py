@@ -108,7 +108,7 @@ class TensorField:
         self._F, self._C = features, coordinates
         m = self._manager = CoordinateManager(D=coordinates.shape[1] - 1, device=coordinates.device)
         self._plan, self._ready = plan, None
-        self._build_stream = torch.cuda.current_stream(coordinates.device)
+        self._build_stream = Fn.current_stream(coordinates.device)
         defer = bool(defer) and plan is not None
         self.coordinate_field_map_key = m.insert_field(coordinates, CoordinateManager.plan_stride_chain(plan), defer=defer)
         if not defer:
@@ -150,7 +150,7 @@ class TensorField:
         m = self._manager
         self.finish()
         if self._ready is not None:  # maps were built ahead of time on another stream
-            cur = torch.cuda.current_stream()
+            cur = Fn.current_stream()
             cur.wait_event(self._ready)
             m.hand_over(cur)
             for t in (self._F, self._C):  # may have been produced on the build stream (GPU-side decode)

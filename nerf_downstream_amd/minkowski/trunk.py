@@ -340,7 +340,7 @@ class TrunkFunction(torch.autograd.Function):
         nbr_pool = _table(m, 1, 2, 2)[0]
         i2o = m.in2out[(1, 2)] if m.prepared else m.stride_map(CoordinateMapKey(1), CoordinateMapKey(2))
         n0, n1 = x.shape[0], nbr_pool.shape[0]
-        cur = torch.cuda.current_stream(dev)
+        cur = Fn.current_stream(dev)
         br = _branch(dev, cur) if (fork and m.prepared) else cur
         # ---- the level records of this batch (level l = tensor stride 2 << l)
         lv, tables, rows = plan.levels, [], []
@@ -417,7 +417,7 @@ class TrunkFunction(torch.autograd.Function):
                     overlap = False
                     break
             overlap = overlap and not torch.is_grad_enabled()
-        cur = torch.cuda.current_stream(dev)
+        cur = Fn.current_stream(dev)
         br = _branch(dev, cur) if (ctx.fork and m.prepared) else cur
         side = Fn._side_stream(dev) if overlap else cur
         C0 = w0p.shape[-1]

@@ -329,8 +329,9 @@ class BucketedGradAllReduce:
     def zero_grad(self):
         """Gradients accumulate into the flat buffer; clear it with one memset per step."""
         if self.flat.is_cuda:
-            self._home = torch.cuda.current_stream(self.flat.device)
             from .minkowski import functional as Fn
+
+            self._home = Fn.current_stream(self.flat.device)
 
             if self._collect:  # last step's collectives were launched from the side streams (one rank: every gradient
                 # write of the last backward pass was joined by its end-of-backward callback -- no barrier packets here)
@@ -473,7 +474,7 @@ class FlatSGD(torch.optim.Optimizer):
         if g.get("dampening", 0) or g.get("nesterov", False) or g.get("maximize", False):
             raise ValueError("FlatSGD: dampening / Nesterov / maximize are not implemented")
         flat = self.reducer.flat
-        raw = torch.cuda.current_stream(flat.device).cuda_stream
+        raw = torch._C._cuda_getCurrentRawStream(flat.device.index if flat.device.index is not None else torch.cuda.current_device())
         if self._stepped:  # the slices the backward pass did not update itself (they are few: ascending, merged where adjacent)
             done, pos, todo = sorted(self._stepped), 0, []
             self._stepped = []
