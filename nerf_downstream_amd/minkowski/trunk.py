@@ -272,7 +272,14 @@ def _stage_hook(stage, backward):
 _HOOK_C = STAGE_HOOK(_stage_hook)
 
 
-def _arm_hook(L, cur, fwd_skew=(), bwd_skew=()):
+def _arm_hook(L, cur, fwd_skew=(), bwd_skew=(), n_stages=None):
+    if Fn._PREPARE_GATE and n_stages is not None and not _HOOK_STATE.get("gate_checked"):
+        _HOOK_STATE["gate_checked"] = True
+        if not -1 <= Fn._PREPARE_GATE[1] < n_stages:  # (a gate point no pass ever reaches: the map builds would simply never be held back)
+            import warnings
+
+            warnings.warn(f"MINK_PREPARE_GATE names block {Fn._PREPARE_GATE[1]} of a trunk with {n_stages} blocks: the gate never fires "
+                          "and the map builds follow the host as without it")
     want = bool(Fn._SKEW) or Fn._PHASE_LOG is not None or bool(Fn._PREPARE_GATE)
     st = _HOOK_STATE
     if want:
@@ -383,7 +390,7 @@ class TrunkFunction(torch.autograd.Function):
         else:
             xb_pre = None
         arena = torch.empty(act_floats, dtype=torch.float32, device=dev)
-        _arm_hook(L, cur, fwd_skew=(br,) if (Fn._SKEW and br != cur) else ())
+        _arm_hook(L, cur, fwd_skew=(br,) if (Fn._SKEW and br != cur) else (), n_stages=len(plan.stages))
         net = plan.net
         check(L.mink_net_forward(ctypes.byref(net), lv, plan.n_levels, arena.data_ptr(), act_floats, exp))
         if Fn._TIMING_MODE == 1:
